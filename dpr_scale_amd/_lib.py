@@ -1,0 +1,69 @@
+"""ctypes binding of libdprhot.so (include/dprhot.h).  There is no CPU fallback: if the library is missing
+or fails to load, importing this module raises -- the product path must fail loudly (it never routes
+through oracle/)."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("DPRHOT_LIB", os.path.join(_HERE, "libdprhot.so"))
+
+if not os.path.isfile(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C dpr_scale_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback."
+    )
+
+try:  # torch first, so that libamdhip64.so.7 resolves to the runtime torch already loaded (one HIP runtime)
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - the library also works without torch (system ROCm runtime)
+    torch = None
+
+lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+
+# name -> (restype, argtypes); must list every symbol include/dprhot.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "dprhot_version": (c_int, []),
+    "dprhot_last_error": (c_char_p, []),
+    "dprhot_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
+    "dprhot_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_sim_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "dprhot_softmax_ce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dprhot_reduce_sum": (c_int, [c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "dprhot_dq": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                          c_size_t, c_void_p]),
+    "dprhot_dc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "dprhot_rank_of_gold": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
+    "dprhot_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dprhot_inbatch_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
+                                   c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    "dprhot_inbatch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == ABI mismatch: fail at import
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class DprhotError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib.dprhot_last_error()
+        raise DprhotError(f"{what or 'dprhot'} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def version() -> int:
+    return lib.dprhot_version()
+
+
+def workspace_bytes(B: int, Nc: int, d: int) -> int:
+    out = c_size_t(0)
+    check(lib.dprhot_workspace_bytes(B, Nc, d, ctypes.byref(out)), "dprhot_workspace_bytes")
+    return out.value

@@ -1,0 +1,259 @@
+// rowwise.h -- HBM-bound row kernels of the in-batch contrastive path (gfx950, wave64).
+//   softmax_ce_kernel : nn.CrossEntropyLoss (dpr_task.py:46,212) + its backward into dScores, one launch
+//   rank_kernel       : compute_rank_metrics (dpr_task.py:235-246) as a count, no sort
+//   topk_kernel       : torch.topk epilogue of run_retrieval_pytorch.py:149-150
+//   cast / reduce helpers
+// All global accesses are 16-byte vectors, lanes consecutive (1 KiB per wave instruction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dprhot {
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// (max, sum of exp relative to max) pairs combine associatively; -inf max carries sum 0.
+__device__ __forceinline__ void ms_combine(float& m, float& s, float m2, float s2) {
+  const float M = fmaxf(m, m2);
+  if (M == -INFINITY) { m = M; s = 0.f; return; }
+  s = s * __expf(m - M) + s2 * __expf(m2 - M);
+  m = M;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// fp32 -> bf16
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n8; c += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * c];
+    const float4 b = reinterpret_cast<const float4*>(src)[2 * c + 1];
+    uint4 o;
+    o.x = f32_to_bf16_rne(a.x) | ((uint32_t)f32_to_bf16_rne(a.y) << 16);
+    o.y = f32_to_bf16_rne(a.z) | ((uint32_t)f32_to_bf16_rne(a.w) << 16);
+    o.z = f32_to_bf16_rne(b.x) | ((uint32_t)f32_to_bf16_rne(b.y) << 16);
+    o.w = f32_to_bf16_rne(b.z) | ((uint32_t)f32_to_bf16_rne(b.w) << 16);
+    reinterpret_cast<uint4*>(dst)[c] = o;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Row softmax cross-entropy + dScores.  TPR threads cooperate on one row (64 = one wave, 256 = the block);
+// a block handles 256 / TPR rows.  Pass 1 streams the row once (online max/sum); pass 2 re-reads it (the
+// row is L2-resident: <= 256 KiB) and emits G in bf16.  Algorithmic HBM bytes: 4 (S read) + 2 (G write)
+// per score.
+// ----------------------------------------------------------------------------------------------------
+struct SoftmaxArgs {
+  const float* S;
+  int B, Nc;
+  const int64_t* y;
+  int64_t y_offset;
+  float grad_scale;
+  const int64_t* row_win_start;  // optional [B]
+  int win_len;
+  float* row_loss;
+  float* row_lse;
+  uint16_t* G;
+};
+
+template <int TPR>
+__global__ __launch_bounds__(256) void softmax_ce_kernel(SoftmaxArgs p) {
+  constexpr int RPB = 256 / TPR;
+  const int tid = threadIdx.x;
+  const int sub = tid / TPR, t = tid % TPR;
+  const int row = blockIdx.x * RPB + sub;
+  __shared__ float sm_m[4], sm_s[4];
+  const bool active = row < p.B;
+  const float* Srow = p.S + (size_t)(active ? row : 0) * p.Nc;
+  int lo = 0, hi = p.Nc;
+  if (p.row_win_start != nullptr && active) {
+    lo = (int)(p.row_win_start[row] + p.y_offset);
+    hi = lo + p.win_len;
+  }
+  const bool windowed = p.row_win_start != nullptr;
+
+  float m = -INFINITY, s = 0.f;
+  if (active) {
+    for (int j = t * 4; j < p.Nc; j += TPR * 4) {
+      float4 v = *reinterpret_cast<const float4*>(Srow + j);
+      if (windowed) {
+        if (j + 0 < lo || j + 0 >= hi) v.x = -INFINITY;
+        if (j + 1 < lo || j + 1 >= hi) v.y = -INFINITY;
+        if (j + 2 < lo || j + 2 >= hi) v.z = -INFINITY;
+        if (j + 3 < lo || j + 3 >= hi) v.w = -INFINITY;
+      }
+      const float lm = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+      if (lm > m) {  // rescale only when the running max moves
+        s *= __expf(m - lm);  // m == -inf -> s == 0 * 0
+        m = lm;
+      }
+      if (m != -INFINITY) s += __expf(v.x - m) + __expf(v.y - m) + __expf(v.z - m) + __expf(v.w - m);
+    }
+  }
+  // combine across the TPR threads of the row
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    ms_combine(m, s, m2, s2);
+  }
+  if constexpr (TPR == 256) {
+    const int w = tid >> 6;
+    if ((tid & 63) == 0) { sm_m[w] = m; sm_s[w] = s; }
+    __syncthreads();
+    m = sm_m[0]; s = sm_s[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) ms_combine(m, s, sm_m[k], sm_s[k]);
+  }
+  if (!active) return;
+  const float lse = m + logf(s);
+  const int64_t yi = p.y[row] + p.y_offset;
+  if (t == 0) {
+    if (p.row_lse) p.row_lse[row] = lse;
+    if (p.row_loss) p.row_loss[row] = lse - Srow[yi];
+  }
+  if (p.G == nullptr) return;
+  uint16_t* Grow = p.G + (size_t)row * p.Nc;
+  const float gs = p.grad_scale;
+  for (int j = t * 8; j < p.Nc; j += TPR * 8) {
+    const float4 a = *reinterpret_cast<const float4*>(Srow + j);
+    const float4 b = *reinterpret_cast<const float4*>(Srow + j + 4);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = j + e;
+      float pr = (windowed && (col < lo || col >= hi)) ? 0.f : __expf(v[e] - lse);  // exp(-inf) == 0
+      if (col == yi) pr -= 1.0f;
+      const uint16_t h = f32_to_bf16_rne(pr * gs);
+      if (e & 1) o[e >> 1] |= (uint32_t)h << 16; else o[e >> 1] = h;
+    }
+    *reinterpret_cast<uint4*>(Grow + j) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// out[0] = scale * sum(x[0..n))   single workgroup, fixed order -> deterministic
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float scale, float* out) {
+  __shared__ float sm[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) * scale;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// split-K combine: out[i] = scale * sum_z part[z][i]      (n4 = elements / 4)
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, size_t n4, float h_scale,
+                                                            const float* d_scale, float* __restrict__ out) {
+  const float sc = h_scale * (d_scale ? *d_scale : 1.0f);
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n4; c += (size_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(part)[c];
+    for (int z = 1; z < splits; ++z) {
+      const float4 b = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + c];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
+    reinterpret_cast<float4*>(out)[c] = a;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// rank of the gold column: 1 + #{S > gold} + #{S == gold, j < y}      one workgroup per row
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, int rows, int cols, const int64_t* __restrict__ y,
+                                                   int64_t y_offset, int64_t* __restrict__ rank) {
+  const int row = blockIdx.x;
+  const float* Srow = S + (size_t)row * cols;
+  const int yi = (int)(y[row] + y_offset);
+  const float gold = Srow[yi];
+  int cnt = 0;
+  const int c4 = cols & ~3;
+  for (int j = threadIdx.x * 4; j < c4; j += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(Srow + j);
+    cnt += (v.x > gold) + (v.y > gold) + (v.z > gold) + (v.w > gold);
+    cnt += (v.x == gold && j + 0 < yi) + (v.y == gold && j + 1 < yi) + (v.z == gold && j + 2 < yi) + (v.w == gold && j + 3 < yi);
+  }
+  for (int j = c4 + threadIdx.x; j < cols; j += 256) {
+    const float v = Srow[j];
+    cnt += (v > gold) + (v == gold && j < yi);
+  }
+  __shared__ int sm[4];
+  cnt = wave_sum_i(cnt);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) rank[row] = 1 + (int64_t)(sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// top-k per row by repeated selection in the total order (score desc, column asc): round r picks the
+// best element strictly after the previous pick.  O(k * cols) reads of an L2-resident row; exact and
+// deterministic (ties by lower column).  One workgroup per row.
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool before(float v1, int j1, float v2, int j2) {  // (v1,j1) ranks ahead of (v2,j2)
+  return v1 > v2 || (v1 == v2 && j1 < j2);
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ S, int rows, int cols, int k, float* __restrict__ values,
+                                                   int64_t* __restrict__ indices) {
+  const int row = blockIdx.x;
+  const float* Srow = S + (size_t)row * cols;
+  __shared__ float sv[4];
+  __shared__ int sj[4];
+  __shared__ float pv;
+  __shared__ int pj;
+  float lastv = INFINITY;
+  int lastj = -1;
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int j = threadIdx.x; j < cols; j += 256) {
+      const float v = Srow[j];
+      if (v != v) continue;  // NaN never selected
+      const bool after_last = (lastj < 0) || before(lastv, lastj, v, j);
+      if (after_last && before(v, j, bv, bj)) { bv = v; bj = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bv, o, 64);
+      const int j2 = __shfl_xor(bj, o, 64);
+      if (before(v2, j2, bv, bj)) { bv = v2; bj = j2; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; sj[threadIdx.x >> 6] = bj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float v = sv[0]; int j = sj[0];
+      for (int w = 1; w < 4; ++w) if (before(sv[w], sj[w], v, j)) { v = sv[w]; j = sj[w]; }
+      pv = v; pj = j;
+      values[(size_t)row * k + r] = v;
+      indices[(size_t)row * k + r] = (j == 0x7fffffff) ? -1 : (int64_t)j;
+    }
+    __syncthreads();
+    lastv = pv; lastj = pj;
+    __syncthreads();
+  }
+}
+
+}  // namespace dprhot

@@ -1,0 +1,304 @@
+// selftest.hip -- standalone (no Python, no torch) check + timing of every libdprhot entry point against
+// a double-precision host computation of the same formulas.  Used on the GPU box:
+//   ./selftest            all shapes, default kernel selection
+//   ./selftest time       plus hipEvent timings
+//   DPRHOT_TILE=2 DPRHOT_NO_TR=1 ./selftest      pin a tile / swap the transpose read for 16-bit gathers
+// Also dumps what ds_read_b64_tr_b16 returns for a known LDS image ("trdump").
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/dprhot.h"
+
+#define CK(x)                                                                         \
+  do {                                                                                \
+    hipError_t e = (x);                                                               \
+    if (e != hipSuccess) {                                                            \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__);    \
+      exit(2);                                                                        \
+    }                                                                                 \
+  } while (0)
+#define OK(x)                                                                   \
+  do {                                                                          \
+    int rc = (x);                                                               \
+    if (rc != 0) {                                                              \
+      printf("dprhot error %d (%s) at line %d\n", rc, dprhot_last_error(), __LINE__); \
+      exit(3);                                                                  \
+    }                                                                           \
+  } while (0)
+
+static uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static float bf2f(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static double urand() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return (double)(rng_state >> 11) / 9007199254740992.0;
+}
+static float nrand() {
+  double u1 = urand() + 1e-12, u2 = urand();
+  return (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+}
+
+template <class T>
+struct Dev {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit Dev(size_t n_) : n(n_) { CK(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16))); }
+  ~Dev() { hipFree(p); }
+  void up(const std::vector<T>& h) { CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> down() const {
+    std::vector<T> h(n);
+    CK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+};
+
+__global__ void trdump_kernel(uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[64 * 4];
+  for (int i = threadIdx.x; i < 256; i += 64) lds[i] = (uint16_t)i;
+  __syncthreads();
+  typedef short v4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) v4 lv4;
+  v4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4*)(lds + threadIdx.x * 4));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)r[j];
+}
+
+static int g_fail = 0;
+static void report(const char* what, double err, double tol) {
+  const bool ok = err <= tol;
+  printf("    %-28s err %.3e (tol %.1e) %s\n", what, err, tol, ok ? "ok" : "FAIL");
+  if (!ok) ++g_fail;
+}
+
+static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool timing) {
+  printf("case B=%d Nc=%d d=%d T=%g ragged=%d\n", B, Nc, d, T, (int)ragged);
+  const float dscale = powf((float)d, -0.25f);
+  std::vector<uint16_t> hQ((size_t)B * d), hC((size_t)Nc * d);
+  std::vector<float> fQ((size_t)B * d), fC((size_t)Nc * d);
+  for (size_t i = 0; i < hQ.size(); ++i) { hQ[i] = f2bf(nrand() * dscale); fQ[i] = bf2f(hQ[i]); }
+  for (size_t i = 0; i < hC.size(); ++i) { hC[i] = f2bf(nrand() * dscale); fC[i] = bf2f(hC[i]); }
+  std::vector<int64_t> hy(B);
+  std::vector<uint8_t> hm(Nc, 0);
+  for (int i = 0; i < B; ++i) hy[i] = ((int64_t)i * K + 3 * Nc / 8) % Nc;  // not aligned with the row tiling
+  if (ragged)
+    for (int j = 0; j < Nc; ++j) hm[j] = urand() < 0.05;
+  for (int i = 0; i < B; ++i) hm[hy[i]] = 0;
+
+  // host reference in double
+  const double invT = 1.0 / T;
+  std::vector<double> rS((size_t)B * Nc), rlse(B), rloss(B);
+  for (int i = 0; i < B; ++i)
+    for (int j = 0; j < Nc; ++j) {
+      double a = 0;
+      for (int k = 0; k < d; ++k) a += (double)fQ[(size_t)i * d + k] * fC[(size_t)j * d + k];
+      rS[(size_t)i * Nc + j] = hm[j] ? -INFINITY : a * invT;
+    }
+  const double gscale = 1.0 / (B * 3 * T);  // pretend Nq_global = 3B
+  std::vector<double> rG((size_t)B * Nc);
+  for (int i = 0; i < B; ++i) {
+    double m = -INFINITY, s = 0;
+    for (int j = 0; j < Nc; ++j) m = std::max(m, rS[(size_t)i * Nc + j]);
+    for (int j = 0; j < Nc; ++j) s += exp(rS[(size_t)i * Nc + j] - m);
+    rlse[i] = m + log(s);
+    rloss[i] = rlse[i] - rS[(size_t)i * Nc + hy[i]];
+    for (int j = 0; j < Nc; ++j) rG[(size_t)i * Nc + j] = (exp(rS[(size_t)i * Nc + j] - rlse[i]) - (j == hy[i])) * gscale;
+  }
+
+  Dev<uint16_t> dQ_(hQ.size()), dC_(hC.size()), dG((size_t)B * Nc);
+  Dev<float> dS((size_t)B * Nc), dloss(B), dlse(B), dsum(1), ddq((size_t)B * d), ddc((size_t)Nc * d), dgo(1);
+  Dev<int64_t> dy(B), drank(B);
+  Dev<uint8_t> dm(Nc);
+  dQ_.up(hQ); dC_.up(hC); dy.up(hy); dm.up(hm);
+  size_t wsb = 0;
+  OK(dprhot_workspace_bytes(B, Nc, d, &wsb));
+  Dev<char> ws(wsb);
+  std::vector<float> go = {1.75f};
+  dgo.up(go);
+
+  // ---- sim ----
+  OK(dprhot_sim_fwd(dQ_.p, B, dC_.p, Nc, d, dm.p, 1.0f / T, dS.p, nullptr));
+  CK(hipDeviceSynchronize());
+  {
+    auto S = dS.down();
+    double err = 0, mx = 0;
+    int badinf = 0;
+    for (size_t i = 0; i < S.size(); ++i) {
+      if (isinf(rS[i])) { badinf += !(isinf(S[i]) && S[i] < 0); continue; }
+      err = std::max(err, fabs(S[i] - rS[i]));
+      mx = std::max(mx, fabs(rS[i]));
+    }
+    report("sim_fwd logits (rel max)", err / mx, 1e-5);
+    report("sim_fwd -inf placement", badinf, 0);
+  }
+  // ---- softmax CE + G ----
+  OK(dprhot_softmax_ce_fwd_bwd(dS.p, B, Nc, dy.p, 0, (float)gscale, nullptr, 0, dloss.p, dlse.p, dG.p, nullptr));
+  OK(dprhot_reduce_sum(dloss.p, B, 1.0f, dsum.p, nullptr));
+  CK(hipDeviceSynchronize());
+  std::vector<float> fG((size_t)B * Nc);
+  {
+    auto lse = dlse.down(); auto loss = dloss.down(); auto G = dG.down(); auto sum = dsum.down();
+    double e1 = 0, e2 = 0, e3 = 0, gm = 0, tot = 0;
+    for (int i = 0; i < B; ++i) {
+      e1 = std::max(e1, fabs(lse[i] - rlse[i]) / std::max(1.0, fabs(rlse[i])));
+      e2 = std::max(e2, fabs(loss[i] - rloss[i]) / std::max(1.0, fabs(rloss[i])));
+      tot += rloss[i];
+    }
+    for (size_t i = 0; i < G.size(); ++i) {
+      fG[i] = bf2f(G[i]);
+      e3 = std::max(e3, fabs(fG[i] - rG[i]));
+      gm = std::max(gm, fabs(rG[i]));
+    }
+    report("row_lse", e1, 2e-6);
+    report("row_loss", e2, 1e-5);
+    report("loss_sum", fabs(sum[0] - tot) / std::max(1.0, fabs(tot)), 1e-5);
+    report("G bf16 (rel max)", e3 / gm, 4.5e-3);
+  }
+  // ---- dQ / dC against the bf16 G the device produced (isolates the GEMMs) ----
+  OK(dprhot_dq(dG.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ws.p, wsb, nullptr));
+  OK(dprhot_dc(dG.p, dQ_.p, B, Nc, d, 2.0f, dgo.p, ddc.p, nullptr));
+  CK(hipDeviceSynchronize());
+  {
+    auto q = ddq.down(); auto c = ddc.down();
+    const double sc = 2.0 * 1.75;
+    double e = 0, mx = 0;
+    for (int i = 0; i < B; ++i)
+      for (int k = 0; k < d; ++k) {
+        double a = 0;
+        for (int j = 0; j < Nc; ++j) a += (double)fG[(size_t)i * Nc + j] * fC[(size_t)j * d + k];
+        a *= sc;
+        e = std::max(e, fabs(q[(size_t)i * d + k] - a));
+        mx = std::max(mx, fabs(a));
+      }
+    report("dQ = s*G*C (rel max)", e / mx, 2e-5);
+    e = 0; mx = 0;
+    for (int j = 0; j < Nc; ++j)
+      for (int k = 0; k < d; ++k) {
+        double a = 0;
+        for (int i = 0; i < B; ++i) a += (double)fG[(size_t)i * Nc + j] * fQ[(size_t)i * d + k];
+        a *= sc;
+        e = std::max(e, fabs(c[(size_t)j * d + k] - a));
+        mx = std::max(mx, fabs(a));
+      }
+    report("dC = s*G^T*Q (rel max)", e / mx, 2e-5);
+  }
+  // ---- rank of gold ----
+  OK(dprhot_rank_of_gold(dS.p, B, Nc, dy.p, 0, drank.p, nullptr));
+  CK(hipDeviceSynchronize());
+  {
+    auto S = dS.down(); auto r = drank.down();
+    int bad = 0;
+    for (int i = 0; i < B; ++i) {
+      const float g = S[(size_t)i * Nc + hy[i]];
+      int64_t c = 1;
+      for (int j = 0; j < Nc; ++j) c += (S[(size_t)i * Nc + j] > g) || (S[(size_t)i * Nc + j] == g && j < hy[i]);
+      bad += (c != r[i]);
+    }
+    report("rank_of_gold mismatches", bad, 0);
+  }
+  // ---- top-k ----
+  {
+    const int k = std::min(16, Nc);
+    Dev<float> dv((size_t)B * k);
+    Dev<int64_t> di((size_t)B * k);
+    OK(dprhot_topk(dS.p, B, Nc, k, dv.p, di.p, nullptr));
+    CK(hipDeviceSynchronize());
+    auto S = dS.down(); auto v = dv.down(); auto idx = di.down();
+    int bad = 0;
+    std::vector<int> ord(Nc);
+    for (int i = 0; i < B; ++i) {
+      for (int j = 0; j < Nc; ++j) ord[j] = j;
+      const float* row = &S[(size_t)i * Nc];
+      std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return row[a] > row[b]; });
+      for (int r = 0; r < k; ++r) bad += (idx[(size_t)i * k + r] != ord[r]) || (v[(size_t)i * k + r] != row[ord[r]]);
+    }
+    report("topk mismatches", bad, 0);
+  }
+  // ---- fused entry points agree with the pieces ----
+  {
+    Dev<float> l2(B), s2(1), q2((size_t)B * d), c2((size_t)Nc * d);
+    Dev<uint16_t> G2((size_t)B * Nc);
+    OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, l2.p, nullptr, s2.p, G2.p, ws.p, wsb, nullptr));
+    CK(hipDeviceSynchronize());
+    auto a = G2.down(), b = dG.down();
+    report("inbatch_fwd G == pieces", memcmp(a.data(), b.data(), a.size() * 2) != 0, 0);
+    OK(dprhot_inbatch_bwd(dG.p, dQ_.p, dC_.p, B, Nc, d, 2.0f, dgo.p, q2.p, c2.p, ws.p, wsb, nullptr));
+    CK(hipDeviceSynchronize());
+    auto x = q2.down(), y0 = ddq.down(), z = c2.down(), w = ddc.down();
+    report("inbatch_bwd dQ == pieces", memcmp(x.data(), y0.data(), x.size() * 4) != 0, 0);
+    report("inbatch_bwd dC == pieces", memcmp(z.data(), w.data(), z.size() * 4) != 0, 0);
+  }
+  if (timing) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](const char* name, auto fn, double bytes, double flops) {
+      for (int i = 0; i < 5; ++i) fn();
+      CK(hipDeviceSynchronize());
+      const int iters = 50;
+      CK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < iters; ++i) fn();
+      CK(hipEventRecord(e1, nullptr));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1000.0 / iters;
+      printf("    TIME %-22s %9.2f us  %8.1f GB/s  %8.2f TFLOP/s\n", name, us, bytes / us * 1e-3, flops / us * 1e-6);
+    };
+    const double bn = (double)B * Nc, bd = (double)B * d, nd = (double)Nc * d;
+    timeit("sim_fwd", [&] { OK(dprhot_sim_fwd(dQ_.p, B, dC_.p, Nc, d, dm.p, 1.0f / T, dS.p, nullptr)); }, 2 * (bd + nd) + 4 * bn, 2 * bn * d);
+    timeit("softmax_ce_fwd_bwd", [&] { OK(dprhot_softmax_ce_fwd_bwd(dS.p, B, Nc, dy.p, 0, (float)gscale, nullptr, 0, dloss.p, dlse.p, dG.p, nullptr)); }, 6 * bn, 0);
+    timeit("dq", [&] { OK(dprhot_dq(dG.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ws.p, wsb, nullptr)); }, 2 * bn + 2 * nd + 4 * bd, 2 * bn * d);
+    timeit("dc", [&] { OK(dprhot_dc(dG.p, dQ_.p, B, Nc, d, 2.0f, dgo.p, ddc.p, nullptr)); }, 2 * bn + 2 * bd + 4 * nd, 2 * bn * d);
+    timeit("rank_of_gold", [&] { OK(dprhot_rank_of_gold(dS.p, B, Nc, dy.p, 0, drank.p, nullptr)); }, 4 * bn, 0);
+    timeit("inbatch_fwd", [&] { OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, dloss.p, dlse.p, dsum.p, dG.p, ws.p, wsb, nullptr)); }, 2 * (bd + nd) + 10 * bn, 2 * bn * d);
+    timeit("inbatch_bwd", [&] { OK(dprhot_inbatch_bwd(dG.p, dQ_.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ddc.p, ws.p, wsb, nullptr)); }, 4 * bn + 2 * (bd + nd) + 4 * (bd + nd), 4 * bn * d);
+    timeit("fwd+bwd", [&] {
+      OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, dloss.p, dlse.p, dsum.p, dG.p, ws.p, wsb, nullptr));
+      OK(dprhot_inbatch_bwd(dG.p, dQ_.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ddc.p, ws.p, wsb, nullptr)); }, 0, 6 * bn * d);
+  }
+}
+
+int main(int argc, char** argv) {
+  const bool timing = argc > 1 && strstr(argv[1], "time");
+  const bool big = argc > 1 && strstr(argv[1], "big");
+  printf("libdprhot version %d  DPRHOT_TILE=%s DPRHOT_NO_TR=%s\n", dprhot_version(), getenv("DPRHOT_TILE") ? getenv("DPRHOT_TILE") : "-",
+         getenv("DPRHOT_NO_TR") ? getenv("DPRHOT_NO_TR") : "-");
+  {
+    Dev<uint16_t> o(256);
+    hipLaunchKernelGGL(trdump_kernel, dim3(1), dim3(64), 0, nullptr, o.p);
+    CK(hipDeviceSynchronize());
+    auto h = o.down();
+    printf("trdump (lane: 4 values; LDS image value = element index, lane l address = 4*l):\n");
+    int expect_ok = 1;
+    for (int l = 0; l < 64; ++l) {
+      if (l < 20 || l >= 60) printf("  lane %2d: %3d %3d %3d %3d\n", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3]);
+      for (int j = 0; j < 4; ++j) expect_ok &= (h[l * 4 + j] == (l & 15) + j * 16 + (l >> 4) * 64);
+    }
+    printf("trdump matches documented layout: %s\n", expect_ok ? "yes" : "NO");
+  }
+  run_case(4, 8, 128, 2, 1.0f, false, false);
+  run_case(32, 256, 768, 8, 1.0f, false, timing);
+  run_case(37, 264, 136, 7, 0.5f, true, false);
+  run_case(100, 1000, 200, 10, 1.0f, true, false);
+  run_case(64, 1024, 1024, 2, 1.0f, false, timing);
+  run_case(8, 512, 768, 8, 0.05f, true, timing);
+  if (timing || big) run_case(128, 8192, 768, 8, 1.0f, true, timing);
+  printf(g_fail ? "SELFTEST FAILED (%d)\n" : "SELFTEST PASSED\n", g_fail);
+  return g_fail ? 1 : 0;
+}

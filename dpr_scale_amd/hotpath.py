@@ -1,0 +1,305 @@
+"""The in-batch contrastive step of dpr-scale on MI355X: host side of the operator boundary.
+
+Replaces, for one rank, dpr_scale/task/dpr_task.py:163-212 (gather -> sim_score -> /T -> CrossEntropyLoss) and
+its autograd backward by:  fp32->bf16 cast | RCCL all-gather of context rows | HIP sim + softmax-CE + dScores |
+HIP dQ / dC GEMMs | RCCL reduce-scatter of dC.  All device work goes through the C ABI of libdprhot.so
+(include/dprhot.h); this file only moves pointers.  There is NO CPU path here: CPU tensors raise.
+
+`kernels` arguments exist so that the CPU test-suite can exercise the distributed orchestration (gather
+layout, label offsets, reduce-scatter, loss all-reduce) on gloo with a stand-in; the default -- and the only
+thing the product ever passes -- is the HIP library.
+"""
+import ctypes
+
+import torch
+
+from . import dist as D
+
+_BF16 = torch.bfloat16
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class HipKernels:
+    """Thin, allocation-aware wrapper over libdprhot.  Every tensor must live on a HIP device."""
+
+    name = "hip"
+
+    def __init__(self):
+        from . import _lib  # raises ImportError if libdprhot.so is missing -- loudly, by design
+
+        self._lib = _lib
+        self.lib = _lib.lib
+        self._ws = {}
+
+    # -- plumbing --------------------------------------------------------------------------------------
+    @staticmethod
+    def _require_gpu(*ts):
+        for t in ts:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError(
+                    "dpr_scale_amd hot path needs HIP device tensors (got a CPU tensor); there is no CPU fallback")
+
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _workspace(self, device, nbytes):
+        ws = self._ws.get(device)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self._ws[device] = ws
+        return ws
+
+    def empty(self, shape, dtype, like):
+        return torch.empty(shape, dtype=dtype, device=like.device)
+
+    # -- ops -------------------------------------------------------------------------------------------
+    def cast_bf16(self, src, dst):
+        """dst (bf16, contiguous, may be a row-slice of the gather buffer) <- src (fp32 or bf16)."""
+        self._require_gpu(src, dst)
+        src = src.detach()
+        if src.dtype == _BF16:
+            dst.copy_(src)
+            return dst
+        src = src.contiguous().float()
+        n = src.numel()
+        assert dst.is_contiguous() and dst.numel() == n and n % 8 == 0
+        self._lib.check(self.lib.dprhot_cast_bf16(_ptr(src), _ptr(dst), n, self._stream()), "dprhot_cast_bf16")
+        return dst
+
+    def inbatch_fwd(self, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
+        self._require_gpu(Qb, Cb, y, colmask)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        dev = Qb.device
+        row_loss = torch.empty(B, dtype=torch.float32, device=dev)
+        row_lse = torch.empty(B, dtype=torch.float32, device=dev)
+        loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        G = torch.empty((B, Nc), dtype=_BF16, device=dev) if want_G else None
+        S = torch.empty((B, Nc), dtype=torch.float32, device=dev) if want_logits else None
+        nbytes = self._lib.workspace_bytes(B, Nc, d)
+        ws = self._workspace(dev, nbytes)
+        self._lib.check(self.lib.dprhot_inbatch_fwd(
+            _ptr(Qb), B, _ptr(Cb), Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T), float(grad_scale),
+            _ptr(S), _ptr(row_loss), _ptr(row_lse), _ptr(loss_sum), _ptr(G), _ptr(ws), ws.numel(), self._stream()),
+            "dprhot_inbatch_fwd")
+        return row_loss, row_lse, loss_sum, G, S
+
+    def inbatch_bwd(self, G, Qb, Cb, h_scale, d_scale, need_dq=True, need_dc=True):
+        self._require_gpu(G, Qb, Cb, d_scale)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        dev = Qb.device
+        dQ = torch.empty((B, d), dtype=torch.float32, device=dev) if need_dq else None
+        dC = torch.empty((Nc, d), dtype=torch.float32, device=dev) if need_dc else None
+        ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_inbatch_bwd(
+            _ptr(G), _ptr(Qb), _ptr(Cb), B, Nc, d, float(h_scale), _ptr(d_scale), _ptr(dQ), _ptr(dC), _ptr(ws),
+            ws.numel(), self._stream()), "dprhot_inbatch_bwd")
+        return dQ, dC
+
+    def sim(self, Qb, Cb, colmask=None, inv_T=1.0):
+        self._require_gpu(Qb, Cb, colmask)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        S = torch.empty((B, Nc), dtype=torch.float32, device=Qb.device)
+        self._lib.check(self.lib.dprhot_sim_fwd(_ptr(Qb), B, _ptr(Cb), Nc, d, _ptr(colmask), float(inv_T), _ptr(S),
+                                                self._stream()), "dprhot_sim_fwd")
+        return S
+
+    def softmax_ce(self, S, y, y_offset=0, grad_scale=1.0, want_G=False, row_win_start=None, win_len=0):
+        self._require_gpu(S, y, row_win_start)
+        B, Nc = S.shape
+        dev = S.device
+        row_loss = torch.empty(B, dtype=torch.float32, device=dev)
+        row_lse = torch.empty(B, dtype=torch.float32, device=dev)
+        G = torch.empty((B, Nc), dtype=_BF16, device=dev) if want_G else None
+        self._lib.check(self.lib.dprhot_softmax_ce_fwd_bwd(
+            _ptr(S), B, Nc, _ptr(y), int(y_offset), float(grad_scale), _ptr(row_win_start), int(win_len),
+            _ptr(row_loss), _ptr(row_lse), _ptr(G), self._stream()), "dprhot_softmax_ce_fwd_bwd")
+        return row_loss, row_lse, G
+
+    def reduce_sum(self, x, scale=1.0):
+        self._require_gpu(x)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        self._lib.check(self.lib.dprhot_reduce_sum(_ptr(x), x.numel(), float(scale), _ptr(out), self._stream()),
+                        "dprhot_reduce_sum")
+        return out
+
+    def dq(self, G, Cb, h_scale=1.0, d_scale=None):
+        B, Nc = G.shape
+        d = Cb.shape[1]
+        out = torch.empty((B, d), dtype=torch.float32, device=G.device)
+        ws = self._workspace(G.device, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_dq(_ptr(G), _ptr(Cb), B, Nc, d, float(h_scale), _ptr(d_scale), _ptr(out), _ptr(ws),
+                                           ws.numel(), self._stream()), "dprhot_dq")
+        return out
+
+    def dc(self, G, Qb, h_scale=1.0, d_scale=None):
+        B, Nc = G.shape
+        d = Qb.shape[1]
+        out = torch.empty((Nc, d), dtype=torch.float32, device=G.device)
+        self._lib.check(self.lib.dprhot_dc(_ptr(G), _ptr(Qb), B, Nc, d, float(h_scale), _ptr(d_scale), _ptr(out),
+                                           self._stream()), "dprhot_dc")
+        return out
+
+    def rank_of_gold(self, S, y, y_offset=0):
+        self._require_gpu(S, y)
+        rows, cols = S.shape
+        out = torch.empty(rows, dtype=torch.int64, device=S.device)
+        self._lib.check(self.lib.dprhot_rank_of_gold(_ptr(S), rows, cols, _ptr(y), int(y_offset), _ptr(out), self._stream()),
+                        "dprhot_rank_of_gold")
+        return out
+
+    def topk(self, S, k):
+        self._require_gpu(S)
+        rows, cols = S.shape
+        v = torch.empty((rows, k), dtype=torch.float32, device=S.device)
+        i = torch.empty((rows, k), dtype=torch.int64, device=S.device)
+        self._lib.check(self.lib.dprhot_topk(_ptr(S), rows, cols, k, _ptr(v), _ptr(i), self._stream()), "dprhot_topk")
+        return v, i
+
+
+_DEFAULT = None
+
+
+def default_kernels():
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = HipKernels()
+    return _DEFAULT
+
+
+def _pad_cols(n):
+    return (n + 7) // 8 * 8
+
+
+class InBatchContrastive(torch.autograd.Function):
+    """loss = InBatchContrastive.apply(q_local, c_local, pos_idx, ctx_mask, temperature, group, kernels)
+
+    q_local [B,d], c_local [B*K,d] (fp32 or bf16, requires_grad), pos_idx [B] int64 rank-local positive
+    indices (dpr_transform.py:164-166), ctx_mask [B*K] bool (dummy-context mask, dpr_transform.py:143-157).
+    Returns the scalar fp32 loss, identical on every rank (mean over the W*B global queries), exactly the
+    value dpr_task.py:212 returns.  backward returns (dq_local, dc_local): the same tensors the reference's
+    autograd leaves in q.grad / c.grad on this rank.
+    """
+
+    @staticmethod
+    def forward(ctx, q, c, pos_idx, ctx_mask, temperature, group, kernels):
+        kn = kernels if kernels is not None else default_kernels()
+        W, r = D.world(group)
+        B, d = q.shape
+        n_ctx = c.shape[0]  # contexts on this rank (B*K)
+        Nc = W * n_ctx
+        Nq = W * B
+        assert pos_idx.shape[0] == B and ctx_mask.shape[0] == n_ctx
+        if d % 8 != 0:
+            raise ValueError(f"hidden size {d} must be a multiple of 8")
+        Nc_pad = _pad_cols(Nc)
+
+        Qb = kn.empty((B, d), _BF16, q)
+        kn.cast_bf16(q, Qb)
+        Cb = kn.empty((Nc_pad, d), _BF16, c)
+        mask_all = kn.empty((Nc_pad,), torch.uint8, c)
+        m8 = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask.to(torch.uint8)
+        if W == 1:
+            kn.cast_bf16(c, Cb[:n_ctx])
+            mask_all[:n_ctx].copy_(m8)
+        else:
+            send = kn.empty((n_ctx, d), _BF16, c)
+            kn.cast_bf16(c, send)
+            h1 = D.all_gather_rows(send, Cb[:Nc], group, async_op=True)
+            h2 = D.all_gather_rows(m8.contiguous(), mask_all[:Nc], group, async_op=True)
+            h1.wait()
+            h2.wait()
+        if Nc_pad != Nc:  # pad columns are masked out (-inf) and carry zero rows
+            Cb[Nc:].zero_()
+            mask_all[Nc:].fill_(1)
+
+        inv_T = 1.0 / float(temperature)
+        grad_scale = inv_T / Nq  # d loss / d S of the global mean, before grad_output
+        row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, r * n_ctx, mask_all, inv_T, grad_scale)
+        if W > 1:
+            D.all_reduce_sum(loss_sum, group)
+        loss = (loss_sum / Nq).reshape(())
+
+        ctx.kn, ctx.group = kn, group
+        ctx.dims = (W, r, B, d, n_ctx, Nc)
+        ctx.in_dtypes = (q.dtype, c.dtype)
+        ctx.save_for_backward(Qb, Cb, G)
+        ctx.row_lse = row_lse
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        kn, group = ctx.kn, ctx.group
+        W, r, B, d, n_ctx, Nc = ctx.dims
+        Qb, Cb, G = ctx.saved_tensors
+        need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        go = grad_out.detach().reshape(1).float().contiguous()  # device scalar: AMP loss scale, no host sync
+        dQ, dC_part = kn.inbatch_bwd(G, Qb, Cb, 1.0, go, need_dq, need_dc)
+        dq = dc = None
+        if need_dq:
+            dq = dQ.to(ctx.in_dtypes[0])
+        if need_dc:
+            if W == 1:
+                dc = dC_part[:n_ctx]
+            else:
+                dc = kn.empty((n_ctx, d), torch.float32, dC_part)
+                D.reduce_scatter_rows(dC_part[:Nc], dc, group)
+            dc = dc.to(ctx.in_dtypes[1])
+        return dq, dc, None, None, None, None, None
+
+
+def inbatch_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, group=None, kernels=None):
+    return InBatchContrastive.apply(q, c, pos_idx, ctx_mask, temperature, group, kernels)
+
+
+# ---- forward-only helpers used by the task's eval path -------------------------------------------------
+def sim_score(q, c, colmask=None, inv_T=1.0, kernels=None):
+    """dpr_task.py:98-105 on the device: fp32 logits [Nq, Nc] from fp32/bf16 embeddings; colmask is the [Nc]
+    dummy-context mask (the row the reference broadcasts at :197)."""
+    kn = kernels if kernels is not None else default_kernels()
+    Nc = c.shape[0]
+    Nc_pad = _pad_cols(Nc)
+    Qb = kn.empty(tuple(q.shape), _BF16, q)
+    kn.cast_bf16(q, Qb)
+    Cb = kn.empty((Nc_pad, c.shape[1]), _BF16, c)
+    kn.cast_bf16(c, Cb[:Nc])
+    m8 = None
+    if colmask is not None or Nc_pad != Nc:
+        m8 = torch.zeros(Nc_pad, dtype=torch.uint8, device=c.device)
+        if colmask is not None:
+            m8[:Nc].copy_(colmask.view(torch.uint8) if colmask.dtype == torch.bool else colmask)
+        if Nc_pad != Nc:
+            Cb[Nc:].zero_()
+            m8[Nc:] = 1
+    S = kn.sim(Qb, Cb, m8, inv_T)
+    return S if Nc_pad == Nc else S[:, :Nc]
+
+
+def cross_entropy_mean(S, labels, kernels=None):
+    """nn.CrossEntropyLoss()(S, labels) for existing fp32 logits (eval: dpr_task.py:224,299)."""
+    kn = kernels if kernels is not None else default_kernels()
+    S = S.contiguous()
+    if S.shape[1] % 8 != 0:
+        pad = _pad_cols(S.shape[1]) - S.shape[1]
+        S = torch.nn.functional.pad(S, (0, pad), value=float("-inf"))
+    row_loss, _, _ = kn.softmax_ce(S, labels)
+    return kn.reduce_sum(row_loss, 1.0 / S.shape[0]).reshape(())
+
+
+def rank_of_gold(S, labels, kernels=None):
+    kn = kernels if kernels is not None else default_kernels()
+    S = S.contiguous()
+    if S.shape[1] % 4 != 0:
+        S = torch.nn.functional.pad(S, (0, 4 - S.shape[1] % 4), value=float("-inf"))
+    return kn.rank_of_gold(S, labels)
+
+
+def topk(S, k, kernels=None):
+    kn = kernels if kernels is not None else default_kernels()
+    return kn.topk(S.contiguous(), k)

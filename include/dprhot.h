@@ -1,0 +1,121 @@
+/*
+ * dprhot.h -- C ABI of libdprhot.so: the MI355X (gfx950) implementation of dpr-scale's in-batch
+ * contrastive hot path.  Reference boundary (paths relative to the dpr-scale tree):
+ *
+ *   dpr_scale/task/dpr_task.py:153-214  DenseRetrieverTask.training_step   (the step)
+ *   dpr_scale/task/dpr_task.py:98-105   DenseRetrieverTask.sim_score       (Q x C^T, masked fill)
+ *   dpr_scale/task/dpr_task.py:46,212   nn.CrossEntropyLoss()              (row softmax CE, mean)
+ *   dpr_scale/task/dpr_task.py:235-246  compute_rank_metrics               (rank of the gold ctx)
+ *   dpr_scale/run_retrieval_pytorch.py:141-176 search_index                (einsum + topk)  ["next" row]
+ *
+ * The reference is 100 % Python and has no FFI of its own; these entry points are what a binding for this
+ * path binds (INTEGRATION.md shows the ctypes stub and the dpr_task.py patch).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (e.g. torch's caching allocator) unless its
+ *     name starts with h_.  Nothing is allocated, freed or retained by the library.
+ *   - All matrices are row-major and contiguous; rows are 16-byte aligned: d % 8 == 0, Nc % 8 == 0.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Kernels are enqueued
+ *     asynchronously; no entry point synchronises with the host.
+ *   - bf16 values travel as uint16_t bit patterns (round-to-nearest-even from fp32).
+ *   - Return value: 0 = OK, <0 = error (DPRHOT_E_*); dprhot_last_error() returns a thread-local message.
+ *     Functions are re-entrant; there is no global mutable state.
+ *   - Shapes: B = rows (queries) held by this rank, Nc = all columns (contexts) after the gather,
+ *     d = hidden size.
+ */
+#ifndef DPRHOT_H
+#define DPRHOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPRHOT_VERSION 100 /* 0.1.0 */
+
+#define DPRHOT_OK 0
+#define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
+#define DPRHOT_E_HIP (-2)         /* a HIP runtime call failed; message has hipGetErrorString */
+#define DPRHOT_E_UNSUPPORTED (-3) /* shape outside what the kernels were built for */
+#define DPRHOT_E_WORKSPACE (-4)   /* workspace too small */
+
+typedef uint16_t dprhot_bf16;
+
+int dprhot_version(void);
+const char* dprhot_last_error(void);
+
+/* Bytes of scratch the fused entry points (dprhot_inbatch_fwd/_bwd, dprhot_dq) need for this shape. */
+int dprhot_workspace_bytes(int B, int Nc, int d, size_t* h_out);
+
+/* fp32 -> bf16 (RNE) of n contiguous values.  Producer side of the gather: the encoder output
+ * (hf_model.py:36-41, fp32) is written straight into this rank's slot of the gathered bf16 buffer.
+ * n % 8 == 0. */
+int dprhot_cast_bf16(const float* src, dprhot_bf16* dst, size_t n, void* stream);
+
+/* sim_score (dpr_task.py:98-105) + the temperature scale (:211), one kernel:
+ *   S[i][j] = inv_T * sum_k Q[i][k] * C[j][k]      (bf16 MFMA, fp32 accumulate)
+ *   S[i][j] = -inf where colmask[j] != 0            (colmask may be NULL; it is the row that
+ *                                                    `mask.repeat(Nq, 1)` at :197 broadcasts)
+ * Q [B,d], C [Nc,d] bf16; S [B,Nc] fp32. */
+int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const uint8_t* colmask,
+                   float inv_T, float* S, void* stream);
+
+/* Row softmax cross-entropy (dpr_task.py:46,212) fused with its backward into dScores, one pass over S:
+ *   row_lse[i]  = logsumexp_j S[i][j]
+ *   row_loss[i] = row_lse[i] - S[i][y[i]]
+ *   G[i][j]     = (exp(S[i][j] - row_lse[i]) - [j == y[i]]) * grad_scale        (bf16, 0 at -inf columns)
+ * The gold column of row i is y[i] + y_offset: y holds the rank-local positive indices from the batch
+ * (dpr_transform.py:164-166) and y_offset = rank * ctx_per_rank is the label offset the reference adds
+ * in its gather loop (dpr_task.py:189-190).  row_win_start is relative to the same offset.
+ * grad_scale carries 1/(Nq_global * T); the incoming grad_output is applied later by dprhot_dq/_dc.
+ * row_win_start/win_len (optional, NULL/0): the in_batch_negatives=False branch (:198-207) -- row i only
+ * sees columns [row_win_start[i], row_win_start[i] + win_len).
+ * row_loss, row_lse, G may each be NULL (not written). */
+int dprhot_softmax_ce_fwd_bwd(const float* S, int B, int Nc, const int64_t* y, int64_t y_offset, float grad_scale,
+                              const int64_t* row_win_start, int win_len, float* row_loss, float* row_lse,
+                              dprhot_bf16* G, void* stream);
+
+/* out[0] = scale * sum_i x[i]  (deterministic single-workgroup tree; the `mean` of CrossEntropyLoss). */
+int dprhot_reduce_sum(const float* x, int n, float scale, float* out, void* stream);
+
+/* Backward of sim_score into the local query rows:  dQ[B,d] = s * G[B,Nc] x C[Nc,d]   (fp32 out),
+ * s = h_scale * (d_scale ? *d_scale : 1).  d_scale is the autograd grad_output scalar, read on the
+ * device so that no host sync is needed (AMP loss scale).  Split-K over Nc; `workspace` of
+ * dprhot_workspace_bytes() is required. */
+int dprhot_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale,
+              const float* d_scale, float* dQ, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward into ALL context columns (this rank's partial; summed over ranks by reduce-scatter):
+ *   dC_part[Nc,d] = s * G^T[Nc,B] x Q[B,d]   (fp32 out) */
+int dprhot_dc(const dprhot_bf16* G, const dprhot_bf16* Q, int B, int Nc, int d, float h_scale,
+              const float* d_scale, float* dC_part, void* stream);
+
+/* compute_rank_metrics (dpr_task.py:235-246) without the sort or the per-row host syncs:
+ *   rank[i] = 1 + #{j : S[i][j] > S[i][y[i]]} + #{j < y[i] : S[i][j] == S[i][y[i]]}
+ * (== position of y[i] in torch.sort(S[i], descending=True, stable=True); bit-exact integer result). */
+int dprhot_rank_of_gold(const float* S, int rows, int cols, const int64_t* y, int64_t y_offset, int64_t* rank,
+                        void* stream);
+
+/* Whole forward of the step for this rank's rows, minimum number of launches:
+ * sim (+mask, +1/T) -> row softmax CE -> G, row_loss, row_lse and loss_sum[0] = sum_i row_loss[i].
+ * S_out may be NULL (logits not kept) or a [B,Nc] fp32 buffer (debug / parity / eval). */
+int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y,
+                       int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss,
+                       float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Whole backward: dQ (local rows) and dC_part (all columns) from G; see dprhot_dq / dprhot_dc. */
+int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_bf16* C, int B, int Nc, int d,
+                       float h_scale, const float* d_scale, float* dQ, float* dC_part, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
+ * their column indices, descending, ties by lower column index.  k <= 128. */
+int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPRHOT_H */

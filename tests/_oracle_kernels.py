@@ -1,0 +1,38 @@
+"""TEST-ONLY stand-in for dpr_scale_amd.hotpath.HipKernels, built on the numpy oracle, so that the CPU suite
+can run the *distributed orchestration* of InBatchContrastive on gloo (gather layout, label offsets,
+reduce-scatter, loss all-reduce).  It lives under tests/ and is never importable from the product."""
+import numpy as np
+import torch
+
+from oracle import inbatch_oracle as O
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+class OracleKernels:
+    name = "oracle-test-standin"
+
+    def empty(self, shape, dtype, like):
+        return torch.empty(shape, dtype=dtype, device=like.device)
+
+    def cast_bf16(self, src, dst):
+        dst.copy_(src.detach().to(torch.bfloat16))
+        return dst
+
+    def inbatch_fwd(self, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
+        S = O.sim_score(_np(Qb), _np(Cb), colmask.numpy().astype(bool)) * inv_T
+        labels = y.numpy() + y_offset
+        _, row_loss, lse = O.log_softmax_ce(S, labels)
+        G = O.dscores(S, labels, lse, grad_scale)
+        t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt)
+        return (t(row_loss), t(lse), t(np.array([row_loss.sum()])), t(G, torch.bfloat16) if want_G else None,
+                t(S) if want_logits else None)
+
+    def inbatch_bwd(self, G, Qb, Cb, h_scale, d_scale, need_dq=True, need_dc=True):
+        s = h_scale * (float(d_scale.item()) if d_scale is not None else 1.0)
+        g = _np(G).astype(np.float64)
+        dQ = torch.from_numpy((g @ _np(Cb).astype(np.float64) * s).astype(np.float32)) if need_dq else None
+        dC = torch.from_numpy((g.T @ _np(Qb).astype(np.float64) * s).astype(np.float32)) if need_dc else None
+        return dQ, dC

@@ -1,0 +1,66 @@
+"""The C-ABI library loads on a GPU-less box and exports every symbol include/dprhot.h declares; argument
+validation (pure host code, no kernel launch) behaves as documented."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "dprhot.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dprhot_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dpr_scale_amd import _lib
+
+    syms = declared_symbols()
+    assert len(syms) >= 13
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"libdprhot.so does not export {s}"
+        assert s in _lib.SIGNATURES, f"dpr_scale_amd/_lib.py does not bind {s}"
+    assert sorted(_lib.SIGNATURES) == syms, "binding lists symbols the header does not declare"
+
+
+def test_version_and_header_agree():
+    from dpr_scale_amd import _lib
+
+    m = re.search(r"#define\s+DPRHOT_VERSION\s+(\d+)", open(HEADER).read())
+    assert _lib.version() == int(m.group(1))
+
+
+def test_argument_validation_is_host_side():
+    from dpr_scale_amd import _lib
+
+    lib = _lib.lib
+    out = ctypes.c_size_t(0)
+    assert lib.dprhot_workspace_bytes(128, 8192, 768, ctypes.byref(out)) == 0 and out.value >= 128 * 8192 * 4
+    assert lib.dprhot_workspace_bytes(128, 8190, 768, ctypes.byref(out)) == -1  # Nc % 8
+    assert b"multiple of 8" in lib.dprhot_last_error()
+    assert lib.dprhot_workspace_bytes(0, 8, 8, ctypes.byref(out)) == -1
+    assert lib.dprhot_sim_fwd(None, 4, None, 8, 128, None, 1.0, None, None) == -1  # NULL pointers
+    assert lib.dprhot_cast_bf16(None, None, 8, None) == -1
+    assert lib.dprhot_topk(None, 1, 1, 1, None, None, None) == -1
+    with pytest.raises(_lib.DprhotError):
+        _lib.check(-1, "x")
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    import importlib
+    import sys
+
+    monkeypatch.setenv("DPRHOT_LIB", str(tmp_path / "nope.so"))
+    saved = sys.modules.pop("dpr_scale_amd._lib", None)
+    try:
+        with pytest.raises(ImportError, match="no CPU fallback"):
+            importlib.import_module("dpr_scale_amd._lib")
+    finally:
+        sys.modules.pop("dpr_scale_amd._lib", None)
+        if saved is not None:
+            sys.modules["dpr_scale_amd._lib"] = saved

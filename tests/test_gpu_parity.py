@@ -1,0 +1,292 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the reference-generated fixtures, the numpy
+oracle, and size-independent properties at BASELINE.json's full sizes.  All need a real MI355X.
+
+Tolerances (north_star): loss / logits <= 1e-3 relative to the fp32 reference on identical bf16-representable
+inputs (measured ~1e-6: only the accumulation order differs); rank / top-k indices bit-exact under the frozen
+tie rule; gradients <= 1e-2 of max|grad| because dScores travels as bf16 (2^-9 per element), as it does in the
+reference under AMP.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import inbatch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-3
+LOGIT_RTOL = 1e-3
+GRAD_RTOL = 1e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def kn():
+    from dpr_scale_amd.hotpath import default_kernels
+
+    return default_kernels()
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def rank_inputs(meta):
+    W, B, K, d = meta["W"], meta["B"], meta["K"], meta["d"]
+    return [O.synth_embeddings(meta["seed"] + r, B, K, d, meta["dist"], meta["ragged"]) for r in range(W)]
+
+
+def t(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def bf16(x, dev):
+    return t(x, dev).to(torch.bfloat16)
+
+
+def test_native_library_is_the_in_tree_one(kn):
+    import os
+
+    from dpr_scale_amd import _lib
+
+    assert os.path.samefile(os.path.dirname(_lib.LIB_PATH), os.path.dirname(_lib.__file__))
+    maps = open("/proc/self/maps").read()
+    assert "libdprhot.so" in maps
+
+
+@pytest.mark.parametrize("name", golden_names("cfg1") + golden_names("cfg2"))
+def test_autograd_op_against_reference_fixture(name, dev):
+    """The whole operator (cast -> sim -> softmax CE -> backward) vs the reference's training_step outputs."""
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss, rank_of_gold, sim_score
+
+    meta, g = load_golden(name)
+    q, c, y, m = rank_inputs(meta)[0]
+    tq = t(q, dev).requires_grad_(True)
+    tc = t(c, dev).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), meta["T"])
+    loss.backward()
+    assert abs(loss.item() - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+    assert rel(tq.grad.cpu().numpy(), g["dQ"]) <= GRAD_RTOL
+    assert rel(tc.grad.cpu().numpy(), g["dC"]) <= GRAD_RTOL
+    S = sim_score(tq.detach(), tc.detach(), t(m, dev)).cpu().numpy()
+    fin = np.isfinite(g["S"])
+    assert np.array_equal(fin, np.isfinite(S))
+    assert np.all(S[~fin] == -np.inf)
+    assert rel(S[fin], g["S"][fin]) <= LOGIT_RTOL
+    ranks = rank_of_gold(t(S, dev), t(y, dev)).cpu().numpy()
+    assert np.array_equal(ranks, g["ranks"])
+
+
+def test_grad_output_scalar_is_applied_on_device(dev):
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    meta, g = load_golden("cfg2_U_T1")
+    q, c, y, m = rank_inputs(meta)[0]
+    tq = t(q, dev).requires_grad_(True)
+    tc = t(c, dev).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), meta["T"])
+    (loss * 1024.0).backward()  # AMP-style loss scale
+    assert rel(tq.grad.cpu().numpy() / 1024.0, g["dQ"]) <= GRAD_RTOL
+    assert rel(tc.grad.cpu().numpy() / 1024.0, g["dC"]) <= GRAD_RTOL
+
+
+def _emulate_ranks(meta, kn, dev, want_logits_rank=None):
+    """Run every rank's local-rows step on this one GPU; return per-rank pieces and the summed dC."""
+    W, B, K, d = meta["W"], meta["B"], meta["K"], meta["d"]
+    parts = rank_inputs(meta)
+    Cb = bf16(np.concatenate([p[1] for p in parts]), dev)
+    mask = t(np.concatenate([p[3] for p in parts]).astype(np.uint8), dev)
+    inv_T = 1.0 / meta["T"]
+    out = []
+    dC = torch.zeros((W * B * K, d), dtype=torch.float32, device=dev)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    for r in range(W):
+        Qb = bf16(parts[r][0], dev)
+        y = t(parts[r][2], dev)
+        row_loss, lse, loss_sum, G, S = kn.inbatch_fwd(Qb, Cb, y, r * B * K, mask, inv_T, inv_T / (W * B),
+                                                       want_logits=(r == want_logits_rank))
+        dq, dcp = kn.inbatch_bwd(G, Qb, Cb, 1.0, one)
+        dC += dcp
+        out.append(dict(loss_sum=loss_sum.item(), lse=lse.cpu().numpy(), dq=dq.cpu().numpy(),
+                        S=None if S is None else S.cpu().numpy(), y=parts[r][2] + r * B * K))
+    return out, dC.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["w2_ddp", "w4_ddp", "cfg4_ddp"])
+def test_local_rows_vs_reference_ddp_branch(name, kn, dev):
+    """Per-rank loss / q.grad / c.grad of the reference's DDP branch (real gloo ranks) from the HIP kernels."""
+    meta, g = load_golden(name)
+    W, B, K = meta["W"], meta["B"], meta["K"]
+    outs, dC = _emulate_ranks(meta, kn, dev)
+    loss = sum(o["loss_sum"] for o in outs) / (W * B)
+    for r in range(W):
+        assert abs(loss - g["loss_per_rank"][r]) <= LOSS_RTOL * max(1.0, abs(loss))
+        assert rel(outs[r]["dq"], g["dq_per_rank"][r]) <= GRAD_RTOL
+        assert rel(dC[r * B * K:(r + 1) * B * K], g["dc_per_rank"][r]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("name", golden_names("cfg3") + golden_names("cfg5"))
+def test_full_size_configs_against_reference_summaries(name, kn, dev):
+    """cfg3 (W8 B128 K8 d768: 1024 x 8192) and cfg5 (W8 B64 K2 d1024) at full size."""
+    meta, g = load_golden(name)
+    W, B, K = meta["W"], meta["B"], meta["K"]
+    own = meta["own_rank"]
+    outs, dC = _emulate_ranks(meta, kn, dev, want_logits_rank=own)
+    loss = sum(o["loss_sum"] for o in outs) / (W * B)
+    assert abs(loss - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+    assert rel(np.concatenate([o["lse"] for o in outs]), g["lse"]) <= LOGIT_RTOL
+    assert rel(outs[own]["dq"], g["dq_own"]) <= GRAD_RTOL
+    S = outs[own]["S"] * meta["T"]
+    si, sj = g["sample_i"], g["sample_j"]
+    sel = (si >= own * B) & (si < (own + 1) * B)
+    mine, ref = S[si[sel] - own * B, sj[sel]], g["sample_S"][sel]
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(mine)) and rel(mine[fin], ref[fin]) <= LOGIT_RTOL
+    from dpr_scale_amd.hotpath import rank_of_gold
+
+    ranks = rank_of_gold(t(outs[own]["S"], dev), t(outs[own]["y"], dev)).cpu().numpy()
+    assert np.array_equal(ranks, g["ranks"][own * B:(own + 1) * B])
+    assert rel(dC[own * B * K:own * B * K + 64], g["dc_own_head"]) <= GRAD_RTOL
+
+
+def test_tie_rule_bit_exact(dev):
+    from dpr_scale_amd.hotpath import rank_of_gold, topk
+
+    _, g = load_golden("ties")
+    S = t(g["S"], dev)
+    assert np.array_equal(rank_of_gold(S, t(g["y"], dev)).cpu().numpy(), g["ranks"])
+    v, i = topk(S, 16)
+    assert np.array_equal(i.cpu().numpy(), g["order16"])
+    assert np.array_equal(v.cpu().numpy(), g["topk_values"])
+
+
+def test_non_inbatch_window_branch(kn, dev):
+    """in_batch_negatives=False (dpr_task.py:198-207): row i sees only its own K columns."""
+    meta, g = load_golden("nib")
+    q, c, y, m = O.synth_embeddings(meta["seed"], meta["B"], meta["K"], meta["d"], meta["dist"], meta["ragged"])
+    B, K = meta["B"], meta["K"]
+    Qb, Cb = bf16(q, dev), bf16(c, dev)
+    S = kn.sim(Qb, Cb, t(m.astype(np.uint8), dev), 1.0)
+    row_loss, _, G = kn.softmax_ce(S, t(y, dev), 0, 1.0 / B, want_G=True, row_win_start=t(y, dev), win_len=K)
+    assert abs(row_loss.mean().item() - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+    assert rel(kn.dq(G, Cb).cpu().numpy(), g["dQ"]) <= GRAD_RTOL
+    assert rel(kn.dc(G, Qb).cpu().numpy(), g["dC"]) <= GRAD_RTOL
+
+
+# ---- size-independent properties at full size -----------------------------------------------------------
+@pytest.mark.parametrize("B,Nc,d", [(128, 8192, 768), (1024, 8192, 768), (64, 1024, 1024)])
+def test_properties_full_size(B, Nc, d, kn, dev):
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16)
+    c = (torch.randn(Nc, d, generator=gen) * d ** -0.25).to(torch.bfloat16)
+    y = torch.randint(0, Nc, (B,), generator=gen)
+    mask = (torch.rand(Nc, generator=gen) < 0.05)
+    mask[y] = False
+    Qb, Cb, yd, md = q.to(dev), c.to(dev), y.to(dev), mask.to(torch.uint8).to(dev)
+    row_loss, lse, loss_sum, G, S = kn.inbatch_fwd(Qb, Cb, yd, 0, md, 1.0, 1.0 / B, want_logits=True)
+    # (1) logits vs a plain fp32 torch matmul on the device (same bf16-representable inputs)
+    S_ref = Qb.float() @ Cb.float().T
+    S_ref[:, mask.to(dev)] = float("-inf")
+    fin = torch.isfinite(S_ref)
+    assert torch.equal(fin, torch.isfinite(S))
+    assert ((S[fin] - S_ref[fin]).abs().max() / S_ref[fin].abs().max()).item() <= LOGIT_RTOL
+    # (2) lse >= max logit, loss >= 0, loss_sum == sum(row_loss), lse vs torch.logsumexp
+    assert torch.all(lse >= S.max(dim=1).values - 1e-5) and torch.all(row_loss >= -1e-5)
+    assert abs(loss_sum.item() - row_loss.double().sum().item()) <= 1e-4 * max(1.0, row_loss.double().sum().item())
+    assert ((lse - torch.logsumexp(S_ref, dim=1)).abs().max() / lse.abs().max()).item() <= LOGIT_RTOL
+    # (3) rows of G sum to zero (softmax - onehot), masked columns carry exactly zero
+    Gf = G.float()
+    assert Gf.sum(dim=1).abs().max().item() <= 2e-2 / B
+    assert torch.all(Gf[:, mask.to(dev)] == 0)
+    # (4) backward is linear in grad_output and equals fp32 torch GEMMs on the same G
+    one = torch.ones(1, device=dev)
+    two = torch.full((1,), 2.0, device=dev)
+    dq1, dc1 = kn.inbatch_bwd(G, Qb, Cb, 1.0, one)
+    dq2, dc2 = kn.inbatch_bwd(G, Qb, Cb, 1.0, two)
+    assert torch.equal(dq2, 2 * dq1) and torch.equal(dc2, 2 * dc1)
+    dq_ref, dc_ref = Gf @ Cb.float(), Gf.T @ Qb.float()
+    assert ((dq1 - dq_ref).abs().max() / dq_ref.abs().max()).item() <= 1e-4
+    assert ((dc1 - dc_ref).abs().max() / dc_ref.abs().max()).item() <= 1e-4
+    # (5) a column permutation of C (labels and mask permuted with it) changes neither loss nor ranks
+    perm = torch.randperm(Nc, generator=gen)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(Nc)
+    rl2, _, ls2, _, S2 = kn.inbatch_fwd(Qb, Cb[perm.to(dev)].contiguous(), inv[y].to(dev), 0, md[perm.to(dev)].contiguous(),
+                                        1.0, 1.0 / B, want_logits=True)
+    assert abs(ls2.item() - loss_sum.item()) <= 1e-5 * max(1.0, abs(loss_sum.item()))
+    greater1 = (S > S.gather(1, yd[:, None])).sum(1)
+    greater2 = (S2 > S2.gather(1, inv[y].to(dev)[:, None])).sum(1)
+    assert torch.equal(greater1, greater2)
+    # (6) rank of gold == position in a stable descending sort; top-k == stable sort prefix
+    order = torch.sort(S, dim=1, descending=True, stable=True).indices
+    ref_rank = (order == yd[:, None]).nonzero()[:, 1] + 1
+    assert torch.equal(kn.rank_of_gold(S, yd), ref_rank)
+    v, i = kn.topk(S, 10)
+    assert torch.equal(i, order[:, :10]) and torch.equal(v, S.gather(1, order[:, :10]))
+
+
+# ---- edge cases -------------------------------------------------------------------------------------------
+def test_edge_single_row_and_minimal_columns(kn, dev):
+    q, c, y, m = O.synth_embeddings(3, 1, 8, 64, "U", False)
+    r = O.training_step_global(q, c, y, m, 1.0)
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), 1.0)
+    loss.backward()
+    assert abs(loss.item() - r["loss"]) <= LOSS_RTOL * max(1.0, abs(r["loss"]))
+    assert rel(tq.grad.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy(), r["dC"]) <= GRAD_RTOL
+
+
+def test_edge_ragged_column_count_is_padded(dev):
+    """B*K not a multiple of 8 (K=3): the wrapper pads with masked columns; result equals the oracle."""
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    q, c, y, m = O.synth_embeddings(11, 5, 3, 128, "U", True)
+    r = O.training_step_global(q, c, y, m, 0.5)
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), 0.5)
+    loss.backward()
+    assert abs(loss.item() - r["loss"]) <= LOSS_RTOL * max(1.0, abs(r["loss"]))
+    assert tc.grad.shape == (15, 128)
+    assert rel(tq.grad.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy(), r["dC"]) <= GRAD_RTOL
+
+
+def test_edge_everything_but_gold_masked(kn, dev):
+    q, c, y, m = O.synth_embeddings(5, 8, 4, 128, "U", False)
+    m[:] = True
+    m[y] = False
+    Qb, Cb = bf16(q, dev), bf16(c, dev)
+    row_loss, lse, loss_sum, G, S = kn.inbatch_fwd(Qb, Cb, t(y, dev), 0, t(m.astype(np.uint8), dev), 1.0, 1.0 / 8,
+                                                   want_logits=True)
+    r = O.training_step_global(q, c, y, m, 1.0)
+    assert abs(loss_sum.item() / 8 - r["loss"]) <= LOSS_RTOL * max(1.0, abs(r["loss"]))
+    assert torch.isfinite(G.float()).all() and torch.isfinite(row_loss).all()
+
+
+def test_edge_peaky_logits_and_small_temperature(kn, dev):
+    """dist P (logit sigma ~ 28) at T = 0.05: |logits| in the thousands; no overflow, loss matches oracle."""
+    q, c, y, m = O.synth_embeddings(9, 32, 8, 768, "P", True)
+    r = O.training_step_global(q, c, y, m, 0.05)
+    Qb, Cb = bf16(q, dev), bf16(c, dev)
+    row_loss, lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, t(y, dev), 0, t(m.astype(np.uint8), dev), 20.0, 20.0 / 32)
+    assert torch.isfinite(row_loss).all() and torch.isfinite(G.float()).all()
+    assert abs(loss_sum.item() / 32 - r["loss"]) <= LOSS_RTOL * abs(r["loss"])
+    assert rel(row_loss.cpu().numpy(), r["row_loss"]) <= LOSS_RTOL
+
+
+def test_bad_arguments_raise(kn, dev):
+    from dpr_scale_amd._lib import DprhotError
+
+    Qb = torch.zeros((4, 60), dtype=torch.bfloat16, device=dev)  # d % 8 != 0
+    Cb = torch.zeros((8, 60), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(DprhotError, match="multiple of 8"):
+        kn.sim(Qb, Cb)
