@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd databases (ROCm 7.2 default output) into small CSV/markdown files under profiles/.
+
+  python scripts/prof_summary.py <tag> [--trace gpurun_out/prof_trace/bench_results.db]
+                                        [--fetch gpurun_out/prof_fetch/bench_results.db]
+                                        [--write gpurun_out/prof_write/bench_results.db]
+Kernel-trace stats: calls, total, average, min, max duration per kernel (the `--stats` table).
+PMC: per-kernel average FETCH_SIZE / WRITE_SIZE (KiB) and the HBM bytes derived from them with the gfx950
+correction of MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of wide coalesced reads -> x2; WRITE_SIZE as is).
+"""
+import argparse
+import csv
+import os
+import sqlite3
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--trace")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--out", default="profiles")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    rows = {}
+    if a.trace:
+        for name, n, tot, avg, mn, mx in q(a.trace, "select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                                                    "from kernels group by name order by sum(duration) desc"):
+            rows[name] = dict(kernel=name, calls=n, total_us=tot / 1e3, avg_us=avg / 1e3, min_us=mn / 1e3, max_us=mx / 1e3)
+        tot = sum(r["total_us"] for r in rows.values()) or 1.0
+        for r in rows.values():
+            r["pct"] = 100.0 * r["total_us"] / tot
+    for key, db in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+        if not db:
+            continue
+        for name, avg in q(db, f"select kernel_name, avg(value) from counters_collection where counter_name='{key}' group by kernel_name"):
+            rows.setdefault(name, dict(kernel=name))[key + "_KiB_avg"] = avg
+    for r in rows.values():
+        f, w = r.get("FETCH_SIZE_KiB_avg"), r.get("WRITE_SIZE_KiB_avg")
+        if f is not None and w is not None:
+            r["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
+    cols = ["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct", "FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg",
+            "hbm_bytes_per_launch_corrected"]
+    path = os.path.join(a.out, f"{a.tag}_kernel_stats.csv")
+    with open(path, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=cols)
+        w.writeheader()
+        for r in sorted(rows.values(), key=lambda r: -r.get("total_us", 0)):
+            w.writerow({k: (f"{v:.3f}" if isinstance(v, float) else v) for k, v in r.items()})
+    print(open(path).read())
+
+
+if __name__ == "__main__":
+    main()
