@@ -2,16 +2,20 @@
 """bench.py -- query-passage pairs/sec of dpr-scale's in-batch contrastive hot path on MI355X.
 
 A "step" is one pass of the hot path over one synthetic NQ-shaped batch whose embeddings are already resident
-in HBM: fp32->bf16 cast of q/c -> (W>1: RCCL all-gather of context rows + mask) -> sim (+mask, 1/T) ->
-row-softmax CE + dScores -> loss sum (-> W>1: all-reduce) -> dC, dQ GEMMs (-> W>1: reduce-scatter of dC),
-i.e. everything dpr_task.py:163-212 and its autograd backward do between the encoder outputs and their
-gradients.  The step is driven through the C ABI (include/dprhot.h) exactly as a binding would drive it.
+in HBM: fp32->bf16 cast of q/c -> (W>1: RCCL all-gather of context rows + mask) -> sim (+mask, 1/T, softmax
+statistics) -> logsumexp + dScores + loss (-> W>1: all-reduce) -> dC and dQ GEMMs (-> W>1: reduce-scatter of
+dC), i.e. everything dpr_task.py:163-212 and its autograd backward do between the encoder outputs and their
+gradients.  The step is driven through the C ABI (include/dprhot.h) exactly as a binding would drive it:
+dprhot_inbatch_fwd_f32 (fp32 embeddings in, rounded to bf16 while staging) and dprhot_inbatch_bwd -- 3 kernel
+launches at N=1.
 
 N=1 workload = BASELINE.json configs[1]: bert-base shapes, batch 32, 1 positive + 7 negatives, d=768, no
 all-gather.  N>1: the same per-GPU batch on every rank (weak scaling; the global negatives grow with N).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--negatives 7] [--dim 768]
-                  [--no-cpu-baseline] [--e2e]        (--e2e adds the bert-base end-to-end step as extra info)
+                  [--driver graph|eager] [--no-cpu-baseline] [--e2e]
+--driver eager: one C-ABI call per stage per step; graph: the step's launches captured once into a HIP graph and
+replayed; auto (default): an untimed probe picks the faster of the two on this box (both rates are reported).
 Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
 """
@@ -42,12 +46,13 @@ def parse():
     ap.add_argument("--negatives", type=int, default=7)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--driver", choices=["auto", "graph", "eager"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true")
     return ap.parse_args()
 
 
-def p(t):
+def P(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
@@ -88,52 +93,64 @@ class HotPathStep:
         self.gscale = self.inv_T / self.Nq
         if W == 1:
             self.mask_all.copy_(self.m8)
+        self.bind_stream()
 
-    def stream(self):
-        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    def bind_stream(self):
+        """(Re)build the argument tuples for the CURRENT torch stream (every buffer is static)."""
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B, Nc, d, off = self.B, self.Nc, self.d, self.r * self.n_ctx
+        ws, wsb = P(self.ws), self.ws_bytes
+        self.a_prep = (P(self.q), self.q.numel(), P(self.Qb), P(self.c), self.c.numel(), P(self.send), st)
+        self.a_fwd = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, self.gscale, None,
+                      P(self.row_loss), P(self.row_lse), P(self.loss_sum), P(self.G), ws, wsb, st)
+        self.a_fwd32 = (P(self.q), P(self.c) if self.W == 1 else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
+                        P(self.mask_all), self.inv_T, self.gscale, None, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
+                        P(self.G), ws, wsb, st)
+        self.a_sim32 = (P(self.q), P(self.c) if self.W == 1 else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
+                        P(self.mask_all), self.inv_T, None, ws, wsb, st)
+        self.a_castc = (P(self.c), P(self.send), self.c.numel(), st)
+        self.a_bwd = (P(self.G), P(self.Qb), P(self.Cb), B, Nc, d, 1.0, P(self.go), P(self.dQ), P(self.dC), ws, wsb, st)
+        self.a_sim = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, None, ws, wsb, st)
+        self.a_fin = (None, B, Nc, d, P(self.y), off, self.gscale, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
+                      P(self.G), ws, wsb, st)
 
-    # individual stages (also timed one by one for the roofline report)
-    def k_cast_q(self):
-        self._lib.check(self.lib.dprhot_cast_bf16(p(self.q), p(self.Qb), self.q.numel(), self.stream()))
+    def _call(self, fn, args):
+        rc = fn(*args)
+        if rc:
+            self._lib.check(rc, fn.__name__)
 
-    def k_cast_c(self):
-        self._lib.check(self.lib.dprhot_cast_bf16(p(self.c), p(self.send), self.c.numel(), self.stream()))
+    # the launches of one step
+    def k_prep(self):
+        self._call(self.lib.dprhot_prep, self.a_prep)
 
     def k_fwd(self):
-        self._lib.check(self.lib.dprhot_inbatch_fwd(
-            p(self.Qb), self.B, p(self.Cb), self.Nc, self.d, p(self.y), self.r * self.n_ctx, p(self.mask_all),
-            self.inv_T, self.gscale, None, p(self.row_loss), p(self.row_lse), p(self.loss_sum), p(self.G),
-            p(self.ws), self.ws_bytes, self.stream()))
+        self._call(self.lib.dprhot_inbatch_fwd, self.a_fwd)
 
     def k_bwd(self):
-        self._lib.check(self.lib.dprhot_inbatch_bwd(
-            p(self.G), p(self.Qb), p(self.Cb), self.B, self.Nc, self.d, 1.0, p(self.go), p(self.dQ), p(self.dC),
-            p(self.ws), self.ws_bytes, self.stream()))
+        self._call(self.lib.dprhot_inbatch_bwd, self.a_bwd)
 
     def k_sim(self):
-        self._lib.check(self.lib.dprhot_sim_fwd(p(self.Qb), self.B, p(self.Cb), self.Nc, self.d, p(self.mask_all),
-                                                self.inv_T, p(self.ws), self.stream()))
+        self._call(self.lib.dprhot_sim_stats, self.a_sim)
+
+    def k_fwd32(self):
+        self._call(self.lib.dprhot_inbatch_fwd_f32, self.a_fwd32)
+
+    def k_sim32(self):
+        self._call(self.lib.dprhot_sim_stats_f32, self.a_sim32)
+
+    def k_castc(self):
+        self._call(self.lib.dprhot_cast_bf16, self.a_castc)
 
     def k_softmax(self):
-        self._lib.check(self.lib.dprhot_softmax_ce_fwd_bwd(
-            p(self.ws), self.B, self.Nc, p(self.y), self.r * self.n_ctx, self.gscale, None, 0, p(self.row_loss),
-            p(self.row_lse), p(self.G), self.stream()))
-
-    def k_dq(self):
-        self._lib.check(self.lib.dprhot_dq(p(self.G), p(self.Cb), self.B, self.Nc, self.d, 1.0, p(self.go), p(self.dQ),
-                                           p(self.ws), self.ws_bytes, self.stream()))
-
-    def k_dc(self):
-        self._lib.check(self.lib.dprhot_dc(p(self.G), p(self.Qb), self.B, self.Nc, self.d, 1.0, p(self.go), p(self.dC),
-                                           self.stream()))
+        self._call(self.lib.dprhot_softmax_finish, self.a_fin)
 
     def step(self):
-        self.k_cast_q()
-        self.k_cast_c()
+        # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
         if self.W > 1:
+            self.k_castc()
             self.D.all_gather_rows(self.send, self.Cb, self.group)
             self.D.all_gather_rows(self.m8, self.mask_all, self.group)
-        self.k_fwd()
+        self.k_fwd32()
         if self.W > 1:
             self.D.all_reduce_sum(self.loss_sum, self.group)
         self.k_bwd()
@@ -141,18 +158,38 @@ class HotPathStep:
             self.D.reduce_scatter_rows(self.dC, self.dc, self.group)
 
 
-def time_kernel(fn, iters=200, warm=20):
-    """Average duration of `fn`'s launches, HIP events on the launch stream."""
-    for _ in range(warm):
-        fn()
+def capture(hp, fn, repeat=1):
+    """Capture `repeat` back-to-back invocations of fn into one HIP graph; returns the replay callable."""
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hp.bind_stream()
+        fn()  # warm (hipFuncSetAttribute etc. must not happen under capture)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=side):
+        hp.bind_stream()
+        for _ in range(repeat):
+            fn()
+    hp.bind_stream()
+    return g.replay
+
+
+def time_kernel(hp, fn, reps=50, iters=20):
+    """Average duration of one launch of `fn`, HIP events on the launch stream, launches back to back on the
+    device (50 per graph replay, so the host launch rate does not enter the number)."""
+    run = capture(hp, fn, reps)
+    for _ in range(3):
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        fn()
+        run()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters  # us
+    return e0.elapsed_time(e1) * 1e3 / (iters * reps)  # us
 
 
 def cpu_baseline(B, K, d, T, budget_s=12.0):
@@ -172,6 +209,21 @@ def cpu_baseline(B, K, d, T, budget_s=12.0):
             "sample": f"{n} steps of the same B={B} K={K} d={d} workload in {el:.1f} s (oracle/inbatch_oracle.c, OpenMP)"}
 
 
+def timed_loop(run, steps, W):
+    torch.cuda.synchronize()
+    if W > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    if W > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
 def main():
     a = parse()
     W = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,21 +238,24 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     B, K, d, T = a.batch, 1 + a.negatives, a.dim, a.temperature
     hp = HotPathStep(B, K, d, T, W, rank, dev)
+    driver = a.driver
+    if W > 1:
+        driver = "eager"  # the collectives stay outside graphs
+    runs = {"eager": hp.step}
+    if W == 1 and driver in ("auto", "graph"):
+        runs["graph"] = capture(hp, hp.step)
+    if driver == "auto":  # launch-rate-bound regime: pick the faster issue mechanism on this box (untimed probe)
+        probe = {}
+        for name, fn in runs.items():
+            for _ in range(50):
+                fn()
+            probe[name] = timed_loop(fn, 300, W)
+        driver = min(probe, key=probe.get)
+    run = runs[driver]
 
     for _ in range(a.warmup):
-        hp.step()
-    torch.cuda.synchronize()
-    if W > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        hp.step()
-    torch.cuda.synchronize()
-    if W > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+        run()
+    el = timed_loop(run, a.steps, W)
     if W > 1:
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -208,24 +263,29 @@ def main():
 
     out = None
     if rank == 0:
-        Nc, bn, bd, nd = hp.Nc, float(B) * hp.Nc, float(B) * d, float(hp.Nc) * d
-        kern = {  # name: (fn, algorithmic bytes, flops)  -- DESIGN.md "algorithmic bytes per unit"
-            "sim_fwd": (hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d),
-            "softmax_ce_fwd_bwd": (hp.k_softmax, 6 * bn, 0.0),
-            "dq": (hp.k_dq, 2 * bn + 2 * nd + 4 * bd, 2 * bn * d),
-            "dc": (hp.k_dc, 2 * bn + 2 * bd + 4 * nd, 2 * bn * d),
-            "cast_c": (hp.k_cast_c, 6 * float(hp.n_ctx) * d, 0.0),
+        bn, bd, nd = float(B) * hp.Nc, float(B) * d, float(hp.Nc) * d
+        kern = {  # the launches of one step, in order: (fn, algorithmic HBM bytes, flops) -- DESIGN.md section 4
+            "sim_stats_f32": (hp.k_sim32, (4 + 2) * bd + (6 * nd if W == 1 else 2 * nd) + 4 * bn, 2 * bn * d),
+            "softmax_finish": (hp.k_softmax, 6 * bn, 0.0),
+            "bwd_pair": (hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d),
         }
         ktimes = {}
         for name, (fn, by, fl) in kern.items():
-            us = time_kernel(fn)
+            us = time_kernel(hp, fn)
             ktimes[name] = {"us": round(us, 3), "GBps": round(by / us * 1e-3, 1), "TFLOPs": round(fl / us * 1e-6, 2)}
         dom = max(ktimes, key=lambda k: ktimes[k]["us"])
-        by, fl = kern[dom][1], kern[dom][2]
+        by = kern[dom][1]
         us = ktimes[dom]["us"]
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(by / us * 1e-3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 5), "traffic": None,
-                "avg_launch_us": us, "algorithmic_bytes": by}
+                "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": us, "algorithmic_bytes": by}
+        other = "eager" if driver == "graph" else "graph"
+        alt = None
+        if W == 1:
+            run2 = runs.get(other) or capture(hp, hp.step)
+            for _ in range(50):
+                run2()
+            el2 = timed_loop(run2, a.steps, 1)
+            alt = {"driver": other, "value": round(B * a.steps / el2, 1), "ms_per_step": round(el2 / a.steps * 1e3, 5)}
         out = {
             "metric": "query-passage pairs/sec (in-batch contrastive hot path: gather+sim+softmax-CE+dQ/dC)",
             "value": round(W * B * a.steps / el, 1), "unit": "pairs/s", "n_gpus": W, "steps": a.steps, "warmup": a.warmup,
@@ -233,8 +293,9 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cfg2-shaped per GPU: B={B} queries x (1+{a.negatives}) contexts, d={d}, T={T}; "
                                    f"global Nq={W * B}, Nc={hp.Nc}; embeddings resident in HBM, step driven through the C ABI",
-                       "global_batch": W * B, "global_negatives_per_query": hp.Nc - 1, "parallelism": f"dp{W}"},
-            "roofline": roof, "kernels": ktimes,
+                       "global_batch": W * B, "global_negatives_per_query": hp.Nc - 1, "parallelism": f"dp{W}",
+                       "driver": driver},
+            "roofline": roof, "kernels": ktimes, "other_driver": alt,
         }
         if not a.no_cpu_baseline and W == 1:
             out["cpu_baseline"] = cpu_baseline(B, K, d, T)

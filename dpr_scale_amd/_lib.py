@@ -27,6 +27,7 @@ SIGNATURES = {
     "dprhot_last_error": (c_char_p, []),
     "dprhot_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "dprhot_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_prep": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "dprhot_sim_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "dprhot_softmax_ce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -39,6 +40,15 @@ SIGNATURES = {
     "dprhot_inbatch_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
                                    c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "dprhot_sim_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p,
+                                 c_void_p, c_size_t, c_void_p]),
+    "dprhot_softmax_finish": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_sim_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
+                                     c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_inbatch_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,
+                                       c_void_p, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "dprhot_inbatch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
 }

@@ -1,5 +1,10 @@
 // dprhot.hip -- C ABI (include/dprhot.h) over the gfx950 kernels in gemm_bf16.h / rowwise.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC dprhot.hip -o libdprhot.so
+//
+// Launch structure of one training step on one rank:
+//   dprhot_prep         1 launch   fp32 -> bf16 of q and of this rank's context rows
+//   dprhot_inbatch_fwd  2 launches sim GEMM (+mask, 1/T, per-tile softmax stats, gold logit)  ->  G + loss
+//   dprhot_inbatch_bwd  1 launch   dC_part = G^T Q  and  dQ = G C  side by side (+1 when dQ is split over Nc)
 #include "../../include/dprhot.h"
 
 #include <hip/hip_runtime.h>
@@ -37,6 +42,7 @@ int fail(int code, const char* fmt, ...) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 bool use_tr() {  // DPRHOT_NO_TR=1 swaps the LDS transpose read for plain 16-bit gathers (cross-check)
   static const bool v = []() {
@@ -46,7 +52,7 @@ bool use_tr() {  // DPRHOT_NO_TR=1 swaps the LDS transpose read for plain 16-bit
   return v;
 }
 
-int force_tile() {  // DPRHOT_TILE=0..3 pins the tile config (tuning / tests)
+int force_tile() {  // DPRHOT_TILE=0..5 pins the tile config of the single-GEMM launches (tuning / tests)
   static const int v = []() {
     const char* e = getenv("DPRHOT_TILE");
     return e ? atoi(e) : -1;
@@ -54,31 +60,43 @@ int force_tile() {  // DPRHOT_TILE=0..3 pins the tile config (tuning / tests)
   return v;
 }
 
-constexpr int kNumCU = 256;
-
-// tile configurations, largest first
-struct TileCfg { int bm, bn; };
-constexpr TileCfg kTiles[4] = {{128, 128}, {64, 128}, {64, 64}, {32, 64}};
-
-// Largest tile (with BM no larger than M needs) that still yields >= want workgroups; else the one with most.
-int pick_tile(int M, int N, int splits_hint, int want) {
-  if (force_tile() >= 0 && force_tile() < 4) return force_tile();
-  const int bm_cap = M <= 32 ? 32 : (M <= 64 ? 64 : 128);
-  int best = -1;
-  for (int t = 0; t < 4; ++t) {
-    if (kTiles[t].bm > bm_cap) continue;
-    if (best < 0) best = t;
-    const long wgs = (long)cdiv(M, kTiles[t].bm) * cdiv(N, kTiles[t].bn) * splits_hint;
-    if (wgs >= want) return t;
-    best = t;  // keeps shrinking: smallest admissible tile has the most workgroups
-  }
-  return best;
+bool unfused_bwd() {  // DPRHOT_UNFUSED_BWD=1: dC and dQ as two launches (A/B of the horizontal fusion)
+  static const bool v = []() {
+    const char* e = getenv("DPRHOT_UNFUSED_BWD");
+    return e && e[0] == '1';
+  }();
+  return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool AK, bool BKM, bool TR, class Epi>
+constexpr int kNumCU = 256;
+
+// tile configurations {BM, BN, BK}
+struct TileSpec { int bm, bn, bk; };
+constexpr int kNumTiles = 6;
+constexpr TileSpec kTiles[kNumTiles] = {{128, 128, 64}, {64, 128, 64}, {64, 64, 64}, {32, 64, 64}, {32, 64, 256}, {32, 32, 256}};
+
+// Tile for D[M,N] with contraction length K: the largest tile (BM capped by M) that still yields `want`
+// workgroups, else the smallest; small-M problems with a long K use the BK=256 variants (latency-bound:
+// fewer, fatter K steps keep a whole K range in flight).
+int pick_tile(int M, int N, int K, int splits_hint, int want) {
+  if (force_tile() >= 0 && force_tile() < kNumTiles) return force_tile();
+  if (M <= 32) {
+    if (K < 256) return 3;
+    const long wg64 = (long)cdiv(N, 64) * splits_hint;
+    return wg64 >= want / 2 ? 4 : 5;
+  }
+  const int first = M <= 64 ? 1 : 0;
+  for (int t = first; t <= 2; ++t) {
+    const long wgs = (long)cdiv(M, kTiles[t].bm) * cdiv(N, kTiles[t].bn) * splits_hint;
+    if (wgs >= want) return t;
+  }
+  return 2;
+}
+
+template <int BM, int BN, int BK, bool AK, bool BKM, bool TR, class Epi, bool AF = false, bool BF = false>
 int launch_one(const GemmArgs& a, const Epi& epi, int splits, hipStream_t st) {
-  auto kern = gemm_bf16_kernel<BM, BN, WM, WN, AK, BKM, TR, Epi>;
-  constexpr size_t lds = gemm_lds_bytes<BM, BN, AK, BKM>();
+  auto kern = gemm_bf16_kernel<BM, BN, BK, 2, 2, AK, BKM, TR, Epi, AF, BF>;
+  constexpr size_t lds = gemm_lds_bytes<BM, BN, BK, AK, BKM>();
   static bool attr_done = false;  // benign race: idempotent
   if (lds > 48 * 1024 && !attr_done) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -94,22 +112,75 @@ template <bool AK, bool BKM, class Epi>
 int launch_gemm(int tile, const GemmArgs& a, const Epi& epi, int splits, hipStream_t st) {
   constexpr bool needs_tr = !(AK && BKM);
   const bool tr = needs_tr ? use_tr() : false;
-#define DPRHOT_TILE_CASE(T, BM, BN)                                                           \
-  case T:                                                                                     \
-    if constexpr (needs_tr) {                                                                 \
-      return tr ? launch_one<BM, BN, 2, 2, AK, BKM, true, Epi>(a, epi, splits, st)            \
-                : launch_one<BM, BN, 2, 2, AK, BKM, false, Epi>(a, epi, splits, st);          \
-    } else {                                                                                  \
-      return launch_one<BM, BN, 2, 2, AK, BKM, false, Epi>(a, epi, splits, st);               \
+#define DPRHOT_TILE_CASE(T, BM, BN, BK_)                                                       \
+  case T:                                                                                      \
+    if constexpr (needs_tr) {                                                                  \
+      return tr ? launch_one<BM, BN, BK_, AK, BKM, true, Epi>(a, epi, splits, st)              \
+                : launch_one<BM, BN, BK_, AK, BKM, false, Epi>(a, epi, splits, st);            \
+    } else {                                                                                   \
+      return launch_one<BM, BN, BK_, AK, BKM, false, Epi>(a, epi, splits, st);                 \
     }
   switch (tile) {
-    DPRHOT_TILE_CASE(0, 128, 128)
-    DPRHOT_TILE_CASE(1, 64, 128)
-    DPRHOT_TILE_CASE(2, 64, 64)
-    DPRHOT_TILE_CASE(3, 32, 64)
+    DPRHOT_TILE_CASE(0, 128, 128, 64)
+    DPRHOT_TILE_CASE(1, 64, 128, 64)
+    DPRHOT_TILE_CASE(2, 64, 64, 64)
+    DPRHOT_TILE_CASE(3, 32, 64, 64)
+    DPRHOT_TILE_CASE(4, 32, 64, 256)
+    DPRHOT_TILE_CASE(5, 32, 32, 256)
   }
 #undef DPRHOT_TILE_CASE
   return fail(DPRHOT_E_UNSUPPORTED, "bad tile id %d", tile);
+}
+
+// sim GEMM reading fp32 operands directly (AF: q is fp32, BF: c is fp32); bf16 copies go to a.Acopy / a.Bcopy
+template <bool AF, bool BF>
+int launch_sim_f32(int tile, const GemmArgs& a, const EpiSim& epi, hipStream_t st) {
+  switch (tile) {
+    case 0: return launch_one<128, 128, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+    case 1: return launch_one<64, 128, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+    case 2: return launch_one<64, 64, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+    case 3: return launch_one<32, 64, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+    case 4: return launch_one<32, 64, 256, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+    case 5: return launch_one<32, 32, 256, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+  }
+  return fail(DPRHOT_E_UNSUPPORTED, "bad tile id %d", tile);
+}
+
+// ---- backward pair: dC (tile 0 or 2) next to dQ (tile 0, 2 or 4) in one launch --------------------------
+template <class C1, class C2>
+int launch_pair_one(const GemmArgs& a1, const EpiScaleF32& e1, const GemmArgs& a2, const EpiScaleF32& e2, int splits2,
+                    hipStream_t st) {
+  auto kern = gemm_pair_kernel<C1, C2, EpiScaleF32, EpiScaleF32>;
+  constexpr size_t lds = C1::lds > C2::lds ? C1::lds : C2::lds;
+  static bool attr_done = false;
+  if (lds > 48 * 1024 && !attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  const int nbx1 = cdiv(a1.N, C1::BN), nby1 = cdiv(a1.M, C1::BM);
+  const int nbx2 = cdiv(a2.N, C2::BN), nby2 = cdiv(a2.M, C2::BM);
+  const long blocks = (long)nbx1 * nby1 + (long)nbx2 * nby2 * splits2;
+  if (blocks > 0x7fffffffL) return fail(DPRHOT_E_UNSUPPORTED, "grid too large");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a1, e1, nbx1, nby1, a2, e2, nbx2, nby2);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+template <bool TR>
+int launch_pair_tr(int t1, int t2, const GemmArgs& a1, const EpiScaleF32& e1, const GemmArgs& a2, const EpiScaleF32& e2,
+                   int splits2, hipStream_t st) {
+  using DC0 = GemmCfg<128, 128, 64, false, false, TR>;
+  using DC2 = GemmCfg<64, 64, 64, false, false, TR>;
+  using DQ0 = GemmCfg<128, 128, 64, true, false, TR>;
+  using DQ2 = GemmCfg<64, 64, 64, true, false, TR>;
+  using DQ4 = GemmCfg<32, 64, 256, true, false, TR>;
+  if (t1 == 0 && t2 == 0) return launch_pair_one<DC0, DQ0>(a1, e1, a2, e2, splits2, st);
+  if (t1 == 0 && t2 == 2) return launch_pair_one<DC0, DQ2>(a1, e1, a2, e2, splits2, st);
+  if (t1 == 0 && t2 == 4) return launch_pair_one<DC0, DQ4>(a1, e1, a2, e2, splits2, st);
+  if (t1 == 2 && t2 == 0) return launch_pair_one<DC2, DQ0>(a1, e1, a2, e2, splits2, st);
+  if (t1 == 2 && t2 == 2) return launch_pair_one<DC2, DQ2>(a1, e1, a2, e2, splits2, st);
+  if (t1 == 2 && t2 == 4) return launch_pair_one<DC2, DQ4>(a1, e1, a2, e2, splits2, st);
+  return fail(DPRHOT_E_UNSUPPORTED, "no fused backward for tiles (%d,%d)", t1, t2);
 }
 
 int check_shape(int B, int Nc, int d) {
@@ -119,23 +190,68 @@ int check_shape(int B, int Nc, int d) {
   return DPRHOT_OK;
 }
 
-// split-K plan of dQ = G x C  (M = B, N = d, K = Nc)
+// split-K plan of dQ = G x C  (M = B, N = d, K = Nc); tile restricted to what the fused pair kernel has
 struct DqPlan { int tile, splits, kchunk; };
 DqPlan dq_plan(int B, int Nc, int d) {
   DqPlan p;
-  p.tile = pick_tile(B, d, 8, 2 * kNumCU);
-  const int tiles = cdiv(B, kTiles[p.tile].bm) * cdiv(d, kTiles[p.tile].bn);
-  int splits = cdiv(2 * kNumCU, tiles);
-  const int ksteps = cdiv(Nc, BK);
-  if (splits > ksteps / 2) splits = ksteps / 2;  // at least two K steps per split
+  if (B <= 32 && Nc >= 256) p.tile = 4;
+  else if (B <= 256) p.tile = 2;
+  else p.tile = 0;
+  const TileSpec ts = kTiles[p.tile];
+  const int tiles = cdiv(B, ts.bm) * cdiv(d, ts.bn);
+  const int ksteps = cdiv(Nc, ts.bk);
+  int splits = cdiv(kNumCU, tiles);
+  const int min_steps = ts.bk >= 256 ? 1 : 2;
+  if (splits > ksteps / min_steps) splits = ksteps / min_steps;
+  if (splits > 16) splits = 16;  // bounds the fp32 slab traffic (splits * B * d * 4 bytes each way)
   if (splits < 1) splits = 1;
-  if (splits > 64) splits = 64;
-  p.kchunk = cdiv(ksteps, splits) * BK;
+  p.kchunk = cdiv(ksteps, splits) * ts.bk;
   p.splits = cdiv(Nc, p.kchunk);
   return p;
 }
 
-size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
+
+// workspace carve-up (all offsets 256-byte aligned)
+struct WsLayout {
+  size_t header, gold, part_m, part_s, logits, dq_part, total;
+};
+WsLayout ws_layout(int B, int Nc, int d) {
+  WsLayout w;
+  const size_t ntmax = (size_t)cdiv(Nc, 32);
+  size_t off = 0;
+  w.header = off; off += 256;
+  w.gold = off; off += align256((size_t)B * 4);
+  w.part_m = off; off += align256((size_t)B * ntmax * 4);
+  w.part_s = off; off += align256((size_t)B * ntmax * 4);
+  w.logits = off; off += align256((size_t)B * Nc * 4);
+  const DqPlan p = dq_plan(B, Nc, d);
+  w.dq_part = off; off += align256((size_t)p.splits * B * d * 4);
+  w.total = off;
+  return w;
+}
+
+int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
+              char* ws, const WsLayout& wl, hipStream_t st, bool gemm_too) {
+  const DqPlan p = dq_plan(B, Nc, d);
+  if (gemm_too) {
+    GemmArgs a{G, C, B, d, Nc, Nc, d, p.kchunk};
+    if (p.splits == 1) {
+      EpiScaleF32 epi{dQ, B, d, h_scale, d_scale};
+      return launch_gemm<true, false>(p.tile, a, epi, 1, st);
+    }
+    EpiScaleF32 epi{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
+    if (int rc = launch_gemm<true, false>(p.tile, a, epi, p.splits, st)) return rc;
+  }
+  if (p.splits > 1) {
+    const size_t n4 = (size_t)B * d / 4;
+    const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
+                       p.splits, n4, h_scale, d_scale, dQ);
+    HIP_TRY(hipGetLastError());
+  }
+  return DPRHOT_OK;
+}
 
 }  // namespace
 
@@ -147,10 +263,7 @@ const char* dprhot_last_error(void) { return g_err; }
 int dprhot_workspace_bytes(int B, int Nc, int d, size_t* h_out) {
   REQUIRE(h_out != nullptr, "h_out is NULL");
   if (int rc = check_shape(B, Nc, d)) return rc;
-  const DqPlan p = dq_plan(B, Nc, d);
-  const size_t dq_part = align256((size_t)p.splits * B * d * sizeof(float));
-  const size_t logits = align256((size_t)B * Nc * sizeof(float));  // inbatch_fwd with S_out == NULL
-  *h_out = (dq_part > logits ? dq_part : logits) + 256;
+  *h_out = ws_layout(B, Nc, d).total;
   return DPRHOT_OK;
 }
 
@@ -166,19 +279,32 @@ int dprhot_cast_bf16(const float* src, dprhot_bf16* dst, size_t n, void* stream)
   return DPRHOT_OK;
 }
 
+int dprhot_prep(const float* q, size_t nq, dprhot_bf16* Qb, const float* c, size_t nc, dprhot_bf16* Cdst, void* stream) {
+  REQUIRE(q && Qb && c && Cdst, "NULL pointer");
+  REQUIRE(nq % 8 == 0 && nc % 8 == 0, "element counts must be multiples of 8 (nq=%zu nc=%zu)", nq, nc);
+  REQUIRE(aligned16(q) && aligned16(Qb) && aligned16(c) && aligned16(Cdst), "pointers must be 16-byte aligned");
+  const size_t n8 = (nq + nc) / 8;
+  if (n8 == 0) return DPRHOT_OK;
+  const int blocks = (int)((n8 + 255) / 256 > 2048 ? 2048 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(cast2_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, q, Qb, nq / 8, c, Cdst, nc / 8);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const uint8_t* colmask, float inv_T,
                    float* S, void* stream) {
   REQUIRE(Q && C && S, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   REQUIRE(aligned16(Q) && aligned16(C) && aligned16(S), "pointers must be 16-byte aligned");
-  GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, BK) * BK};
-  EpiSim epi{S, colmask, B, Nc, inv_T};
-  const int tile = pick_tile(B, Nc, 1, 2 * kNumCU);
+  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
+  GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
+  EpiSim epi{S, colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   return launch_gemm<true, true>(tile, a, epi, 1, (hipStream_t)stream);
 }
 
 int dprhot_softmax_ce_fwd_bwd(const float* S, int B, int Nc, const int64_t* y, int64_t y_offset, float grad_scale,
-                              const int64_t* row_win_start, int win_len, float* row_loss, float* row_lse, dprhot_bf16* G, void* stream) {
+                              const int64_t* row_win_start, int win_len, float* row_loss, float* row_lse, dprhot_bf16* G,
+                              void* stream) {
   REQUIRE(S && y, "NULL pointer");
   REQUIRE(B > 0 && Nc > 0 && Nc % 8 == 0, "bad shape B=%d Nc=%d (Nc %% 8 == 0)", B, Nc);
   REQUIRE(aligned16(S) && (G == nullptr || aligned16(G)), "pointers must be 16-byte aligned");
@@ -205,24 +331,13 @@ int dprhot_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
   REQUIRE(G && C && dQ, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   REQUIRE(aligned16(G) && aligned16(C) && aligned16(dQ), "pointers must be 16-byte aligned");
-  const DqPlan p = dq_plan(B, Nc, d);
-  GemmArgs a{G, C, B, d, Nc, Nc, d, p.kchunk};
-  if (p.splits == 1) {
-    EpiScaleF32 epi{dQ, B, d, h_scale, d_scale};
-    return launch_gemm<true, false>(p.tile, a, epi, 1, (hipStream_t)stream);
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (dq_plan(B, Nc, d).splits > 1) {
+    if (workspace == nullptr || workspace_bytes < wl.total)
+      return fail(DPRHOT_E_WORKSPACE, "dq needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+    REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
   }
-  const size_t need = (size_t)p.splits * B * d * sizeof(float);
-  if (workspace == nullptr || workspace_bytes < need)
-    return fail(DPRHOT_E_WORKSPACE, "dq needs %zu workspace bytes, got %zu", need, workspace_bytes);
-  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
-  EpiScaleF32 epi{static_cast<float*>(workspace), B, d, 1.0f, nullptr};
-  if (int rc = launch_gemm<true, false>(p.tile, a, epi, p.splits, (hipStream_t)stream)) return rc;
-  const size_t n4 = (size_t)B * d / 4;
-  const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace),
-                     p.splits, n4, h_scale, d_scale, dQ);
-  HIP_TRY(hipGetLastError());
-  return DPRHOT_OK;
+  return launch_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, static_cast<char*>(workspace), wl, (hipStream_t)stream, true);
 }
 
 int dprhot_dc(const dprhot_bf16* G, const dprhot_bf16* Q, int B, int Nc, int d, float h_scale, const float* d_scale,
@@ -231,17 +346,17 @@ int dprhot_dc(const dprhot_bf16* G, const dprhot_bf16* Q, int B, int Nc, int d, 
   if (int rc = check_shape(B, Nc, d)) return rc;
   REQUIRE(aligned16(G) && aligned16(Q) && aligned16(dC_part), "pointers must be 16-byte aligned");
   // A(m = ctx column, k = query row) = G[k][m]  (mn-major, lda = Nc);  B(k, n) = Q[k][n]  (mn-major, ldb = d)
-  GemmArgs a{G, Q, Nc, d, B, Nc, d, cdiv(B, BK) * BK};
+  GemmArgs a{G, Q, Nc, d, B, Nc, d, cdiv(B, 64) * 64};
   EpiScaleF32 epi{dC_part, Nc, d, h_scale, d_scale};
-  const int tile = pick_tile(Nc, d, 1, 2 * kNumCU);
+  const int tile = force_tile() >= 0 && force_tile() <= 3 ? force_tile() : dc_tile(B, Nc, d);
   return launch_gemm<false, false>(tile, a, epi, 1, (hipStream_t)stream);
 }
 
 int dprhot_rank_of_gold(const float* S, int rows, int cols, const int64_t* y, int64_t y_offset, int64_t* rank, void* stream) {
   REQUIRE(S && y && rank, "NULL pointer");
   REQUIRE(rows > 0 && cols > 0, "bad shape rows=%d cols=%d", rows, cols);
-  REQUIRE(cols % 4 == 0 ? aligned16(S) : true, "S must be 16-byte aligned");
   if (cols % 4 != 0) return fail(DPRHOT_E_UNSUPPORTED, "cols=%d must be a multiple of 4", cols);
+  REQUIRE(aligned16(S), "S must be 16-byte aligned");
   hipLaunchKernelGGL(rank_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, rows, cols, y, y_offset, rank);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
@@ -255,32 +370,125 @@ int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_
   return DPRHOT_OK;
 }
 
-int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
-                       const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss, float* row_lse, float* loss_sum,
-                       dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
-  REQUIRE(Q && C && y && row_loss && loss_sum, "NULL pointer");
+// launch 1 of the fused forward: logits + per-tile softmax statistics + gold logit (and clears the loss
+// accumulator words the next launch adds into)
+int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                     const uint8_t* colmask, float inv_T, float* S_out, void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(Q && C && y, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
-  float* S = S_out;
-  if (S == nullptr) {
-    // logits live in the caller's workspace for the duration of the call
-    const size_t need = (size_t)B * Nc * sizeof(float);
-    if (workspace == nullptr || workspace_bytes < need)
-      return fail(DPRHOT_E_WORKSPACE, "inbatch_fwd needs %zu workspace bytes (or S_out), got %zu", need, workspace_bytes);
-    S = static_cast<float*>(workspace);
-  }
-  if (int rc = dprhot_sim_fwd(Q, B, C, Nc, d, colmask, inv_T, S, stream)) return rc;
-  if (int rc = dprhot_softmax_ce_fwd_bwd(S, B, Nc, y, y_offset, grad_scale, nullptr, 0, row_loss, row_lse, G, stream)) return rc;
-  return dprhot_reduce_sum(row_loss, B, 1.0f, loss_sum, stream);
+  REQUIRE(aligned16(Q) && aligned16(C) && (S_out == nullptr || aligned16(S_out)), "pointers must be 16-byte aligned");
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (workspace == nullptr || workspace_bytes < wl.total)
+    return fail(DPRHOT_E_WORKSPACE, "sim_stats needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  char* ws = static_cast<char*>(workspace);
+  float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
+  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
+  GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
+  EpiSim epi{S, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m), reinterpret_cast<float*>(ws + wl.part_s),
+             y, y_offset, reinterpret_cast<float*>(ws + wl.gold), reinterpret_cast<unsigned long long*>(ws + wl.header), 2};
+  return launch_gemm<true, true>(tile, a, epi, 1, (hipStream_t)stream);
+}
+
+// launch 1 with fp32 operands: q [B,d] fp32 always; c [Nc,d] fp32 when non-NULL (single rank: no gather), else
+// Cb is the (gathered) bf16 input.  Qb (and Cb when c is given) receive the bf16 copies the backward reads.
+int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
+                         int64_t y_offset, const uint8_t* colmask, float inv_T, float* S_out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  REQUIRE(q && Qb && Cb && y, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  REQUIRE(aligned16(q) && aligned16(Qb) && aligned16(Cb) && (c == nullptr || aligned16(c)) && (S_out == nullptr || aligned16(S_out)),
+          "pointers must be 16-byte aligned");
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (workspace == nullptr || workspace_bytes < wl.total)
+    return fail(DPRHOT_E_WORKSPACE, "sim_stats needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  char* ws = static_cast<char*>(workspace);
+  float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
+  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
+  GemmArgs a{reinterpret_cast<const uint16_t*>(q), c ? reinterpret_cast<const uint16_t*>(c) : Cb, B, Nc, d, d, d,
+             cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
+  a.Acopy = Qb;
+  a.Bcopy = c ? Cb : nullptr;
+  EpiSim epi{S, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m), reinterpret_cast<float*>(ws + wl.part_s),
+             y, y_offset, reinterpret_cast<float*>(ws + wl.gold), reinterpret_cast<unsigned long long*>(ws + wl.header), 2};
+  return c ? launch_sim_f32<true, true>(tile, a, epi, (hipStream_t)stream) : launch_sim_f32<true, false>(tile, a, epi, (hipStream_t)stream);
+}
+
+// launch 2 of the fused forward: logsumexp from the statistics, G in one pass over S, loss numerator
+int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t* y, int64_t y_offset, float grad_scale,
+                          float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  REQUIRE(y && loss_sum, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  REQUIRE((G == nullptr || aligned16(G)) && (S_in == nullptr || aligned16(S_in)), "pointers must be 16-byte aligned");
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (workspace == nullptr || workspace_bytes < wl.total)
+    return fail(DPRHOT_E_WORKSPACE, "softmax_finish needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+  char* ws = static_cast<char*>(workspace);
+  const float* S = S_in ? S_in : reinterpret_cast<const float*>(ws + wl.logits);
+  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);  // same choice as dprhot_sim_stats -> same statistics layout
+  const int nt = cdiv(Nc, kTiles[tile].bn);
+  if (nt > kGfMaxPairs) return fail(DPRHOT_E_UNSUPPORTED, "Nc=%d too long for the statistics buffer (%d column tiles)", Nc, nt);
+  GFinalArgs g{S, B, Nc, y, y_offset, grad_scale, reinterpret_cast<const float*>(ws + wl.part_m),
+               reinterpret_cast<const float*>(ws + wl.part_s), nt, reinterpret_cast<const float*>(ws + wl.gold), row_loss, row_lse,
+               G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum};
+  const bool thin = (long)B * (Nc / 8) <= 256L * 256;  // latency-bound sizes: one chunk per thread
+  int rpb, xblocks;
+  gfinal_geometry(Nc, thin ? 1 : 8, &rpb, &xblocks);
+  dim3 grid(xblocks, cdiv(B, rpb));
+  if (thin) hipLaunchKernelGGL(gfinal_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(gfinal_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, g);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                       const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss, float* row_lse,
+                       float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = dprhot_sim_stats(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream)) return rc;
+  return dprhot_softmax_finish(S_out, B, Nc, d, y, y_offset, grad_scale, row_loss, row_lse, loss_sum, G, workspace, workspace_bytes,
+                               stream);
+}
+
+int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
+                           int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss,
+                           float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = dprhot_sim_stats_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream))
+    return rc;
+  return dprhot_softmax_finish(S_out, B, Nc, d, y, y_offset, grad_scale, row_loss, row_lse, loss_sum, G, workspace, workspace_bytes,
+                               stream);
 }
 
 int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_bf16* C, int B, int Nc, int d, float h_scale,
                        const float* d_scale, float* dQ, float* dC_part, void* workspace, size_t workspace_bytes, void* stream) {
   REQUIRE(G && Q && C, "NULL pointer");
-  if (dC_part != nullptr)
-    if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
-  if (dQ != nullptr)
-    if (int rc = dprhot_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, workspace, workspace_bytes, stream)) return rc;
-  return DPRHOT_OK;
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0) {
+    if (dC_part != nullptr)
+      if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
+    if (dQ != nullptr)
+      if (int rc = dprhot_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, workspace, workspace_bytes, stream)) return rc;
+    return DPRHOT_OK;
+  }
+  REQUIRE(aligned16(G) && aligned16(Q) && aligned16(C) && aligned16(dQ) && aligned16(dC_part), "pointers must be 16-byte aligned");
+  const WsLayout wl = ws_layout(B, Nc, d);
+  const DqPlan p = dq_plan(B, Nc, d);
+  char* ws = static_cast<char*>(workspace);
+  if (p.splits > 1 && (ws == nullptr || workspace_bytes < wl.total))
+    return fail(DPRHOT_E_WORKSPACE, "inbatch_bwd needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+  // one launch: [dC tiles | dQ tiles x splits]
+  GemmArgs a1{G, Q, Nc, d, B, Nc, d, cdiv(B, 64) * 64};
+  EpiScaleF32 e1{dC_part, Nc, d, h_scale, d_scale};
+  GemmArgs a2{G, C, B, d, Nc, Nc, d, p.kchunk};
+  EpiScaleF32 e2 = p.splits == 1 ? EpiScaleF32{dQ, B, d, h_scale, d_scale}
+                                 : EpiScaleF32{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
+  const int t1 = dc_tile(B, Nc, d);
+  const int rc = use_tr() ? launch_pair_tr<true>(t1, p.tile, a1, e1, a2, e2, p.splits, st)
+                          : launch_pair_tr<false>(t1, p.tile, a1, e1, a2, e2, p.splits, st);
+  if (rc) return rc;
+  return launch_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, ws, wl, st, /*gemm_too=*/false);
 }
 
 }  // extern "C"

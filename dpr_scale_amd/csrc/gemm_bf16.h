@@ -8,12 +8,24 @@
 // mn-major tile is staged row-for-row into LDS and handed to the matrix core through the gfx950 LDS
 // transpose read (ds_read_b64_tr_b16).
 //
-// Geometry: 256 threads = 4 wave64 as WM x WN; block tile BM x BN, K step 64; v_mfma_f32_16x16x32_bf16.
-// Staging is global -> VGPR -> LDS with the loads for tile t+1 issued before the MFMAs of tile t and the
-// LDS writes after them (two LDS buffers, one barrier per K step).
+// Geometry: 256 threads = 4 wave64 as WM x WN; block tile BM x BN, K step BK (64 for big tiles, up to 256 for
+// the small-M tiles of the training shapes so that a whole K range is in flight at once -- those launches
+// are latency-bound, not bandwidth-bound); v_mfma_f32_16x16x32_bf16.
+// Staging is global -> VGPR -> LDS through PF register stages (the loads of 2-4 K steps are in flight at
+// once), two LDS buffers, one barrier per K step.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#ifdef DPRHOT_TIMING
+extern __device__ unsigned long long g_dprhot_tm[64];
+#define DPRHOT_TM(i)                                                                       \
+  do {                                                                                     \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dprhot_tm[i] = wall_clock64(); \
+  } while (0)
+#else
+#define DPRHOT_TM(i) do {} while (0)
+#endif
 
 namespace dprhot {
 
@@ -21,19 +33,20 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 64;        // K step (bf16 elements)
-constexpr int KPAD = 8;       // k-major LDS row = 64 + 8 bf16 = 144 B (row-to-row bank rotation)
-constexpr int MNPAD = 16;     // mn-major LDS row = R + 16 bf16
+constexpr int KPAD = 8;    // k-major LDS row = BK + 8 bf16 (row-to-row bank rotation)
+constexpr int MNPAD = 16;  // mn-major LDS row = R + 16 bf16
 
 struct GemmArgs {
   const uint16_t* A;
   const uint16_t* B;
   int M, N, K;
   int lda, ldb;  // leading dimensions in elements
-  int kchunk;    // K range per blockIdx.z (multiple of BK); == K when not split
+  int kchunk;    // K range per split (multiple of BK); >= K when not split
+  uint16_t* Acopy = nullptr;  // fp32 operands only: where the staged tile is also stored as bf16 (same layout), or null
+  uint16_t* Bcopy = nullptr;
 };
 
-template <int R, bool KMAJOR>
+template <int R, int BK, bool KMAJOR>
 struct TileGeom {
   static constexpr int kRowStride = KMAJOR ? (BK + KPAD) : (R + MNPAD);  // elements
   static constexpr int kRows = KMAJOR ? R : BK;
@@ -42,51 +55,105 @@ struct TileGeom {
   static constexpr int kIters = (kChunks + 255) / 256;
 };
 
-template <int R, bool KMAJOR>
+// F32: the operand lives in HBM as fp32 (encoder output); a chunk of 8 values is two 16-byte loads, rounded to
+// bf16 (RNE) on its way into LDS -- the separate cast launch and its round trip through HBM disappear.
+template <int R, int BK, bool KMAJOR, bool F32 = false>
 struct StageRegs {
-  uint4 v[TileGeom<R, KMAJOR>::kIters];
+  uint4 v[TileGeom<R, BK, KMAJOR>::kIters * (F32 ? 2 : 1)];
 };
 
+// two fp32 -> one dword of two bf16, round-to-nearest-even: a single v_cvt_pk_bf16_f32 on gfx950
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  const f32x2_t v = {a, b};
+  const bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pack_bf16_rne(uint32_t a, uint32_t b) {  // two fp32 bit patterns -> bf16 pair
+  return cvt_pk_bf16(__uint_as_float(a), __uint_as_float(b));
+}
+
 // global -> registers: each thread fetches kIters 16-byte chunks of the tile (zero outside the matrix)
-template <int R, bool KMAJOR>
-__device__ __forceinline__ void stage_load(StageRegs<R, KMAJOR>& regs, const uint16_t* __restrict__ P, int ld, int r0,
+template <int R, int BK, bool KMAJOR, bool F32>
+__device__ __forceinline__ void stage_load(StageRegs<R, BK, KMAJOR, F32>& regs, const uint16_t* __restrict__ P, int ld, int r0,
                                            int rdim, int k0, int kend, int tid) {
-  using G = TileGeom<R, KMAJOR>;
+  // Branch-free: every load executes, on a clamped address.  Rows of the M/N dimension beyond the matrix only
+  // feed output rows/columns that are never stored, so they may hold anything; positions beyond the K range
+  // would enter every sum, so stage_store zeroes them on their way into LDS (a select, not a branch).
+  using G = TileGeom<R, BK, KMAJOR>;
+  constexpr int ES = F32 ? 2 : 1;  // element size in uint16 units
 #pragma unroll
   for (int it = 0; it < G::kIters; ++it) {
     const int c = tid + it * 256;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u), w = make_uint4(0u, 0u, 0u, 0u);
     if (G::kChunks % 256 == 0 || c < G::kChunks) {
+      size_t off;
+      bool kok;
       if constexpr (KMAJOR) {
-        const int row = c >> 3, kc = c & 7;
-        const int gr = r0 + row, gk = k0 + kc * 8;
-        if (gr < rdim && gk < kend) v = *reinterpret_cast<const uint4*>(P + (size_t)gr * ld + gk);
+        constexpr int CPR = BK / 8;  // chunks per row
+        const int row = c / CPR, kc = c % CPR;
+        const int gr = min(r0 + row, rdim - 1), gk = k0 + kc * 8;
+        kok = gk < kend;
+        off = (size_t)gr * ld + (kok ? gk : 0);
       } else {
         constexpr int CPR = R / 8;  // chunks per k-row
         const int krow = c / CPR, mc = c % CPR;
-        const int gk = k0 + krow, gr = r0 + mc * 8;
-        if (gk < kend && gr < rdim) v = *reinterpret_cast<const uint4*>(P + (size_t)gk * ld + gr);
+        const int gk = k0 + krow, gr = min(r0 + mc * 8, rdim - 8);
+        kok = gk < kend;
+        off = (size_t)(kok ? gk : 0) * ld + gr;
       }
+      const uint16_t* src = P + off * ES;
+      v = *reinterpret_cast<const uint4*>(src);  // NOT touched here (a select would park an s_waitcnt right after
+      if constexpr (F32) w = *reinterpret_cast<const uint4*>(src + 8);  // the load): stage_store zeroes beyond-K chunks
     }
-    regs.v[it] = v;
+    if constexpr (F32) {
+      regs.v[2 * it] = v;
+      regs.v[2 * it + 1] = w;
+    } else {
+      regs.v[it] = v;
+    }
   }
 }
 
 // registers -> LDS tile
-template <int R, bool KMAJOR>
-__device__ __forceinline__ void stage_store(const StageRegs<R, KMAJOR>& regs, uint16_t* T, int tid) {
-  using G = TileGeom<R, KMAJOR>;
+// (copy != nullptr, fp32 operands only: the bf16 image of the chunk is also written to HBM at the operand's own
+// [row][ld] position -- the backward GEMMs read that copy)
+template <int R, int BK, bool KMAJOR, bool F32>
+__device__ __forceinline__ void stage_store(const StageRegs<R, BK, KMAJOR, F32>& regs, uint16_t* T, int tid, uint16_t* copy, int ld,
+                                            int r0, int rdim, int k0, int kend) {
+  using G = TileGeom<R, BK, KMAJOR>;
 #pragma unroll
   for (int it = 0; it < G::kIters; ++it) {
     const int c = tid + it * 256;
     if (G::kChunks % 256 == 0 || c < G::kChunks) {
+      uint4 v;
+      if constexpr (F32) {
+        const uint4 a = regs.v[2 * it], b = regs.v[2 * it + 1];
+        v = make_uint4(pack_bf16_rne(a.x, a.y), pack_bf16_rne(a.z, a.w), pack_bf16_rne(b.x, b.y), pack_bf16_rne(b.z, b.w));
+      } else {
+        v = regs.v[it];
+      }
+      {
+        const int kpos = KMAJOR ? (k0 + (c % (BK / 8)) * 8) : (k0 + c / (R / 8));
+        if (kpos >= kend) v = make_uint4(0u, 0u, 0u, 0u);  // beyond the K range: contributes nothing
+      }
       if constexpr (KMAJOR) {
-        const int row = c >> 3, kc = c & 7;
-        *reinterpret_cast<uint4*>(T + row * G::kRowStride + kc * 8) = regs.v[it];
+        constexpr int CPR = BK / 8;
+        const int row = c / CPR, kc = c % CPR;
+        *reinterpret_cast<uint4*>(T + row * G::kRowStride + kc * 8) = v;
+        if constexpr (F32) {
+          const int gr = r0 + row, gk = k0 + kc * 8;
+          if (copy != nullptr && gr < rdim && gk < kend) *reinterpret_cast<uint4*>(copy + (size_t)gr * ld + gk) = v;
+        }
       } else {
         constexpr int CPR = R / 8;
         const int krow = c / CPR, mc = c % CPR;
-        *reinterpret_cast<uint4*>(T + krow * G::kRowStride + mc * 8) = regs.v[it];
+        *reinterpret_cast<uint4*>(T + krow * G::kRowStride + mc * 8) = v;
+        if constexpr (F32) {
+          const int gk = k0 + krow, gr = r0 + mc * 8;
+          if (copy != nullptr && gk < kend && gr < rdim) *reinterpret_cast<uint4*>(copy + (size_t)gk * ld + gr) = v;
+        }
       }
     }
   }
@@ -94,15 +161,16 @@ __device__ __forceinline__ void stage_store(const StageRegs<R, KMAJOR>& regs, ui
 
 // MFMA operand fragment for the 16 rows r0..r0+15 and the 32-wide k slice kk of an LDS tile.
 // Lane l = (g = l >> 4, i = l & 15) receives row r0 + i, k = kk*32 + g*8 + {0..7}.
-template <int R, bool KMAJOR, bool USE_TR>
+template <int R, int BK, bool KMAJOR, bool USE_TR>
 __device__ __forceinline__ bf16x8 load_frag(const uint16_t* T, int r0, int kk, int lane) {
-  using G = TileGeom<R, KMAJOR>;
+  using G = TileGeom<R, BK, KMAJOR>;
   const int i = lane & 15, g = lane >> 4;
   if constexpr (KMAJOR) {
     return *reinterpret_cast<const bf16x8*>(T + (r0 + i) * G::kRowStride + kk * 32 + g * 8);
   } else if constexpr (USE_TR) {
     // ds_read_b64_tr_b16: within each 16-lane group, source lane s supplies 4 contiguous bf16 =
     // row (s >> 2), columns 4*(s & 3).. of a 4 x 16 block; result lane i receives column i of that block.
+    // (verified on MI355X by csrc/selftest "trdump")
     const uint16_t* p = T + (kk * 32 + g * 8 + (i >> 2)) * G::kRowStride + r0 + (i & 3) * 4;
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p));
@@ -121,24 +189,39 @@ __device__ __forceinline__ bf16x8 load_frag(const uint16_t* T, int r0, int kk, i
   }
 }
 
-// Epilogue functors receive one accumulator fragment: rows m..m+3 (m % 4 == 0), one column n.
-// They are responsible for bounds (m + r < M, n < N).
+template <int BM, int BN, int BK, bool A_KMAJOR, bool B_KMAJOR>
+constexpr size_t gemm_lds_bytes() {
+  const size_t tiles = 2 * (size_t)(TileGeom<BM, BK, A_KMAJOR>::kElems + TileGeom<BN, BK, B_KMAJOR>::kElems) * sizeof(uint16_t);
+  const size_t epi = (size_t)BM * 4 * 2 * sizeof(float);  // epilogue scratch: (max,sum) per row per wave column
+  return tiles > epi ? tiles : epi;
+}
 
-template <int BM, int BN, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool USE_TR, class Epi>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p, Epi epi) {
+// What an epilogue sees of one workgroup's tile.
+struct TileCtx {
+  int m0, n0;      // tile origin
+  int wm, wn;      // this wave's position in the WM x WN grid
+  int lane, tid;
+  int bx, nbx;     // column-tile index and count
+  int bz;          // split-K slab
+  float* scratch;  // the LDS tile memory, free for reuse (all waves are past the last barrier)
+};
+
+// One workgroup tile: D[m0.., n0..] over K range of split bz; then epi.finish(acc, ctx).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool USE_TR, class Epi, bool A_F32 = false,
+          bool B_F32 = false>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const Epi& epi, int bx, int by, int bz, int nbx, uint16_t* smem) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
   static_assert(TM >= 1 && TN >= 1, "wave tile");
-  using GA = TileGeom<BM, A_KMAJOR>;
-  using GB = TileGeom<BN, B_KMAJOR>;
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  using GA = TileGeom<BM, BK, A_KMAJOR>;
+  using GB = TileGeom<BN, BK, B_KMAJOR>;
   uint16_t* const As0 = smem;
   uint16_t* const Bs0 = smem + 2 * GA::kElems;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.kchunk;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg + BK - 1) / BK;
 
@@ -148,91 +231,288 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p, Epi epi) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  StageRegs<BM, A_KMAJOR> ra;
-  StageRegs<BN, B_KMAJOR> rb;
-  if (nt > 0) {
-    stage_load<BM, A_KMAJOR>(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
-    stage_load<BN, B_KMAJOR>(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
-    stage_store<BM, A_KMAJOR>(ra, As0, tid);
-    stage_store<BN, B_KMAJOR>(rb, Bs0, tid);
-  }
-  __syncthreads();
+  // the epilogue's own global reads (labels, mask bytes, the grad_output scalar) are issued now, so that their
+  // latency hides under the K loop instead of trailing it
+  DPRHOT_TM(0);
+  const TileCtx ctx{m0, n0, wm, wn, lane, tid, bx, nbx, bz, reinterpret_cast<float*>(smem)};
+  const auto eraw = epi.template begin<BM, BN, WM, WN, TM, TN>(ctx);
 
-  for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    const bool more = (t + 1 < nt);
-    const uint16_t* Ac = As0 + cur * GA::kElems;
-    const uint16_t* Bc = Bs0 + cur * GB::kElems;
-    if (more) {
-      stage_load<BM, A_KMAJOR>(ra, p.A, p.lda, m0, p.M, kbeg + (t + 1) * BK, kend, tid);
-      stage_load<BN, B_KMAJOR>(rb, p.B, p.ldb, n0, p.N, kbeg + (t + 1) * BK, kend, tid);
+  // PF register stages: the loads of K steps t .. t+PF-1 are in flight together (a small-M launch is bound by
+  // the latency of dependent loads, not by bandwidth); LDS is double-buffered, one barrier per K step.
+  constexpr int kStageRegs = GA::kIters * (A_F32 ? 2 : 1) + GB::kIters * (B_F32 ? 2 : 1);
+  constexpr int PF = kStageRegs <= 6 ? 4 : ((kStageRegs <= 8 || (BM * BN <= 32 * 32 && kStageRegs <= 16)) ? 3 : 2);
+  StageRegs<BM, BK, A_KMAJOR, A_F32> ra[PF];
+  StageRegs<BN, BK, B_KMAJOR, B_F32> rb[PF];
+  uint16_t* const acopy = (A_F32 && bx == 0) ? p.Acopy : nullptr;  // each operand row is copied by exactly one tile column/row
+  uint16_t* const bcopy = (B_F32 && by == 0) ? p.Bcopy : nullptr;
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (u < nt) {
+      stage_load<BM, BK, A_KMAJOR, A_F32>(ra[u], p.A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
+      stage_load<BN, BK, B_KMAJOR, B_F32>(rb[u], p.B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
     }
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      bf16x8 af[TM], bfr[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = load_frag<BM, A_KMAJOR, USE_TR>(Ac, wm * (BM / WM) + a * 16, kk, lane);
-#pragma unroll
-      for (int b = 0; b < TN; ++b) bfr[b] = load_frag<BN, B_KMAJOR, USE_TR>(Bc, wn * (BN / WN) + b * 16, kk, lane);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-    }
-    if (more) {
-      stage_store<BM, A_KMAJOR>(ra, As0 + (cur ^ 1) * GA::kElems, tid);
-      stage_store<BN, B_KMAJOR>(rb, Bs0 + (cur ^ 1) * GB::kElems, tid);
-    }
-    __syncthreads();
-  }
 
-  // C/D layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
-  const int i = lane & 15, g = lane >> 4;
+  // The epilogue's prefetched words are consumed HERE: they were issued before the tile loads, so this wait is a
+  // counted vmcnt(<tile loads>) that costs nothing extra.  Consuming them only in the epilogue would force a
+  // vmcnt(0) there (the counter is in-order and also counts stores): a full store round trip, +1.7 us measured.
+  const auto est = epi.template settle<BM, BN, WM, WN, TM, TN>(ctx, eraw);
+
+  for (int t0 = 0; t0 < nt; t0 += PF) {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int u = 0; u < PF; ++u) {
+      const int t = t0 + u;
+      if (t < nt) {  // uniform across the workgroup
+        const int cur = t & 1;
+        uint16_t* Ac = As0 + cur * GA::kElems;
+        uint16_t* Bc = Bs0 + cur * GB::kElems;
+        if (t == 0) DPRHOT_TM(1);
+        stage_store<BM, BK, A_KMAJOR, A_F32>(ra[u], Ac, tid, acopy, p.lda, m0, p.M, kbeg + t * BK, kend);
+        stage_store<BN, BK, B_KMAJOR, B_F32>(rb[u], Bc, tid, bcopy, p.ldb, n0, p.N, kbeg + t * BK, kend);
+        if (t == 0) DPRHOT_TM(2);
+        __syncthreads();  // tile t visible; every wave is past its MFMAs on this buffer (step t-2)
+        if (t == 0) DPRHOT_TM(3);
+        if (t + PF < nt) {
+          stage_load<BM, BK, A_KMAJOR, A_F32>(ra[u], p.A, p.lda, m0, p.M, kbeg + (t + PF) * BK, kend, tid);
+          stage_load<BN, BK, B_KMAJOR, B_F32>(rb[u], p.B, p.ldb, n0, p.N, kbeg + (t + PF) * BK, kend, tid);
+        }
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int m = m0 + wm * (BM / WM) + a * 16 + g * 4;
-      const int n = n0 + wn * (BN / WN) + b * 16 + i;
-      epi(acc[a][b], m, n, (int)blockIdx.z);
+        for (int kk = 0; kk < BK / 32; ++kk) {
+          bf16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int a = 0; a < TM; ++a) af[a] = load_frag<BM, BK, A_KMAJOR, USE_TR>(Ac, wm * (BM / WM) + a * 16, kk, lane);
+#pragma unroll
+          for (int b = 0; b < TN; ++b) bfr[b] = load_frag<BN, BK, B_KMAJOR, USE_TR>(Bc, wn * (BN / WN) + b * 16, kk, lane);
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+      }
     }
+  }
+  DPRHOT_TM(4);
+  __syncthreads();  // the epilogue reuses the tile memory as scratch
+  DPRHOT_TM(5);
+
+  epi.template finish<BM, BN, WM, WN, TM, TN>(acc, ctx, est);
+  DPRHOT_TM(6);
 }
 
-template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR>
-constexpr size_t gemm_lds_bytes() {
-  return 2 * (size_t)(TileGeom<BM, A_KMAJOR>::kElems + TileGeom<BN, B_KMAJOR>::kElems) * sizeof(uint16_t);
+template <int BM, int BN, int BK, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool USE_TR, class Epi, bool A_F32 = false,
+          bool B_F32 = false>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  gemm_tile<BM, BN, BK, WM, WN, A_KMAJOR, B_KMAJOR, USE_TR, Epi, A_F32, B_F32>(p, epi, blockIdx.x, blockIdx.y, blockIdx.z,
+                                                                                gridDim.x, smem);
 }
 
-// ---- epilogues ------------------------------------------------------------------------------------------
+template <int BM_, int BN_, int BK_, bool AK_, bool BKM_, bool TR_>
+struct GemmCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_;
+  static constexpr bool AK = AK_, BKM = BKM_, TR = TR_;
+  static constexpr size_t lds = gemm_lds_bytes<BM_, BN_, BK_, AK_, BKM_>();
+};
 
-// sim_score epilogue: * inv_T, masked columns -> -inf (dpr_task.py:104,211)
+// Two independent GEMMs in ONE launch (horizontal fusion): linear block ids [0, n1) run problem 1, the rest
+// problem 2 (with split-K slabs).  Used for the backward pair dC_part = G^T Q and dQ = G C, which share only
+// their input G.
+template <class Cfg1, class Cfg2, class Epi1, class Epi2>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs p1, Epi1 e1, int nbx1, int nby1, GemmArgs p2, Epi2 e2, int nbx2,
+                                                        int nby2) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int n1 = nbx1 * nby1;
+  int id = blockIdx.x;
+  if (id < n1) {
+    gemm_tile<Cfg1::BM, Cfg1::BN, Cfg1::BK, 2, 2, Cfg1::AK, Cfg1::BKM, Cfg1::TR, Epi1>(p1, e1, id % nbx1, id / nbx1, 0, nbx1, smem);
+  } else {
+    id -= n1;
+    const int per = nbx2 * nby2;
+    const int bz = id / per;
+    id -= bz * per;
+    gemm_tile<Cfg2::BM, Cfg2::BN, Cfg2::BK, 2, 2, Cfg2::AK, Cfg2::BKM, Cfg2::TR, Epi2>(p2, e2, id % nbx2, id / nbx2, bz, nbx2, smem);
+  }
+}
+
+// ---- epilogues --------------------------------------------------------------------------------------------
+// C/D layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+
+// Reductions over the 16 lanes of a DPP row (= the 16 columns of one MFMA fragment row) with row_ror: pure VALU
+// data movement.  (__shfl_xor lowers to ds_bpermute + s_waitcnt lgkmcnt(0): ~120 cycles per step, serialised --
+// 32 of them cost the stats epilogue 1.6 us before this.)
+template <int N>
+__device__ __forceinline__ float dpp_row_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_row_ror<8>(v));
+  v = fmaxf(v, dpp_row_ror<4>(v));
+  v = fmaxf(v, dpp_row_ror<2>(v));
+  v = fmaxf(v, dpp_row_ror<1>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_row_ror<8>(v);
+  v += dpp_row_ror<4>(v);
+  v += dpp_row_ror<2>(v);
+  v += dpp_row_ror<1>(v);
+  return v;
+}
+
+__device__ __forceinline__ void ms_merge(float& m, float& s, float m2, float s2) {
+  const float M = fmaxf(m, m2);
+  if (M == -INFINITY) { m = M; s = 0.f; return; }
+  s = s * __expf(m - M) + s2 * __expf(m2 - M);
+  m = M;
+}
+
+// sim_score epilogue (dpr_task.py:104,211): * inv_T, masked columns -> -inf, fp32 store (optional) and, for the
+// fused training forward, the per-(row, column tile) softmax statistics and the gold logit, so that the row
+// logsumexp never needs a second pass over S.
 struct EpiSim {
-  float* S;
-  const uint8_t* colmask;
+  float* S;                // [M,N] or nullptr
+  const uint8_t* colmask;  // [N] or nullptr
   int M, N;
   float inv_T;
-  __device__ __forceinline__ void operator()(const f32x4& v, int m, int n, int) const {
-    if (n >= N) return;
-    const bool masked = colmask != nullptr && colmask[n] != 0;
+  float* part_m;     // [M][nbx] running max per column tile, or nullptr
+  float* part_s;     // [M][nbx] sum exp(S - max)
+  const int64_t* y;  // [M] gold column (minus y_offset)
+  int64_t y_offset;
+  float* gold;       // [M] gold logit
+  unsigned long long* zero_words;  // words to clear for the next kernel (tile (0,0) clears them), or nullptr
+  int n_zero;
+
+  // begin(): raw loads only, issued back to back BEFORE the tile loads (nothing is used here, or the compiler
+  // parks one s_waitcnt per load at the top of the kernel); settle(): turned into what finish() needs, after the
+  // tile loads have been issued.
+  template <int TM, int TN>
+  struct Raw {
+    int64_t yraw[TM][4];  // label of each row this lane holds (clamped row index)
+    uint8_t mraw[TN];     // mask byte of each column this lane holds (clamped column index)
+  };
+  template <int TM, int TN>
+  struct State {
+    int yi[TM][4];    // gold column of each row (-1: none)
+    bool masked[TN];  // column masked or outside the matrix
+  };
+
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ State<TM, TN> settle(const TileCtx& c, const Raw<TM, TN>& raw) const {
+    const int i = c.lane & 15;
+    State<TM, TN> st;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (m + r < M) S[(size_t)(m + r) * N + n] = masked ? -INFINITY : v[r] * inv_T;
+    for (int b = 0; b < TN; ++b) st.masked[b] = (c.n0 + c.wn * (BN / WN) + b * 16 + i >= N) || raw.mraw[b] != 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.yi[a][r] = part_m != nullptr ? (int)(raw.yraw[a][r] + y_offset) : -1;
+    return st;
+  }
+
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ Raw<TM, TN> begin(const TileCtx& c) const {
+    const int i = c.lane & 15, g = c.lane >> 4;
+    Raw<TM, TN> st;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = min(c.n0 + c.wn * (BN / WN) + b * 16 + i, N - 1);
+      st.mraw[b] = colmask != nullptr ? colmask[n] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = min(c.m0 + c.wm * (BM / WM) + a * 16 + g * 4 + r, M - 1);
+        st.yraw[a][r] = part_m != nullptr ? y[m] : (int64_t)-1;
+      }
+    return st;
+  }
+
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, const State<TM, TN>& st) const {
+    const int i = c.lane & 15, g = c.lane >> 4;
+    if (zero_words != nullptr && c.bx == 0 && c.m0 == 0 && c.tid < n_zero) zero_words[c.tid] = 0ull;
+    const bool (&masked)[TN] = st.masked;
+    float* red_m = c.scratch;            // [BM][WN]
+    float* red_s = c.scratch + BM * WN;  // [BM][WN]
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = c.wm * (BM / WM) + a * 16 + g * 4 + r;
+        const int m = c.m0 + lrow;
+        float v[TN];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          v[b] = masked[b] ? -INFINITY : acc[a][b][r] * inv_T;
+          mx = fmaxf(mx, v[b]);
+        }
+        if (S != nullptr && m < M) {
+#pragma unroll
+          for (int b = 0; b < TN; ++b) {
+            const int n = c.n0 + c.wn * (BN / WN) + b * 16 + i;
+            if (n < N) S[(size_t)m * N + n] = v[b];
+          }
+        }
+        if (part_m != nullptr) {
+          mx = row16_max(mx);  // row max over this wave's columns (all 16 lanes of the row get it)
+          float sm = 0.f;
+          if (mx != -INFINITY) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) sm += __expf(v[b] - mx);
+          }
+          sm = row16_sum(sm);
+          if (i == 0) { red_m[lrow * WN + c.wn] = mx; red_s[lrow * WN + c.wn] = sm; }
+          if (m < M) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+              if (st.yi[a][r] == c.n0 + c.wn * (BN / WN) + b * 16 + i) gold[m] = v[b];
+          }
+        }
+      }
+    }
+    if (part_m != nullptr) {
+      __syncthreads();
+      if (c.tid < BM && c.m0 + c.tid < M) {
+        float mx = red_m[c.tid * WN], sm = red_s[c.tid * WN];
+#pragma unroll
+        for (int w = 1; w < WN; ++w) ms_merge(mx, sm, red_m[c.tid * WN + w], red_s[c.tid * WN + w]);
+        part_m[(size_t)(c.m0 + c.tid) * c.nbx + c.bx] = mx;
+        part_s[(size_t)(c.m0 + c.tid) * c.nbx + c.bx] = sm;
+      }
+    }
   }
 };
 
-// fp32 store with a scale that may live on the device (autograd grad_output); z selects a split-K slab
+// fp32 store with a scale that may live on the device (autograd grad_output); bz selects a split-K slab
 struct EpiScaleF32 {
   float* out;  // [splits][M][N]
   int M, N;
   float h_scale;
   const float* d_scale;
-  __device__ __forceinline__ void operator()(const f32x4& v, int m, int n, int z) const {
-    if (n >= N) return;
-    const float s = h_scale * (d_scale ? *d_scale : 1.0f);
-    float* o = out + (size_t)z * M * N;
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ float begin(const TileCtx&) const {
+    return d_scale ? *d_scale : 1.0f;  // raw prefetch (see EpiSim::State)
+  }
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ float settle(const TileCtx&, float ds) const {
+    return h_scale * ds;
+  }
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, float s) const {
+    const int i = c.lane & 15, g = c.lane >> 4;
+    float* o = out + (size_t)c.bz * M * N;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (m + r < M) o[(size_t)(m + r) * N + n] = v[r] * s;
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int m = c.m0 + c.wm * (BM / WM) + a * 16 + g * 4;
+        const int n = c.n0 + c.wn * (BN / WN) + b * 16 + i;
+        if (n >= N) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (m + r < M) o[(size_t)(m + r) * N + n] = acc[a][b][r] * s;
+      }
   }
 };
 

@@ -10,10 +10,12 @@
 
 namespace dprhot {
 
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+typedef float rw_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rw_bf16x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> one dword of two bf16 (RNE): v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  const rw_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rw_bf16x2));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -48,11 +50,193 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     const float4 a = reinterpret_cast<const float4*>(src)[2 * c];
     const float4 b = reinterpret_cast<const float4*>(src)[2 * c + 1];
     uint4 o;
-    o.x = f32_to_bf16_rne(a.x) | ((uint32_t)f32_to_bf16_rne(a.y) << 16);
-    o.y = f32_to_bf16_rne(a.z) | ((uint32_t)f32_to_bf16_rne(a.w) << 16);
-    o.z = f32_to_bf16_rne(b.x) | ((uint32_t)f32_to_bf16_rne(b.y) << 16);
-    o.w = f32_to_bf16_rne(b.z) | ((uint32_t)f32_to_bf16_rne(b.w) << 16);
+    o.x = pk_bf16(a.x, a.y);
+    o.y = pk_bf16(a.z, a.w);
+    o.z = pk_bf16(b.x, b.y);
+    o.w = pk_bf16(b.z, b.w);
     reinterpret_cast<uint4*>(dst)[c] = o;
+  }
+}
+
+// one launch for both producer-side casts of a step (query rows + this rank's context rows)
+__global__ __launch_bounds__(256) void cast2_bf16_kernel(const float* __restrict__ a, uint16_t* __restrict__ ao, size_t a8,
+                                                         const float* __restrict__ b, uint16_t* __restrict__ bo, size_t b8) {
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < a8 + b8; c += (size_t)gridDim.x * blockDim.x) {
+    const float* src = c < a8 ? a : b;
+    uint16_t* dst = c < a8 ? ao : bo;
+    const size_t k = c < a8 ? c : c - a8;
+    const float4 x = reinterpret_cast<const float4*>(src)[2 * k];
+    const float4 y = reinterpret_cast<const float4*>(src)[2 * k + 1];
+    uint4 o;
+    o.x = pk_bf16(x.x, x.y);
+    o.y = pk_bf16(x.z, x.w);
+    o.z = pk_bf16(y.x, y.y);
+    o.w = pk_bf16(y.z, y.w);
+    reinterpret_cast<uint4*>(dst)[k] = o;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Second (and last) kernel of the fused training forward.  The sim kernel has left, per row, one
+// (max, sum-exp) pair per column tile and the gold logit; this kernel turns them into the row logsumexp
+// (a handful of values per row), then makes ONE streaming pass over S: G = (exp(S - lse) - onehot) * scale
+// in bf16.  Fully parallel over 8-column chunks -- no row-sized serial dependency.
+// The loss numerator is accumulated in 2^-24 fixed point with integer atomics (order-independent, hence
+// deterministic, and no fences needed: the data travels in the atomics themselves); the last workgroup
+// to arrive converts it to the float the caller reads.
+// Algorithmic HBM bytes: 4 (S read) + 2 (G write) per score.
+// ----------------------------------------------------------------------------------------------------
+struct GFinalArgs {
+  const float* S;
+  int B, Nc;
+  const int64_t* y;
+  int64_t y_offset;
+  float grad_scale;
+  const float* part_m;
+  const float* part_s;
+  int nt;  // partials per row
+  const float* gold;
+  float* row_loss;
+  float* row_lse;
+  uint16_t* G;
+  unsigned long long* acc;  // [0] fixed-point loss sum, [1] arrival ticket (zeroed by the sim kernel)
+  float* loss_sum;          // out: sum_i row_loss[i]
+};
+
+constexpr double kLossFix = 16777216.0;  // 2^24
+constexpr int kGfMaxPairs = 2048;         // (max, sum) pairs one workgroup stages in LDS
+
+// rows per workgroup / x-blocks per row for a given row length and CPT chunks per thread (host and device agree)
+__host__ __device__ inline void gfinal_geometry(int Nc, int cpt, int* rpb, int* xblocks) {
+  const int cpr = Nc >> 3, per_block = 256 * cpt;
+  if (cpr >= per_block) {
+    *rpb = 1;
+    *xblocks = (cpr + per_block - 1) / per_block;
+  } else {
+    const int r = per_block / cpr;
+    *rpb = r > 256 ? 256 : r;
+    *xblocks = 1;
+  }
+}
+// "small" problems: workgroup (0,0) reduces the loss of ALL rows itself (no atomics, no second launch)
+__host__ __device__ inline bool gfinal_small(int B, int nt) { return B <= 256 && (long)B * nt <= kGfMaxPairs; }
+
+// CPT = 8-column chunks per thread: 1 for the latency-bound training shapes (a wave's instruction stream is what
+// a microsecond-scale launch pays for, so the work is spread as thin as possible), 8 for bandwidth-bound sizes.
+template <int CPT>
+__global__ __launch_bounds__(256) void gfinal_kernel(GFinalArgs p) {
+  const int cpr = p.Nc >> 3;  // 8-column chunks per row
+  int rpb, xblocks;
+  gfinal_geometry(p.Nc, CPT, &rpb, &xblocks);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.y * rpb;
+  __shared__ float s_lse[256];
+  __shared__ float s_gold[256];
+  __shared__ int s_y[256];
+  __shared__ float s_part[4];
+  __shared__ float s_pm[kGfMaxPairs], s_ps[kGfMaxPairs];
+  // This launch is latency-bound (a few dependent trips to memory), so every global read it needs is issued up
+  // front: first the logits themselves (their addresses depend on nothing computed here), then the per-tile
+  // statistics, gold logits and labels into LDS.
+  const int c_lo = blockIdx.x * 256 * CPT;
+  const int span = xblocks > 1 ? min(256 * CPT, cpr - c_lo) : cpr;  // chunks of each row this block covers
+  const int rows_here = min(rpb, p.B - row0);
+  const int total = rows_here * span;
+  float4 va[CPT], vb[CPT];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int idx = tid + k * 256;
+    if (idx < total && p.G != nullptr) {
+      const int lr = idx / span;
+      const float* src = p.S + (size_t)(row0 + lr) * p.Nc + (size_t)(c_lo + idx - lr * span) * 8;
+      va[k] = *reinterpret_cast<const float4*>(src);
+      vb[k] = *reinterpret_cast<const float4*>(src + 4);
+    }
+  }
+  const bool small = gfinal_small(p.B, p.nt);
+  const bool owner = small && blockIdx.x == 0 && blockIdx.y == 0;  // reduces every row's loss
+  const int st_row0 = owner ? 0 : row0;                            // rows whose statistics this block stages
+  const int st_rows = owner ? p.B : rows_here;
+  const int npairs = st_rows * p.nt;
+  for (int i = tid; i < npairs; i += 256) {
+    s_pm[i] = p.part_m[(size_t)st_row0 * p.nt + i];
+    s_ps[i] = p.part_s[(size_t)st_row0 * p.nt + i];
+  }
+  if (tid < st_rows) {
+    s_gold[tid] = p.gold[st_row0 + tid];
+    s_y[tid] = (int)(p.y[st_row0 + tid] + p.y_offset);
+  }
+  __syncthreads();
+  if (p.nt <= 32) {  // one thread per row
+    if (tid < st_rows) {
+      float m = -INFINITY, sm = 0.f;
+      for (int t = 0; t < p.nt; ++t) ms_combine(m, sm, s_pm[tid * p.nt + t], s_ps[tid * p.nt + t]);
+      s_lse[tid] = m + logf(sm);
+    }
+  } else {  // one wave per row
+    for (int lr = wave; lr < st_rows; lr += 4) {
+      float m = -INFINITY, sm = 0.f;
+      for (int t = lane; t < p.nt; t += 64) ms_combine(m, sm, s_pm[lr * p.nt + t], s_ps[lr * p.nt + t]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sm, o, 64);
+        ms_combine(m, sm, m2, s2);
+      }
+      if (lane == 0) s_lse[lr] = m + logf(sm);
+    }
+  }
+  __syncthreads();
+  const int base = row0 - st_row0;  // index of this block's first row in the staged arrays
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int idx = tid + k * 256;
+    if (idx < total) {
+      const int lr = idx / span;
+      const int chunk = c_lo + idx - lr * span;
+      const int row = row0 + lr;
+      const float lse = s_lse[base + lr];
+      const int yi = s_y[base + lr];
+      if (chunk == 0) {
+        if (p.row_lse) p.row_lse[row] = lse;
+        if (p.row_loss) p.row_loss[row] = lse - s_gold[base + lr];
+      }
+      if (p.G != nullptr) {
+        const int j = chunk * 8;
+        const float v[8] = {va[k].x, va[k].y, va[k].z, va[k].w, vb[k].x, vb[k].y, vb[k].z, vb[k].w};
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float pr = __expf(v[e] - lse);  // exp(-inf) == 0 at masked columns
+          if (j + e == yi) pr -= 1.0f;
+          g[e] = pr * p.grad_scale;
+        }
+        *reinterpret_cast<uint4*>(p.G + (size_t)row * p.Nc + j) =
+            make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
+      }
+    }
+  }
+  // loss numerator.  small: the owner block sums every row (plain store).  Otherwise each row-block adds its rows
+  // with ONE fixed-point integer atomic (order-independent => deterministic) and the last arriver publishes.
+  if (small ? owner : (blockIdx.x == 0)) {
+    const float mine = tid < st_rows ? s_lse[tid] - s_gold[tid] : 0.f;  // st_rows <= 256
+    const float bl = wave_sum(mine);
+    if (lane == 0) s_part[wave] = bl;
+    __syncthreads();
+    if (tid == 0) {
+      const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
+      if (small || gridDim.y == 1) {
+        p.loss_sum[0] = (float)tot;
+      } else {
+        const long long fx = __double2ll_rn(tot * kLossFix);
+        const unsigned long long old = atomicAdd(&p.acc[0], (unsigned long long)fx);
+        asm volatile("" ::"v"(old) : "memory");  // the add has been performed at memory before the ticket is issued
+        const unsigned long long ticket = atomicAdd(&p.acc[1], 1ull);
+        if (ticket == (unsigned long long)gridDim.y - 1) {
+          const long long total_fx = (long long)atomicAdd(&p.acc[0], 0ull);
+          p.loss_sum[0] = (float)((double)total_fx / kLossFix);
+        }
+      }
+    }
   }
 }
 
@@ -137,16 +321,15 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(SoftmaxArgs p) {
     const float4 a = *reinterpret_cast<const float4*>(Srow + j);
     const float4 b = *reinterpret_cast<const float4*>(Srow + j + 4);
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint32_t o[4];
+    float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int col = j + e;
       float pr = (windowed && (col < lo || col >= hi)) ? 0.f : __expf(v[e] - lse);  // exp(-inf) == 0
       if (col == yi) pr -= 1.0f;
-      const uint16_t h = f32_to_bf16_rne(pr * gs);
-      if (e & 1) o[e >> 1] |= (uint32_t)h << 16; else o[e >> 1] = h;
+      g[e] = pr * gs;
     }
-    *reinterpret_cast<uint4*>(Grow + j) = make_uint4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<uint4*>(Grow + j) = make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
   }
 }
 

@@ -236,8 +236,30 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
     Dev<uint16_t> G2((size_t)B * Nc);
     OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, l2.p, nullptr, s2.p, G2.p, ws.p, wsb, nullptr));
     CK(hipDeviceSynchronize());
-    auto a = G2.down(), b = dG.down();
-    report("inbatch_fwd G == pieces", memcmp(a.data(), b.data(), a.size() * 2) != 0, 0);
+    auto a = G2.down();
+    auto l2h = l2.down(); auto s2h = s2.down();
+    double e3 = 0, gm = 0, e2 = 0, tot = 0;
+    for (size_t i = 0; i < a.size(); ++i) { e3 = std::max(e3, fabs(bf2f(a[i]) - rG[i])); gm = std::max(gm, fabs(rG[i])); }
+    for (int i = 0; i < B; ++i) { e2 = std::max(e2, fabs(l2h[i] - rloss[i]) / std::max(1.0, fabs(rloss[i]))); tot += rloss[i]; }
+    report("inbatch_fwd G bf16 (rel max)", e3 / gm, 4.5e-3);
+    report("inbatch_fwd row_loss", e2, 1e-5);
+    report("inbatch_fwd loss_sum", fabs(s2h[0] - tot) / std::max(1.0, fabs(tot)), 1e-5);
+    // fp32-operand forward: (q, c fp32) and (q fp32, C already bf16); bf16 copies must equal host RNE
+    for (int mode = 0; mode < 2; ++mode) {
+      Dev<float> fq((size_t)B * d), fc((size_t)Nc * d);
+      fq.up(fQ); fc.up(fC);
+      Dev<uint16_t> oq((size_t)B * d), oc((size_t)Nc * d), G3((size_t)B * Nc);
+      Dev<float> l3(B), s3(1);
+      if (mode == 1) oc.up(hC);
+      OK(dprhot_inbatch_fwd_f32(fq.p, mode == 0 ? fc.p : nullptr, oq.p, oc.p, B, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr,
+                                l3.p, nullptr, s3.p, G3.p, ws.p, wsb, nullptr));
+      CK(hipDeviceSynchronize());
+      auto hq = oq.down(); auto hc = oc.down(); auto g3 = G3.down(); auto s3h = s3.down();
+      report(mode == 0 ? "fwd_f32(q,c): bf16 copies" : "fwd_f32(q,Cb): bf16 copy",
+             (memcmp(hq.data(), hQ.data(), hq.size() * 2) != 0) + (memcmp(hc.data(), hC.data(), hc.size() * 2) != 0), 0);
+      report("fwd_f32 G == bf16-input path", memcmp(g3.data(), a.data(), a.size() * 2) != 0, 0);
+      report("fwd_f32 loss_sum", fabs(s3h[0] - tot) / std::max(1.0, fabs(tot)), 1e-5);
+    }
     OK(dprhot_inbatch_bwd(dG.p, dQ_.p, dC_.p, B, Nc, d, 2.0f, dgo.p, q2.p, c2.p, ws.p, wsb, nullptr));
     CK(hipDeviceSynchronize());
     auto x = q2.down(), y0 = ddq.down(), z = c2.down(), w = ddc.down();
@@ -261,12 +283,28 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
       printf("    TIME %-22s %9.2f us  %8.1f GB/s  %8.2f TFLOP/s\n", name, us, bytes / us * 1e-3, flops / us * 1e-6);
     };
     const double bn = (double)B * Nc, bd = (double)B * d, nd = (double)Nc * d;
+    {
+      Dev<float> fq((size_t)B * d), fc((size_t)Nc * d);
+      fq.up(fQ); fc.up(fC);
+      Dev<uint16_t> oq((size_t)B * d), oc((size_t)Nc * d);
+      OK(dprhot_prep(fq.p, (size_t)B * d, oq.p, fc.p, (size_t)Nc * d, oc.p, nullptr));
+      CK(hipDeviceSynchronize());
+      auto hq = oq.down(); auto hc = oc.down();
+      report("prep casts == host RNE", (memcmp(hq.data(), hQ.data(), hq.size() * 2) != 0) + (memcmp(hc.data(), hC.data(), hc.size() * 2) != 0), 0);
+      timeit("prep (both casts)", [&] { OK(dprhot_prep(fq.p, (size_t)B * d, oq.p, fc.p, (size_t)Nc * d, oc.p, nullptr)); }, 6 * (bd + nd), 0);
+    }
     timeit("sim_fwd", [&] { OK(dprhot_sim_fwd(dQ_.p, B, dC_.p, Nc, d, dm.p, 1.0f / T, dS.p, nullptr)); }, 2 * (bd + nd) + 4 * bn, 2 * bn * d);
     timeit("softmax_ce_fwd_bwd", [&] { OK(dprhot_softmax_ce_fwd_bwd(dS.p, B, Nc, dy.p, 0, (float)gscale, nullptr, 0, dloss.p, dlse.p, dG.p, nullptr)); }, 6 * bn, 0);
     timeit("dq", [&] { OK(dprhot_dq(dG.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ws.p, wsb, nullptr)); }, 2 * bn + 2 * nd + 4 * bd, 2 * bn * d);
     timeit("dc", [&] { OK(dprhot_dc(dG.p, dQ_.p, B, Nc, d, 2.0f, dgo.p, ddc.p, nullptr)); }, 2 * bn + 2 * bd + 4 * nd, 2 * bn * d);
     timeit("rank_of_gold", [&] { OK(dprhot_rank_of_gold(dS.p, B, Nc, dy.p, 0, drank.p, nullptr)); }, 4 * bn, 0);
     timeit("inbatch_fwd", [&] { OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, dloss.p, dlse.p, dsum.p, dG.p, ws.p, wsb, nullptr)); }, 2 * (bd + nd) + 10 * bn, 2 * bn * d);
+    {
+      Dev<float> fq((size_t)B * d), fc((size_t)Nc * d);
+      fq.up(fQ); fc.up(fC);
+      Dev<uint16_t> oq((size_t)B * d), oc((size_t)Nc * d);
+      timeit("inbatch_fwd_f32", [&] { OK(dprhot_inbatch_fwd_f32(fq.p, fc.p, oq.p, oc.p, B, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, dloss.p, dlse.p, dsum.p, dG.p, ws.p, wsb, nullptr)); }, 6 * (bd + nd) + 10 * bn, 2 * bn * d);
+    }
     timeit("inbatch_bwd", [&] { OK(dprhot_inbatch_bwd(dG.p, dQ_.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ddc.p, ws.p, wsb, nullptr)); }, 4 * bn + 2 * (bd + nd) + 4 * (bd + nd), 4 * bn * d);
     timeit("fwd+bwd", [&] {
       OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, dloss.p, dlse.p, dsum.p, dG.p, ws.p, wsb, nullptr));

@@ -70,6 +70,19 @@ class HipKernels:
         self._lib.check(self.lib.dprhot_cast_bf16(_ptr(src), _ptr(dst), n, self._stream()), "dprhot_cast_bf16")
         return dst
 
+    def prep(self, q, Qb, c, Cdst):
+        """Both producer-side casts in one launch (fp32 inputs); other dtypes take the per-tensor path."""
+        self._require_gpu(q, Qb, c, Cdst)
+        if q.dtype != torch.float32 or c.dtype != torch.float32:
+            self.cast_bf16(q, Qb)
+            self.cast_bf16(c, Cdst)
+            return
+        q = q.detach().contiguous()
+        c = c.detach().contiguous()
+        assert Qb.is_contiguous() and Cdst.is_contiguous() and Qb.numel() == q.numel() and Cdst.numel() == c.numel()
+        self._lib.check(self.lib.dprhot_prep(_ptr(q), q.numel(), _ptr(Qb), _ptr(c), c.numel(), _ptr(Cdst), self._stream()),
+                        "dprhot_prep")
+
     def inbatch_fwd(self, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
         self._require_gpu(Qb, Cb, y, colmask)
         B, d = Qb.shape
@@ -86,6 +99,28 @@ class HipKernels:
             _ptr(Qb), B, _ptr(Cb), Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T), float(grad_scale),
             _ptr(S), _ptr(row_loss), _ptr(row_lse), _ptr(loss_sum), _ptr(G), _ptr(ws), ws.numel(), self._stream()),
             "dprhot_inbatch_fwd")
+        return row_loss, row_lse, loss_sum, G, S
+
+    def inbatch_fwd_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
+        """Forward straight from the fp32 encoder outputs: q [B,d] fp32; c [Nc,d] fp32 or None (Cb already holds
+        the gathered bf16 rows).  Fills Qb (and Cb when c is given) with the bf16 images the backward reads."""
+        self._require_gpu(q, c, Qb, Cb, y, colmask)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        dev = Qb.device
+        q = q.detach().contiguous()
+        c = c.detach().contiguous() if c is not None else None
+        assert q.dtype == torch.float32 and (c is None or (c.dtype == torch.float32 and c.shape[0] == Nc))
+        row_loss = torch.empty(B, dtype=torch.float32, device=dev)
+        row_lse = torch.empty(B, dtype=torch.float32, device=dev)
+        loss_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        G = torch.empty((B, Nc), dtype=_BF16, device=dev) if want_G else None
+        S = torch.empty((B, Nc), dtype=torch.float32, device=dev) if want_logits else None
+        ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_inbatch_fwd_f32(
+            _ptr(q), _ptr(c), _ptr(Qb), _ptr(Cb), B, Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T),
+            float(grad_scale), _ptr(S), _ptr(row_loss), _ptr(row_lse), _ptr(loss_sum), _ptr(G), _ptr(ws), ws.numel(),
+            self._stream()), "dprhot_inbatch_fwd_f32")
         return row_loss, row_lse, loss_sum, G, S
 
     def inbatch_bwd(self, G, Qb, Cb, h_scale, d_scale, need_dq=True, need_dc=True):
@@ -201,16 +236,22 @@ class InBatchContrastive(torch.autograd.Function):
         Nc_pad = _pad_cols(Nc)
 
         Qb = kn.empty((B, d), _BF16, q)
-        kn.cast_bf16(q, Qb)
         Cb = kn.empty((Nc_pad, d), _BF16, c)
         mask_all = kn.empty((Nc_pad,), torch.uint8, c)
         m8 = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask.to(torch.uint8)
+        # fp32 encoder outputs are consumed as they are by the sim kernel (it rounds to bf16 while staging and
+        # leaves the bf16 images in Qb / Cb); only what must travel over xGMI is cast beforehand.
+        direct = q.dtype == torch.float32 and c.dtype == torch.float32 and Nc_pad == Nc and hasattr(kn, "inbatch_fwd_f32")
         if W == 1:
-            kn.cast_bf16(c, Cb[:n_ctx])
+            if not direct:
+                kn.prep(q, Qb, c, Cb[:n_ctx])
             mask_all[:n_ctx].copy_(m8)
         else:
             send = kn.empty((n_ctx, d), _BF16, c)
-            kn.cast_bf16(c, send)
+            if direct:
+                kn.cast_bf16(c, send)
+            else:
+                kn.prep(q, Qb, c, send)
             h1 = D.all_gather_rows(send, Cb[:Nc], group, async_op=True)
             h2 = D.all_gather_rows(m8.contiguous(), mask_all[:Nc], group, async_op=True)
             h1.wait()
@@ -221,7 +262,11 @@ class InBatchContrastive(torch.autograd.Function):
 
         inv_T = 1.0 / float(temperature)
         grad_scale = inv_T / Nq  # d loss / d S of the global mean, before grad_output
-        row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, r * n_ctx, mask_all, inv_T, grad_scale)
+        if direct:
+            row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd_f32(q, c if W == 1 else None, Qb, Cb, pos_idx, r * n_ctx,
+                                                                   mask_all, inv_T, grad_scale)
+        else:
+            row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, r * n_ctx, mask_all, inv_T, grad_scale)
         if W > 1:
             D.all_reduce_sum(loss_sum, group)
         loss = (loss_sum / Nq).reshape(())

@@ -54,6 +54,10 @@ int dprhot_workspace_bytes(int B, int Nc, int d, size_t* h_out);
  * n % 8 == 0. */
 int dprhot_cast_bf16(const float* src, dprhot_bf16* dst, size_t n, void* stream);
 
+/* Both producer-side casts of one step in ONE launch: Qb <- q (nq values), Cdst <- c (nc values), fp32 -> bf16
+ * RNE.  Cdst is this rank's slot of the gathered context buffer (W == 1) or the all-gather send buffer. */
+int dprhot_prep(const float* q, size_t nq, dprhot_bf16* Qb, const float* c, size_t nc, dprhot_bf16* Cdst, void* stream);
+
 /* sim_score (dpr_task.py:98-105) + the temperature scale (:211), one kernel:
  *   S[i][j] = inv_T * sum_k Q[i][k] * C[j][k]      (bf16 MFMA, fp32 accumulate)
  *   S[i][j] = -inf where colmask[j] != 0            (colmask may be NULL; it is the row that
@@ -98,18 +102,48 @@ int dprhot_dc(const dprhot_bf16* G, const dprhot_bf16* Q, int B, int Nc, int d, 
 int dprhot_rank_of_gold(const float* S, int rows, int cols, const int64_t* y, int64_t y_offset, int64_t* rank,
                         void* stream);
 
-/* Whole forward of the step for this rank's rows, minimum number of launches:
- * sim (+mask, +1/T) -> row softmax CE -> G, row_loss, row_lse and loss_sum[0] = sum_i row_loss[i].
- * S_out may be NULL (logits not kept) or a [B,Nc] fp32 buffer (debug / parity / eval). */
+/* Whole forward of the step for this rank's rows in TWO launches:
+ *   1. sim GEMM whose epilogue applies mask and 1/T, stores the fp32 logits and leaves, per row and column
+ *      tile, the (max, sum-exp) pair plus the gold logit;
+ *   2. logsumexp from those pairs, then one streaming pass over the logits producing G (bf16), row_loss,
+ *      row_lse and loss_sum[0] = sum_i row_loss[i] (fixed-point integer atomics: deterministic).
+ * S_out may be NULL (logits live in the workspace) or a [B,Nc] fp32 buffer (debug / parity / eval).
+ * row_loss, row_lse, G may be NULL.  `workspace` must hold dprhot_workspace_bytes(B, Nc, d) bytes. */
 int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y,
                        int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss,
                        float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace,
                        size_t workspace_bytes, void* stream);
 
-/* Whole backward: dQ (local rows) and dC_part (all columns) from G; see dprhot_dq / dprhot_dc. */
+/* Whole backward: dQ (local rows) and dC_part (all columns) from G; see dprhot_dq / dprhot_dc.  The two
+ * GEMMs share only their input, so they run side by side in ONE launch (plus the split-K combine of dQ
+ * when Nc is long). */
 int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_bf16* C, int B, int Nc, int d,
                        float h_scale, const float* d_scale, float* dQ, float* dC_part, void* workspace,
                        size_t workspace_bytes, void* stream);
+
+/* The two launches of dprhot_inbatch_fwd, individually (profiling, or a caller that wants the logits
+ * before deciding on the softmax): dprhot_sim_stats leaves logits (S_out, or the workspace when NULL) and
+ * the per-tile statistics in `workspace`; dprhot_softmax_finish consumes them (S_in NULL = the workspace
+ * logits).  Same B, Nc, d and workspace for both calls. */
+int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y,
+                     int64_t y_offset, const uint8_t* colmask, float inv_T, float* S_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t* y, int64_t y_offset,
+                          float grad_scale, float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same forward reading the encoder outputs as they are (fp32), so that no separate cast launch and no extra
+ * round trip through HBM is needed: q [B,d] fp32; c [Nc,d] fp32 when the rank holds every column (world size
+ * 1), or NULL when Cb is the already gathered bf16 buffer (world size > 1: the all-gather ships bf16).
+ * The sim kernel rounds to bf16 (RNE) while staging and writes the bf16 images to Qb (and to Cb when c is
+ * given) for the backward GEMMs.  Everything else as dprhot_sim_stats / dprhot_inbatch_fwd. */
+int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,
+                         const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float* S_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,
+                           const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale,
+                           float* S_out, float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G,
+                           void* workspace, size_t workspace_bytes, void* stream);
 
 /* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
  * their column indices, descending, ties by lower column index.  k <= 128. */

@@ -21,6 +21,10 @@ class OracleKernels:
         dst.copy_(src.detach().to(torch.bfloat16))
         return dst
 
+    def prep(self, q, Qb, c, Cdst):
+        self.cast_bf16(q, Qb)
+        self.cast_bf16(c, Cdst)
+
     def inbatch_fwd(self, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
         S = O.sim_score(_np(Qb), _np(Cb), colmask.numpy().astype(bool)) * inv_T
         labels = y.numpy() + y_offset
