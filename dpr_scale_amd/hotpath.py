@@ -225,7 +225,7 @@ class InBatchContrastive(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, c, pos_idx, ctx_mask, temperature, group, kernels):
         kn = kernels if kernels is not None else default_kernels()
-        W, r = D.world(group)
+        W, r = (1, 0) if group is False else D.world(group)  # group=False: single-device strategy, never gather
         B, d = q.shape
         n_ctx = c.shape[0]  # contexts on this rank (B*K)
         Nc = W * n_ctx
@@ -301,6 +301,46 @@ class InBatchContrastive(torch.autograd.Function):
 
 def inbatch_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, group=None, kernels=None):
     return InBatchContrastive.apply(q, c, pos_idx, ctx_mask, temperature, group, kernels)
+
+
+class WindowedContrastive(torch.autograd.Function):
+    """in_batch_negatives=False (dpr_task.py:198-207): query i is scored only against its own K contexts
+    [pos_i, pos_i + K) (dummy ones masked).  No gather in the reference on this branch either."""
+
+    @staticmethod
+    def forward(ctx, q, c, pos_idx, ctx_mask, temperature, kernels):
+        kn = kernels if kernels is not None else default_kernels()
+        B, d = q.shape
+        n_ctx = c.shape[0]
+        K = n_ctx // B
+        Nc_pad = _pad_cols(n_ctx)
+        Qb = kn.empty((B, d), _BF16, q)
+        Cb = kn.empty((Nc_pad, d), _BF16, c)
+        kn.prep(q, Qb, c, Cb[:n_ctx])
+        m8 = torch.ones(Nc_pad, dtype=torch.uint8, device=c.device)
+        m8[:n_ctx].copy_(ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask)
+        if Nc_pad != n_ctx:
+            Cb[n_ctx:].zero_()
+        inv_T = 1.0 / float(temperature)
+        S = kn.sim(Qb, Cb, m8, inv_T)
+        row_loss, _, G = kn.softmax_ce(S, pos_idx, 0, inv_T / B, want_G=True, row_win_start=pos_idx, win_len=K)
+        loss = kn.reduce_sum(row_loss, 1.0 / B).reshape(())
+        ctx.kn, ctx.n_ctx, ctx.in_dtypes = kn, n_ctx, (q.dtype, c.dtype)
+        ctx.save_for_backward(Qb, Cb, G)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        Qb, Cb, G = ctx.saved_tensors
+        go = grad_out.detach().reshape(1).float().contiguous()
+        dQ, dC = ctx.kn.inbatch_bwd(G, Qb, Cb, 1.0, go, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dq = dQ.to(ctx.in_dtypes[0]) if dQ is not None else None
+        dc = dC[:ctx.n_ctx].to(ctx.in_dtypes[1]) if dC is not None else None
+        return dq, dc, None, None, None, None
+
+
+def windowed_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, kernels=None):
+    return WindowedContrastive.apply(q, c, pos_idx, ctx_mask, temperature, kernels)
 
 
 # ---- forward-only helpers used by the task's eval path -------------------------------------------------

@@ -1,0 +1,277 @@
+"""Drop-in for dpr_scale.task.dpr_task.DenseRetrieverTask (reference: dpr_scale/task/dpr_task.py:17-368).
+
+Same constructor kwargs (:18-32), same Lightning hooks, same overridable methods (`sim_score`, `encode_queries`,
+`encode_contexts`, `_encode_sequence`, `self.loss`, `compute_rank_metrics`, `_eval_step`, `_eval_epoch_end`),
+same logged metric names and the same checkpoint layout (`query_encoder.*` / `context_encoder.*` +
+`hyper_parameters`).  What changes is what happens between the encoder outputs and the loss:
+
+  reference (:163-212)                                   here
+  4 fp32 all_gathers, python splice loop, 2 torch.cat    1 bf16 all-gather of context rows (+ mask bytes)
+  full [W*B, W*B*K] matmul on EVERY rank                 this rank's B rows only (HIP bf16 MFMA)
+  mask.repeat, masked_fill, /= T, log_softmax, nll       fused in the GEMM epilogue + one softmax/dScores pass
+  autograd through cat/matmul (7/8 of it discarded)      HIP dQ / dC GEMMs + reduce-scatter of dC
+
+The maths per rank is identical (tests/golden/*_ddp.npz come from the reference's own
+DDP branch).  Every device op goes through libdprhot.so (dpr_scale_amd.hotpath); there is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+from torch.optim.lr_scheduler import LambdaLR
+
+from .. import hotpath
+
+try:  # the real runtime when it is installed ...
+    from pytorch_lightning import LightningModule
+    from pytorch_lightning.strategies import DDPShardedStrategy, DDPStrategy
+except ImportError:  # ... the minimal stand-in otherwise (build image: no pytorch_lightning, no network)
+    from ..lightning_compat import DDPShardedStrategy, DDPStrategy, LightningModule
+
+try:
+    from hydra.utils import instantiate
+except ImportError:
+    from ..hydra_compat import instantiate
+
+
+class _CEFunction(torch.autograd.Function):
+    """Mean row cross-entropy on existing fp32 logits with gradient (subclasses train through `self.loss`)."""
+
+    @staticmethod
+    def forward(ctx, scores, labels, kernels):
+        kn = kernels if kernels is not None else hotpath.default_kernels()
+        S = scores.detach().float().contiguous()
+        row_loss, _, G = kn.softmax_ce(S, labels, 0, 1.0 / S.shape[0], want_G=True)
+        ctx.save_for_backward(G)
+        ctx.dtype = scores.dtype
+        return kn.reduce_sum(row_loss, 1.0 / S.shape[0]).reshape(())
+
+    @staticmethod
+    def backward(ctx, go):
+        (G,) = ctx.saved_tensors
+        return (G.float() * go).to(ctx.dtype), None, None
+
+
+class HotCrossEntropyLoss(nn.Module):
+    """`self.loss` of the task: callable (scores, labels) -> scalar, nn.CrossEntropyLoss() semantics (:46)."""
+
+    def __init__(self, kernels=None):
+        super().__init__()
+        self.kernels = kernels
+
+    def forward(self, scores, labels):
+        labels = torch.as_tensor(labels, dtype=torch.long, device=scores.device)
+        if scores.shape[1] % 8 != 0:
+            scores = torch.nn.functional.pad(scores, (0, 8 - scores.shape[1] % 8), value=float("-inf"))
+        if scores.requires_grad:
+            return _CEFunction.apply(scores, labels, self.kernels)
+        return hotpath.cross_entropy_mean(scores.float(), labels, self.kernels)
+
+
+class DenseRetrieverTask(LightningModule):
+    def __init__(
+        self,
+        transform,
+        model,
+        datamodule,
+        optim,
+        k=1,
+        shared_model: bool = True,
+        in_batch_eval: bool = True,
+        in_batch_negatives: bool = True,
+        warmup_steps: int = 0,
+        fp16_grads: bool = False,
+        pretrained_checkpoint_path: str = "",
+        softmax_temperature: float = 1.0,
+    ):
+        super().__init__()
+        self.save_hyperparameters()
+        self.transform_conf = getattr(transform, "text_transform", transform)
+        self.model_conf, self.optim_conf = model, optim
+        self.shared_model = shared_model
+        self.k = k
+        self.kernels = None  # None = libdprhot.so (the only product path); tests may inject a stand-in
+        self.loss = HotCrossEntropyLoss()
+        self.in_batch_eval = in_batch_eval
+        self.in_batch_negatives = in_batch_negatives
+        self.warmup_steps = warmup_steps
+        self.fp16_grads = fp16_grads
+        self.pretrained_checkpoint_path = pretrained_checkpoint_path
+        self.softmax_temperature = softmax_temperature
+        self.setup_done = False
+
+    # ---- model construction / checkpoints (reference :55-92) -------------------------------------------
+    def setup(self, stage: str):
+        if stage == "test" and self.setup_done:
+            return  # keep the restored weights
+        self.call_configure_sharded_model_hook = False
+        self.query_encoder = instantiate(self.model_conf)
+        self.context_encoder = self.query_encoder if self.shared_model else instantiate(self.model_conf)
+        if self.pretrained_checkpoint_path:
+            ck = torch.load(self.pretrained_checkpoint_path, map_location="cpu", weights_only=False)
+            self.load_state_dict(ck["state_dict"])
+            print(f"Loaded state dict from {self.pretrained_checkpoint_path}")
+        self.setup_done = True
+
+    def on_load_checkpoint(self, checkpoint) -> None:
+        self.setup("fit")  # modules must exist before Lightning restores the state dict
+
+    def on_pretrain_routine_start(self):
+        if self.fp16_grads:
+            from torch.distributed.algorithms.ddp_comm_hooks.default_hooks import fp16_compress_hook
+
+            self.trainer.strategy._model.register_comm_hook(None, fp16_compress_hook)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, **kwargs):
+        base = super()
+        if hasattr(base, "load_from_checkpoint"):
+            return base.load_from_checkpoint(checkpoint_path, **kwargs)
+        from ..lightning_compat import load_from_checkpoint
+
+        return load_from_checkpoint(cls, checkpoint_path, **kwargs)
+
+    # ---- encoders (reference :94-121) -------------------------------------------------------------------
+    def _encode_sequence(self, token_ids, encoder_model):
+        return encoder_model(token_ids)  # [rows, d]
+
+    def encode_queries(self, query_ids):
+        return self._encode_sequence(query_ids, self.query_encoder)
+
+    def encode_contexts(self, contexts_ids):
+        return self._encode_sequence(contexts_ids, self.context_encoder)
+
+    def forward(self, query_ids, contexts_ids):
+        return self.encode_queries(query_ids), self.encode_contexts(contexts_ids)
+
+    # ---- scoring (reference :98-105) -----------------------------------------------------------------------
+    def sim_score(self, query_repr, context_repr, mask=None):
+        """fp32 logits [Nq, Nc]; masked entries are -inf.  `mask` is the [Nc] dummy-context mask or, as the
+        reference passes it, that row repeated to [Nq, Nc]."""
+        col = None
+        full = None
+        if mask is not None:
+            if mask.dim() == 1:
+                col = mask
+            else:
+                full = mask
+        scores = hotpath.sim_score(query_repr.detach(), context_repr.detach(), col, 1.0, self.kernels)
+        if full is not None:
+            scores = scores.masked_fill(full, float("-inf"))
+        return scores
+
+    # ---- optimiser (reference :123-151) ----------------------------------------------------------------------
+    def configure_optimizers(self):
+        self.optimizer = instantiate(self.optim_conf, self.parameters())
+        if self.trainer.max_steps and self.trainer.max_steps > 0:
+            total = self.trainer.max_steps
+        else:
+            total = len(self.trainer.datamodule.train_dataloader()) * self.trainer.max_epochs
+        warm = self.warmup_steps
+        print(f"Configured LR scheduler for total {total} training steps, with {warm} warmup steps.")
+
+        def lr_lambda(step):  # linear warm-up then linear decay to zero
+            if step < warm:
+                return float(step) / float(max(1, warm))
+            return max(0.0, float(total - step) / float(max(1, total - warm)))
+
+        sched = {"scheduler": LambdaLR(self.optimizer, lr_lambda), "name": "learning_rate", "interval": "step",
+                 "frequency": 1}
+        return [self.optimizer], [sched]
+
+    # ---- the hot path (reference :153-214) -----------------------------------------------------------------
+    def _is_distributed(self):
+        return isinstance(getattr(self.trainer, "strategy", None), (DDPStrategy, DDPShardedStrategy))
+
+    def training_step(self, batch, batch_idx):
+        q, c = self(batch["query_ids"], batch["contexts_ids"])
+        pos, mask = batch["pos_ctx_indices"], batch["ctx_mask"]
+        T = self.softmax_temperature
+        if self.in_batch_negatives:
+            group = None if self._is_distributed() else False  # False: never gather (single-device strategies)
+            loss = hotpath.inbatch_contrastive_loss(q, c, pos, mask, T, group, self.kernels)
+        else:
+            loss = hotpath.windowed_contrastive_loss(q, c, pos, mask, T, self.kernels)
+        self.log("train_loss", loss, prog_bar=True)
+        return loss
+
+    # ---- evaluation (reference :216-310) ---------------------------------------------------------------------
+    def _eval_step(self, batch, batch_idx):
+        q, c = self(batch["query_ids"], batch["contexts_ids"])
+        labels, mask = batch["pos_ctx_indices"], batch["ctx_mask"]
+        scores = self.sim_score(q, c, mask)
+        loss = self.loss(scores, labels)
+        return (self.compute_rank_metrics(scores, labels), q, c, labels, mask, loss)
+
+    def compute_rank_metrics(self, pred_scores, target_labels):
+        """(sum of ranks, sum of reciprocal ranks, #rows with rank <= k) -- the reference sorts every row and
+        looks the gold index up with one host sync per row (:237-245); here one count kernel, one sync."""
+        labels = torch.as_tensor(target_labels, dtype=torch.long, device=pred_scores.device)
+        ranks = hotpath.rank_of_gold(pred_scores.float(), labels, self.kernels)
+        r = ranks.double()
+        stats = torch.stack([r.sum(), (1.0 / r).sum(), (ranks - 1 < self.k).double().sum()]).tolist()
+        return int(stats[0]), stats[1], int(stats[2])
+
+    def _eval_epoch_end(self, outputs, log_prefix="valid"):
+        if self.in_batch_eval:
+            n = len(outputs)
+            rank = sum(o[0][0] for o in outputs)
+            mrr = sum(o[0][1] for o in outputs)
+            score = sum(o[0][2] for o in outputs)
+            count = sum(o[1].size(0) for o in outputs)
+            ctx_count = sum(o[2].size(0) - torch.sum(o[4]) for o in outputs) / n
+            loss = sum(o[5] for o in outputs) / n
+        else:
+            q_all = torch.cat([o[1] for o in outputs], dim=0)
+            c_all = torch.cat([o[2] for o in outputs], dim=0)
+            m_all = torch.cat([o[4] for o in outputs], dim=0)
+            labels, offset = [], 0
+            for o in outputs:
+                labels.extend(int(x) + offset for x in o[3])
+                offset += o[2].size(0)
+            if self.trainer.world_size > 1:
+                c_g, m_g = self.all_gather((c_all, m_all))
+                labels = [x + c_g.size(1) * self.global_rank for x in labels]
+                c_all, m_all = c_g.flatten(0, 1), m_g.flatten(0, 1)
+            scores = self.sim_score(q_all, c_all, m_all)
+            count = q_all.size(0)
+            ctx_count = scores.size(1) - torch.sum(m_all)
+            rank, mrr, score = self.compute_rank_metrics(scores, labels)
+            loss = self.loss(scores, torch.tensor(labels, dtype=torch.long, device=scores.device))
+        self.log_dict({
+            f"{log_prefix}_avg_rank": rank / count,
+            f"{log_prefix}_mrr": mrr / count,
+            f"{log_prefix}_accuracy@{self.k}": score / count,
+            f"{log_prefix}_ctx_count": ctx_count,
+            f"{log_prefix}_loss": loss,
+        }, on_epoch=True, sync_dist=True)
+
+    def validation_step(self, batch, batch_idx):
+        return self._eval_step(batch, batch_idx)
+
+    def validation_epoch_end(self, valid_outputs):
+        if valid_outputs:
+            self._eval_epoch_end(valid_outputs)
+
+    def test_step(self, batch, batch_idx):
+        return self._eval_step(batch, batch_idx)
+
+    def test_epoch_end(self, test_outputs):
+        if test_outputs:
+            self._eval_epoch_end(test_outputs, "test")
+
+    def to_torchscript(self, file_path=None, method="script", example_inputs=None, **kwargs):
+        """TorchScript export of the encoders (reference :325-368) is encoder packaging, outside the hot path
+        (SURVEY.md section 2 #8); it is delegated to the reference's own ScriptEncoder when that is installed."""
+        try:
+            from dpr_scale.utils.utils import ScriptEncoder  # the reference package, if present
+        except ImportError as e:
+            raise NotImplementedError("to_torchscript needs dpr_scale.utils.utils.ScriptEncoder (reference package)") from e
+        if method != "script":
+            raise ValueError(f"The 'method' parameter only supports 'script', but value given was: {method}")
+        transform = instantiate(self.transform_conf)
+        with torch.no_grad():
+            result = {"ctx_encoder": torch.jit.script(ScriptEncoder(transform, self.context_encoder).eval(), **kwargs)}
+            if not self.shared_model:
+                result["q_encoder"] = torch.jit.script(ScriptEncoder(transform, self.query_encoder).eval(), **kwargs)
+        if file_path is not None:
+            torch.jit.save(result["ctx_encoder"], file_path)
+        return result

@@ -40,3 +40,29 @@ class OracleKernels:
         dQ = torch.from_numpy((g @ _np(Cb).astype(np.float64) * s).astype(np.float32)) if need_dq else None
         dC = torch.from_numpy((g.T @ _np(Qb).astype(np.float64) * s).astype(np.float32)) if need_dc else None
         return dQ, dC
+
+    # ---- forward-only / piecewise ops (eval path, windowed branch) ----
+    def sim(self, Qb, Cb, colmask=None, inv_T=1.0):
+        m = None if colmask is None else colmask.numpy().astype(bool)
+        return torch.from_numpy((O.sim_score(_np(Qb), _np(Cb), m) * inv_T).astype(np.float32))
+
+    def softmax_ce(self, S, y, y_offset=0, grad_scale=1.0, want_G=False, row_win_start=None, win_len=0):
+        s = S.detach().double().numpy().copy()
+        labels = y.numpy() + y_offset
+        if row_win_start is not None:
+            cols = np.arange(s.shape[1])[None, :]
+            lo = (row_win_start.numpy() + y_offset)[:, None]
+            s[(cols < lo) | (cols >= lo + win_len)] = -np.inf
+        _, row_loss, lse = O.log_softmax_ce(s, labels)
+        G = torch.from_numpy(O.dscores(s, labels, lse, grad_scale)).to(torch.bfloat16) if want_G else None
+        return torch.from_numpy(row_loss.astype(np.float32)), torch.from_numpy(lse.astype(np.float32)), G
+
+    def reduce_sum(self, x, scale=1.0):
+        return (x.double().sum() * scale).float().reshape(1)
+
+    def rank_of_gold(self, S, y, y_offset=0):
+        return torch.from_numpy(O.rank_of_gold(S.numpy(), y.numpy() + y_offset))
+
+    def topk(self, S, k):
+        v, i = O.topk_stable(S.numpy(), k)
+        return torch.from_numpy(v), torch.from_numpy(i)
