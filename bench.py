@@ -67,7 +67,10 @@ class HotPathStep:
         self.lib, self._lib, self.D = _lib.lib, _lib, D
         self.B, self.K, self.d, self.T, self.W, self.r, self.group = B, K, d, T, W, r, group
         self.n_ctx = B * K
-        self.Nc = W * self.n_ctx
+        # W>1: every rank ships ONE buffer (context rows + mask bytes in trailing rows, dprhot_pack_ctx); the
+        # trailing rows are extra, always-masked columns of the gathered matrix
+        self.rows_c = self.n_ctx if W == 1 else _lib.packed_rows(self.n_ctx, d)
+        self.Nc = W * self.rows_c
         self.Nq = W * B
         q, c, y, m = synth_embeddings(1234 + r, B, K, d, "U", False)
         f32, bf16 = torch.float32, torch.bfloat16
@@ -77,7 +80,7 @@ class HotPathStep:
         self.m8 = torch.from_numpy(m.astype(np.uint8)).to(dev)
         self.Qb = torch.empty((B, d), dtype=bf16, device=dev)
         self.Cb = torch.empty((self.Nc, d), dtype=bf16, device=dev)
-        self.send = self.Cb[:self.n_ctx] if W == 1 else torch.empty((self.n_ctx, d), dtype=bf16, device=dev)
+        self.send = self.Cb[:self.n_ctx] if W == 1 else torch.empty((self.rows_c, d), dtype=bf16, device=dev)
         self.mask_all = torch.zeros(self.Nc, dtype=torch.uint8, device=dev)
         self.row_loss = torch.empty(B, dtype=f32, device=dev)
         self.row_lse = torch.empty(B, dtype=f32, device=dev)
@@ -85,7 +88,7 @@ class HotPathStep:
         self.G = torch.empty((B, self.Nc), dtype=bf16, device=dev)
         self.dQ = torch.empty((B, d), dtype=f32, device=dev)
         self.dC = torch.empty((self.Nc, d), dtype=f32, device=dev)
-        self.dc = self.dC if W == 1 else torch.empty((self.n_ctx, d), dtype=f32, device=dev)
+        self.dc = self.dC if W == 1 else torch.empty((self.rows_c, d), dtype=f32, device=dev)
         self.go = torch.ones(1, dtype=f32, device=dev)
         self.ws_bytes = _lib.workspace_bytes(B, self.Nc, d)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
@@ -98,7 +101,7 @@ class HotPathStep:
     def bind_stream(self):
         """(Re)build the argument tuples for the CURRENT torch stream (every buffer is static)."""
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        B, Nc, d, off = self.B, self.Nc, self.d, self.r * self.n_ctx
+        B, Nc, d, off = self.B, self.Nc, self.d, self.r * self.rows_c
         ws, wsb = P(self.ws), self.ws_bytes
         self.a_prep = (P(self.q), self.q.numel(), P(self.Qb), P(self.c), self.c.numel(), P(self.send), st)
         self.a_fwd = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, self.gscale, None,
@@ -108,7 +111,8 @@ class HotPathStep:
                         P(self.G), ws, wsb, st)
         self.a_sim32 = (P(self.q), P(self.c) if self.W == 1 else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
                         P(self.mask_all), self.inv_T, None, ws, wsb, st)
-        self.a_castc = (P(self.c), P(self.send), self.c.numel(), st)
+        self.a_pack = (P(self.c), P(self.m8), self.n_ctx, d, P(self.send), st)
+        self.a_unpack = (P(self.Cb), self.W, self.n_ctx, d, P(self.mask_all), st)
         self.a_bwd = (P(self.G), P(self.Qb), P(self.Cb), B, Nc, d, 1.0, P(self.go), P(self.dQ), P(self.dC), ws, wsb, st)
         self.a_sim = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, None, ws, wsb, st)
         self.a_fin = (None, B, Nc, d, P(self.y), off, self.gscale, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
@@ -138,24 +142,29 @@ class HotPathStep:
     def k_sim32(self):
         self._call(self.lib.dprhot_sim_stats_f32, self.a_sim32)
 
-    def k_castc(self):
-        self._call(self.lib.dprhot_cast_bf16, self.a_castc)
+    def k_pack(self):
+        self._call(self.lib.dprhot_pack_ctx, self.a_pack)
+
+    def k_unpack(self):
+        self._call(self.lib.dprhot_unpack_mask, self.a_unpack)
 
     def k_softmax(self):
         self._call(self.lib.dprhot_softmax_finish, self.a_fin)
 
     def step(self):
         # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
+        h = None
         if self.W > 1:
-            self.k_castc()
-            self.D.all_gather_rows(self.send, self.Cb, self.group)
-            self.D.all_gather_rows(self.m8, self.mask_all, self.group)
+            self.k_pack()
+            self.D.all_gather_rows(self.send, self.Cb, self.group)  # the one forward collective
+            self.k_unpack()
         self.k_fwd32()
         if self.W > 1:
-            self.D.all_reduce_sum(self.loss_sum, self.group)
+            h = self.D.all_reduce_sum(self.loss_sum, self.group, async_op=True)  # logging value: off the critical path
         self.k_bwd()
         if self.W > 1:
-            self.D.reduce_scatter_rows(self.dC, self.dc, self.group)
+            self.D.reduce_scatter_rows(self.dC, self.dc, self.group)  # the one backward collective
+            h.wait()
 
 
 def capture(hp, fn, repeat=1):
@@ -293,7 +302,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cfg2-shaped per GPU: B={B} queries x (1+{a.negatives}) contexts, d={d}, T={T}; "
                                    f"global Nq={W * B}, Nc={hp.Nc}; embeddings resident in HBM, step driven through the C ABI",
-                       "global_batch": W * B, "global_negatives_per_query": hp.Nc - 1, "parallelism": f"dp{W}",
+                       "global_batch": W * B, "global_negatives_per_query": W * hp.n_ctx - 1, "parallelism": f"dp{W}",
                        "driver": driver},
             "roofline": roof, "kernels": ktimes, "other_driver": alt,
         }

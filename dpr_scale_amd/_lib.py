@@ -28,6 +28,9 @@ SIGNATURES = {
     "dprhot_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "dprhot_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_prep": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "dprhot_packed_rows": (c_int, [c_int, c_int, POINTER(c_int)]),
+    "dprhot_pack_ctx": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dprhot_unpack_mask": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dprhot_sim_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "dprhot_softmax_ce_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_float, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -71,6 +74,12 @@ def check(rc: int, what: str = ""):
 
 def version() -> int:
     return lib.dprhot_version()
+
+
+def packed_rows(n_ctx: int, d: int) -> int:
+    out = c_int(0)
+    check(lib.dprhot_packed_rows(n_ctx, d, ctypes.byref(out)), "dprhot_packed_rows")
+    return out.value
 
 
 def workspace_bytes(B: int, Nc: int, d: int) -> int:

@@ -291,6 +291,38 @@ int dprhot_prep(const float* q, size_t nq, dprhot_bf16* Qb, const float* c, size
   return DPRHOT_OK;
 }
 
+int dprhot_packed_rows(int n_ctx, int d, int* h_rows) {
+  REQUIRE(h_rows != nullptr && n_ctx > 0 && d > 0 && d % 8 == 0, "bad argument");
+  const int extra = cdiv(n_ctx, 2 * d);           // rows needed for n_ctx mask bytes
+  *h_rows = cdiv(n_ctx + extra, 8) * 8;           // gathered column count stays a multiple of 8
+  return DPRHOT_OK;
+}
+
+int dprhot_pack_ctx(const float* c, const uint8_t* mask, int n_ctx, int d, dprhot_bf16* send, void* stream) {
+  REQUIRE(c && send, "NULL pointer");
+  REQUIRE(n_ctx > 0 && d > 0 && d % 8 == 0, "bad shape n_ctx=%d d=%d", n_ctx, d);
+  REQUIRE(aligned16(c) && aligned16(send), "pointers must be 16-byte aligned");
+  int rows_c = 0;
+  dprhot_packed_rows(n_ctx, d, &rows_c);
+  const size_t n8 = (size_t)rows_c * d / 8;
+  const int blocks = (int)((n8 + 255) / 256 > 2048 ? 2048 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(pack_ctx_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, mask, n_ctx, d, rows_c, send);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_unpack_mask(const dprhot_bf16* gathered, int W, int n_ctx, int d, uint8_t* colmask, void* stream) {
+  REQUIRE(gathered && colmask, "NULL pointer");
+  REQUIRE(W > 0 && n_ctx > 0 && d > 0 && d % 8 == 0, "bad shape W=%d n_ctx=%d d=%d", W, n_ctx, d);
+  int rows_c = 0;
+  dprhot_packed_rows(n_ctx, d, &rows_c);
+  const int total = W * rows_c;
+  hipLaunchKernelGGL(unpack_mask_kernel, dim3(cdiv(total, 256) > 1024 ? 1024 : cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     gathered, W, n_ctx, d, rows_c, colmask);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const uint8_t* colmask, float inv_T,
                    float* S, void* stream) {
   REQUIRE(Q && C && S, "NULL pointer");

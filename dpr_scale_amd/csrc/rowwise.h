@@ -77,6 +77,48 @@ __global__ __launch_bounds__(256) void cast2_bf16_kernel(const float* __restrict
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Multi-rank producer side: ONE buffer travels over xGMI per step.  This rank's context rows (fp32 -> bf16) are
+// followed by a few extra rows whose bytes carry the dummy-context mask, so that a single all-gather moves both
+// (the reference issues four, dpr_task.py:169-176).  After the gather the extra rows simply are additional,
+// always-masked columns of C; unpack_mask_kernel builds the column mask of the gathered matrix.
+//   send [rows_c, d] bf16 : rows [0, n_ctx) = contexts ; rows [n_ctx, rows_c) = mask bytes (then zeros)
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_ctx_kernel(const float* __restrict__ c, const uint8_t* __restrict__ mask, int n_ctx, int d,
+                                                       int rows_c, uint16_t* __restrict__ send) {
+  const size_t n8 = (size_t)rows_c * d / 8, ctx8 = (size_t)n_ctx * d / 8;
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n8; k += (size_t)gridDim.x * blockDim.x) {
+    uint4 o;
+    if (k < ctx8) {
+      const float4 x = reinterpret_cast<const float4*>(c)[2 * k];
+      const float4 y = reinterpret_cast<const float4*>(c)[2 * k + 1];
+      o = make_uint4(pk_bf16(x.x, x.y), pk_bf16(x.z, x.w), pk_bf16(y.x, y.y), pk_bf16(y.z, y.w));
+    } else {
+      const size_t b0 = (k - ctx8) * 16;  // byte position inside the mask region
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const size_t b = b0 + e;
+        const uint32_t v = (mask != nullptr && b < (size_t)n_ctx) ? (mask[b] != 0) : 0u;
+        w[e >> 2] |= v << (8 * (e & 3));
+      }
+      o = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    reinterpret_cast<uint4*>(send)[k] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_mask_kernel(const uint16_t* __restrict__ gathered, int W, int n_ctx, int d, int rows_c,
+                                                          uint8_t* __restrict__ colmask) {
+  const int total = W * rows_c;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < total; n += gridDim.x * blockDim.x) {
+    const int r = n / rows_c, local = n - r * rows_c;
+    uint8_t m = 1;  // the extra rows are not contexts: always masked
+    if (local < n_ctx) m = reinterpret_cast<const uint8_t*>(gathered)[((size_t)r * rows_c + n_ctx) * d * 2 + local];
+    colmask[n] = m;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Second (and last) kernel of the fused training forward.  The sim kernel has left, per row, one
 // (max, sum-exp) pair per column tile and the gold logit; this kernel turns them into the row logsumexp
 // (a handful of values per row), then makes ONE streaming pass over S: G = (exp(S - lse) - onehot) * scale

@@ -83,6 +83,25 @@ class HipKernels:
         self._lib.check(self.lib.dprhot_prep(_ptr(q), q.numel(), _ptr(Qb), _ptr(c), c.numel(), _ptr(Cdst), self._stream()),
                         "dprhot_prep")
 
+    def packed_rows(self, n_ctx, d):
+        return self._lib.packed_rows(n_ctx, d)
+
+    def pack_ctx(self, c, m8, send):
+        """send [rows_c, d] bf16 <- context rows (fp32 -> bf16) followed by the mask bytes (one all-gather moves both)."""
+        self._require_gpu(c, m8, send)
+        c = c.detach().float().contiguous()
+        n_ctx, d = c.shape
+        assert send.is_contiguous() and send.shape == (self.packed_rows(n_ctx, d), d)
+        self._lib.check(self.lib.dprhot_pack_ctx(_ptr(c), _ptr(m8.contiguous()), n_ctx, d, _ptr(send), self._stream()),
+                        "dprhot_pack_ctx")
+
+    def unpack_mask(self, gathered, W, n_ctx, colmask):
+        self._require_gpu(gathered, colmask)
+        d = gathered.shape[1]
+        assert colmask.numel() == W * self.packed_rows(n_ctx, d)
+        self._lib.check(self.lib.dprhot_unpack_mask(_ptr(gathered), W, n_ctx, d, _ptr(colmask), self._stream()),
+                        "dprhot_unpack_mask")
+
     def inbatch_fwd(self, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
         self._require_gpu(Qb, Cb, y, colmask)
         B, d = Qb.shape
@@ -228,51 +247,59 @@ class InBatchContrastive(torch.autograd.Function):
         W, r = (1, 0) if group is False else D.world(group)  # group=False: single-device strategy, never gather
         B, d = q.shape
         n_ctx = c.shape[0]  # contexts on this rank (B*K)
-        Nc = W * n_ctx
         Nq = W * B
         assert pos_idx.shape[0] == B and ctx_mask.shape[0] == n_ctx
         if d % 8 != 0:
             raise ValueError(f"hidden size {d} must be a multiple of 8")
-        Nc_pad = _pad_cols(Nc)
-
-        Qb = kn.empty((B, d), _BF16, q)
-        Cb = kn.empty((Nc_pad, d), _BF16, c)
-        mask_all = kn.empty((Nc_pad,), torch.uint8, c)
         m8 = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask.to(torch.uint8)
-        # fp32 encoder outputs are consumed as they are by the sim kernel (it rounds to bf16 while staging and
-        # leaves the bf16 images in Qb / Cb); only what must travel over xGMI is cast beforehand.
-        direct = q.dtype == torch.float32 and c.dtype == torch.float32 and Nc_pad == Nc and hasattr(kn, "inbatch_fwd_f32")
+        q_f32 = q.dtype == torch.float32 and hasattr(kn, "inbatch_fwd_f32")
+        Qb = kn.empty((B, d), _BF16, q)
+
         if W == 1:
-            if not direct:
+            # columns = this rank's contexts (padded to a multiple of 8 with masked zero rows)
+            rows_c = _pad_cols(n_ctx)
+            Nc = rows_c
+            Cb = kn.empty((Nc, d), _BF16, c)
+            colmask = kn.empty((Nc,), torch.uint8, c)
+            colmask[:n_ctx].copy_(m8)
+            if Nc != n_ctx:
+                Cb[n_ctx:].zero_()
+                colmask[n_ctx:].fill_(1)
+            # fp32 encoder outputs are consumed as they are by the sim kernel (it rounds to bf16 while staging
+            # and leaves the bf16 images in Qb / Cb)
+            c_direct = q_f32 and c.dtype == torch.float32 and Nc == n_ctx
+            if not c_direct:
                 kn.prep(q, Qb, c, Cb[:n_ctx])
-            mask_all[:n_ctx].copy_(m8)
+                q_f32 = False
         else:
-            send = kn.empty((n_ctx, d), _BF16, c)
-            if direct:
-                kn.cast_bf16(c, send)
-            else:
-                kn.prep(q, Qb, c, send)
-            h1 = D.all_gather_rows(send, Cb[:Nc], group, async_op=True)
-            h2 = D.all_gather_rows(m8.contiguous(), mask_all[:Nc], group, async_op=True)
-            h1.wait()
-            h2.wait()
-        if Nc_pad != Nc:  # pad columns are masked out (-inf) and carry zero rows
-            Cb[Nc:].zero_()
-            mask_all[Nc:].fill_(1)
+            # ONE all-gather: context rows (bf16) + mask bytes in trailing rows of the same buffer; the trailing
+            # rows become always-masked extra columns (the reference issues 4 fp32 all_gathers, :169-176)
+            rows_c = kn.packed_rows(n_ctx, d)
+            Nc = W * rows_c
+            send = kn.empty((rows_c, d), _BF16, c)
+            kn.pack_ctx(c, m8, send)
+            Cb = kn.empty((Nc, d), _BF16, c)
+            D.all_gather_rows(send, Cb, group)
+            colmask = kn.empty((Nc,), torch.uint8, c)
+            kn.unpack_mask(Cb, W, n_ctx, colmask)
+            c_direct = False
+            if not q_f32:
+                kn.cast_bf16(q, Qb)
 
         inv_T = 1.0 / float(temperature)
         grad_scale = inv_T / Nq  # d loss / d S of the global mean, before grad_output
-        if direct:
-            row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd_f32(q, c if W == 1 else None, Qb, Cb, pos_idx, r * n_ctx,
-                                                                   mask_all, inv_T, grad_scale)
+        y_off = r * rows_c       # dpr_task.py:189-190 (label offset of this rank's columns)
+        if q_f32:
+            row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off,
+                                                                   colmask, inv_T, grad_scale)
         else:
-            row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, r * n_ctx, mask_all, inv_T, grad_scale)
+            row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale)
         if W > 1:
             D.all_reduce_sum(loss_sum, group)
         loss = (loss_sum / Nq).reshape(())
 
         ctx.kn, ctx.group = kn, group
-        ctx.dims = (W, r, B, d, n_ctx, Nc)
+        ctx.dims = (W, r, B, d, n_ctx, rows_c)
         ctx.in_dtypes = (q.dtype, c.dtype)
         ctx.save_for_backward(Qb, Cb, G)
         ctx.row_lse = row_lse
@@ -281,7 +308,7 @@ class InBatchContrastive(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         kn, group = ctx.kn, ctx.group
-        W, r, B, d, n_ctx, Nc = ctx.dims
+        W, r, B, d, n_ctx, rows_c = ctx.dims
         Qb, Cb, G = ctx.saved_tensors
         need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         go = grad_out.detach().reshape(1).float().contiguous()  # device scalar: AMP loss scale, no host sync
@@ -293,8 +320,9 @@ class InBatchContrastive(torch.autograd.Function):
             if W == 1:
                 dc = dC_part[:n_ctx]
             else:
-                dc = kn.empty((n_ctx, d), torch.float32, dC_part)
-                D.reduce_scatter_rows(dC_part[:Nc], dc, group)
+                mine = kn.empty((rows_c, d), torch.float32, dC_part)
+                D.reduce_scatter_rows(dC_part, mine, group)  # sum over ranks of the partials of MY columns
+                dc = mine[:n_ctx]
             dc = dc.to(ctx.in_dtypes[1])
         return dq, dc, None, None, None, None, None
 

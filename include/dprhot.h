@@ -58,6 +58,17 @@ int dprhot_cast_bf16(const float* src, dprhot_bf16* dst, size_t n, void* stream)
  * RNE.  Cdst is this rank's slot of the gathered context buffer (W == 1) or the all-gather send buffer. */
 int dprhot_prep(const float* q, size_t nq, dprhot_bf16* Qb, const float* c, size_t nc, dprhot_bf16* Cdst, void* stream);
 
+/* Multi-rank gather in ONE collective (the reference issues four all_gathers, dpr_task.py:169-176).
+ * dprhot_pack_ctx writes this rank's all-gather send buffer [rows_c, d] bf16: rows [0, n_ctx) = the context rows
+ * (fp32 -> bf16 RNE), followed by rows whose bytes carry the dummy-context mask (mask may be NULL = no dummies).
+ * rows_c = dprhot_packed_rows(n_ctx, d) (a multiple of 8).  After all-gathering W such buffers back to back, the
+ * result IS the context matrix C [W*rows_c, d] of every other entry point -- the mask rows are just extra columns
+ * that dprhot_unpack_mask marks as masked in the column mask it builds ([W*rows_c] bytes).  The label offset of
+ * rank r becomes r * rows_c, and rank r's gradient is the first n_ctx rows of its reduce-scatter chunk. */
+int dprhot_packed_rows(int n_ctx, int d, int* h_rows);
+int dprhot_pack_ctx(const float* c, const uint8_t* mask, int n_ctx, int d, dprhot_bf16* send, void* stream);
+int dprhot_unpack_mask(const dprhot_bf16* gathered, int W, int n_ctx, int d, uint8_t* colmask, void* stream);
+
 /* sim_score (dpr_task.py:98-105) + the temperature scale (:211), one kernel:
  *   S[i][j] = inv_T * sum_k Q[i][k] * C[j][k]      (bf16 MFMA, fp32 accumulate)
  *   S[i][j] = -inf where colmask[j] != 0            (colmask may be NULL; it is the row that

@@ -21,6 +21,24 @@ class OracleKernels:
         dst.copy_(src.detach().to(torch.bfloat16))
         return dst
 
+    def packed_rows(self, n_ctx, d):
+        extra = -(-n_ctx // (2 * d))
+        return -(-(n_ctx + extra) // 8) * 8
+
+    def pack_ctx(self, c, m8, send):
+        n_ctx, d = c.shape
+        send.zero_()
+        send[:n_ctx].copy_(c.detach().to(torch.bfloat16))
+        send.view(torch.uint8).view(-1)[n_ctx * d * 2:n_ctx * d * 2 + n_ctx] = (m8 != 0).to(torch.uint8)
+
+    def unpack_mask(self, gathered, W, n_ctx, colmask):
+        d = gathered.shape[1]
+        rows_c = self.packed_rows(n_ctx, d)
+        by = gathered.view(torch.uint8).view(W, rows_c * d * 2)
+        cm = torch.ones(W, rows_c, dtype=torch.uint8)
+        cm[:, :n_ctx] = by[:, n_ctx * d * 2:n_ctx * d * 2 + n_ctx]
+        colmask.copy_(cm.view(-1))
+
     def prep(self, q, Qb, c, Cdst):
         self.cast_bf16(q, Qb)
         self.cast_bf16(c, Cdst)

@@ -133,6 +133,48 @@ def test_local_rows_vs_reference_ddp_branch(name, kn, dev):
         assert rel(dC[r * B * K:(r + 1) * B * K], g["dc_per_rank"][r]) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("name", ["w2_ddp", "w4_ddp", "cfg4_ddp"])
+def test_packed_single_gather_layout_vs_reference_ddp(name, kn, dev):
+    """The multi-rank wire format (context rows + mask bytes in ONE buffer per rank, dprhot_pack_ctx /
+    dprhot_unpack_mask) emulated on one GPU: every rank's send buffer is built by the kernel, the buffers are
+    concatenated as an all-gather would, and each rank's step must give the reference DDP-branch results."""
+    meta, g = load_golden(name)
+    W, B, K, d = meta["W"], meta["B"], meta["K"], meta["d"]
+    n_ctx = B * K
+    parts = rank_inputs(meta)
+    rows_c = kn.packed_rows(n_ctx, d)
+    assert rows_c % 8 == 0 and rows_c >= n_ctx + 1
+    sends = []
+    for r in range(W):
+        send = torch.empty((rows_c, d), dtype=torch.bfloat16, device=dev)
+        kn.pack_ctx(t(parts[r][1], dev), t(parts[r][3].astype(np.uint8), dev), send)
+        sends.append(send)
+    Cb = torch.cat(sends, 0).contiguous()  # == all_gather_into_tensor
+    colmask = torch.empty(W * rows_c, dtype=torch.uint8, device=dev)
+    kn.unpack_mask(Cb, W, n_ctx, colmask)
+    cm = colmask.cpu().numpy().reshape(W, rows_c)
+    for r in range(W):
+        assert np.array_equal(cm[r, :n_ctx], parts[r][3].astype(np.uint8)) and np.all(cm[r, n_ctx:] == 1)
+        assert np.array_equal(Cb[r * rows_c:r * rows_c + n_ctx].float().cpu().numpy(), parts[r][1])
+    inv_T = 1.0 / meta["T"]
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float32, device=dev)
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    loss_sum, dqs = 0.0, []
+    for r in range(W):
+        _, _, ls, G, _ = kn.inbatch_fwd_f32(t(parts[r][0], dev), None, Qb, Cb, t(parts[r][2], dev), r * rows_c, colmask,
+                                            inv_T, inv_T / (W * B))
+        dq, dcp = kn.inbatch_bwd(G, Qb, Cb, 1.0, one)
+        dC += dcp
+        loss_sum += ls.item()
+        dqs.append(dq.cpu().numpy())
+    dC = dC.cpu().numpy()
+    for r in range(W):
+        assert abs(loss_sum / (W * B) - g["loss_per_rank"][r]) <= LOSS_RTOL * max(1.0, abs(g["loss_per_rank"][r]))
+        assert rel(dqs[r], g["dq_per_rank"][r]) <= GRAD_RTOL
+        assert rel(dC[r * rows_c:r * rows_c + n_ctx], g["dc_per_rank"][r]) <= GRAD_RTOL
+
+
 @pytest.mark.parametrize("name", golden_names("cfg3") + golden_names("cfg5"))
 def test_full_size_configs_against_reference_summaries(name, kn, dev):
     """cfg3 (W8 B128 K8 d768: 1024 x 8192) and cfg5 (W8 B64 K2 d1024) at full size."""
