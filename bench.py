@@ -185,10 +185,16 @@ def capture(hp, fn, repeat=1):
     return g.replay
 
 
-def time_kernel(hp, fn, reps=50, iters=20):
+def time_kernel(hp, fn, reps=50, iters=20, use_graph=True):
     """Average duration of one launch of `fn`, HIP events on the launch stream, launches back to back on the
-    device (50 per graph replay, so the host launch rate does not enter the number)."""
-    run = capture(hp, fn, reps)
+    device (50 per graph replay, so the host launch rate does not enter the number).  use_graph=False (multi-rank
+    runs: no capture next to a live RCCL communicator): plain eager loop, a host-launch-rate upper bound."""
+    if use_graph:
+        run = capture(hp, fn, reps)
+    else:
+        def run():
+            for _ in range(reps):
+                fn()
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -238,13 +244,18 @@ def main():
     W = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # debugging aid for boxes with ONE GPU: exercise the N>1 code path with every rank on device 0 over gloo
+    # (DPRHOT_DIST_BACKEND=gloo DPRHOT_SAME_DEVICE=1); RCCL itself refuses two ranks on one device
+    backend = os.environ.get("DPRHOT_DIST_BACKEND", "nccl")
+    if os.environ.get("DPRHOT_SAME_DEVICE"):
+        local = 0
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if W > 1:
         assert a.gpus == W, f"--gpus {a.gpus} but WORLD_SIZE={W}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if W > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     B, K, d, T = a.batch, 1 + a.negatives, a.dim, a.temperature
     hp = HotPathStep(B, K, d, T, W, rank, dev)
     driver = a.driver
@@ -280,7 +291,7 @@ def main():
         }
         ktimes = {}
         for name, (fn, by, fl) in kern.items():
-            us = time_kernel(hp, fn)
+            us = time_kernel(hp, fn, use_graph=(W == 1))
             ktimes[name] = {"us": round(us, 3), "GBps": round(by / us * 1e-3, 1), "TFLOPs": round(fl / us * 1e-6, 2)}
         dom = max(ktimes, key=lambda k: ktimes[k]["us"])
         by = kern[dom][1]
@@ -315,8 +326,9 @@ def main():
         except Exception as e:  # extra info only
             out["end_to_end"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if W > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
