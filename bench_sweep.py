@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Roofline sweep of the hot-path launches over (B, Nc) -- the BASELINE shapes are launch/latency-bound, so this
+shows where each kernel goes once the problem is large enough to be bandwidth- or MFMA-bound.
+
+  python bench_sweep.py [--dim 768] [--shapes 32x256,128x8192,...]
+Prints one JSON line per shape: per-launch average duration (HIP events, 20-launch graphs replayed back to back),
+algorithmic GB/s and TFLOP/s and their fractions of the gfx950 peaks.
+"""
+import argparse
+import json
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+
+from bench import HBM_PEAK_GBS, MFMA_PEAK_TFLOPS, HotPathStep, time_kernel  # noqa: E402
+
+DEFAULT = "32x256,32x2048,8x512,64x1024,128x8192,256x8192,1024x8192,4096x8192,8192x8192,1024x65536,8192x65536"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--shapes", default=DEFAULT)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    for sh in a.shapes.split(","):
+        B, Nc = (int(x) for x in sh.split("x"))
+        d = a.dim
+        K = Nc // B
+        hp = HotPathStep(B, K, d, 1.0, 1, 0, dev)
+        bn, bd, nd = float(B) * Nc, float(B) * d, float(Nc) * d
+        kern = {
+            "sim_stats_f32": (hp.k_sim32, 6 * bd + 6 * nd + 4 * bn, 2 * bn * d),
+            "prep": (hp.k_prep, 6 * (bd + nd), 0.0),
+            "sim_stats_bf16": (hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d),
+            "softmax_finish": (hp.k_softmax, 6 * bn, 0.0),
+            "bwd_pair": (hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d),
+        }
+        reps = 20 if bn * d < 1e11 else 4
+        row = {"B": B, "Nc": Nc, "d": d}
+        tot = 0.0
+        for name, (fn, by, fl) in kern.items():
+            us = time_kernel(hp, fn, reps=reps, iters=5)
+            tot += us
+            row[name] = {"us": round(us, 2), "GBps": round(by / us * 1e-3, 1), "hbm_frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 4),
+                         "TFLOPs": round(fl / us * 1e-6, 2), "mfma_frac": round(fl / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+        row["step_us"] = round(tot, 2)
+        row["pairs_per_s"] = round(B / tot * 1e6, 1)
+        print(json.dumps(row), flush=True)
+        del hp
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -436,6 +436,12 @@ int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot
     return fail(DPRHOT_E_WORKSPACE, "sim_stats needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
   char* ws = static_cast<char*>(workspace);
+  if (B > 128 && c != nullptr) {
+    // Beyond the latency-bound sizes reading fp32 operands in the GEMM costs more than it saves (twice the staging
+    // registers and bytes per tile, measured 250 vs 580 TFLOP/s at 8192^2): cast once, then the bf16 kernel.
+    if (int rc = dprhot_prep(q, (size_t)B * d, Qb, c, (size_t)Nc * d, Cb, stream)) return rc;
+    return dprhot_sim_stats(Qb, B, Cb, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream);
+  }
   float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
   const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
   GemmArgs a{reinterpret_cast<const uint16_t*>(q), c ? reinterpret_cast<const uint16_t*>(c) : Cb, B, Nc, d, d, d,
@@ -465,7 +471,7 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   GFinalArgs g{S, B, Nc, y, y_offset, grad_scale, reinterpret_cast<const float*>(ws + wl.part_m),
                reinterpret_cast<const float*>(ws + wl.part_s), nt, reinterpret_cast<const float*>(ws + wl.gold), row_loss, row_lse,
                G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum};
-  const bool thin = (long)B * (Nc / 8) <= 256L * 256;  // latency-bound sizes: one chunk per thread
+  const bool thin = (long)B * (Nc / 8) <= 1L << 18;  // latency-bound sizes: one chunk per thread, many small workgroups
   int rpb, xblocks;
   gfinal_geometry(Nc, thin ? 1 : 8, &rpb, &xblocks);
   dim3 grid(xblocks, cdiv(B, rpb));

@@ -33,7 +33,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KPAD = 8;    // k-major LDS row = BK + 8 bf16 (row-to-row bank rotation)
+constexpr int KPAD = 0;    // k-major LDS rows are dense; bank conflicts are removed by an XOR swizzle of the 16-byte chunks
 constexpr int MNPAD = 16;  // mn-major LDS row = R + 16 bf16
 
 struct GemmArgs {
@@ -48,7 +48,7 @@ struct GemmArgs {
 
 template <int R, int BK, bool KMAJOR>
 struct TileGeom {
-  static constexpr int kRowStride = KMAJOR ? (BK + KPAD) : (R + MNPAD);  // elements
+  static constexpr int kRowStride = KMAJOR ? (BK + KPAD) : (R == 128 ? R : R + MNPAD);  // elements
   static constexpr int kRows = KMAJOR ? R : BK;
   static constexpr int kElems = kRows * kRowStride;
   static constexpr int kChunks = R * BK / 8;  // 16-byte chunks in the tile
@@ -74,38 +74,75 @@ __device__ __forceinline__ uint32_t pack_bf16_rne(uint32_t a, uint32_t b) {  // 
   return cvt_pk_bf16(__uint_as_float(a), __uint_as_float(b));
 }
 
-// global -> registers: each thread fetches kIters 16-byte chunks of the tile (zero outside the matrix)
+// k-major LDS image: row r holds BK bf16 = BK/8 chunks of 16 bytes; chunk c of row r lives at chunk position
+// swz(r, c).  ds_read_b128 serves a wave in four 16-lane groups over a 256-byte bank row (16 slots of 16 bytes); a
+// fragment read touches 16 consecutive rows at one chunk column, so the swizzle must spread 16 rows over the 16
+// slots: BK=64 (128-byte rows, two rows per bank row): c ^ ((r >> 1) & 7);  BK>=128 (row = k * 256 bytes): c ^ (r & 15).
+// Both are conflict-free for the b128 lane groups (checked against the group table of MI355X_MICROARCH.md) and keep
+// the 8-lane write groups of ds_write_b128 inside one row.  (The padded layout it replaces measured 32 % extra
+// LDS cycles, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)
+// mn-major LDS image of a 128-wide tile: k row = 256 bytes = one bank row = eight 32-byte column groups (the unit one
+// 4-lane quarter of a ds_read_b64_tr_b16 group fetches).  The 32 lanes served together read rows k0..k0+3 and
+// k0+8..k0+11 of ONE column group, so group cg of row k is stored at slot cg ^ mswz(k): 8 distinct slots.
+__device__ __forceinline__ int mswz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <int BK>
+__device__ __forceinline__ int kswz(int row, int chunk) {
+  if constexpr (BK == 64) return chunk ^ ((row >> 1) & 7);
+  else return chunk ^ (row & 15);
+}
+
+// Per-thread staging plan, computed ONCE per tile: element offset of each of the thread's chunks at K step 0 and its
+// LDS position.  Per K step only a wave-uniform offset is added (the earlier per-step 64-bit index arithmetic was
+// ~40 % of all VALU instructions of a large GEMM).
+template <int R, int BK, bool KMAJOR>
+struct StagePlan {
+  size_t eoff[TileGeom<R, BK, KMAJOR>::kIters];  // element offset in the operand (row clamped into the matrix)
+  int lds[TileGeom<R, BK, KMAJOR>::kIters];      // element offset in the LDS tile
+  int kpos[TileGeom<R, BK, KMAJOR>::kIters];     // k position of the chunk inside a K step
+};
+
+template <int R, int BK, bool KMAJOR>
+__device__ __forceinline__ void stage_plan(StagePlan<R, BK, KMAJOR>& pl, int ld, int r0, int rdim, int tid) {
+  using G = TileGeom<R, BK, KMAJOR>;
+#pragma unroll
+  for (int it = 0; it < G::kIters; ++it) {
+    const int c = tid + it * 256;
+    if constexpr (KMAJOR) {
+      constexpr int CPR = BK / 8;  // chunks per row
+      const int row = c / CPR, kc = c % CPR;
+      pl.eoff[it] = (size_t)min(r0 + row, rdim - 1) * ld + kc * 8;
+      pl.lds[it] = row * G::kRowStride + kswz<BK>(row, kc) * 8;
+      pl.kpos[it] = kc * 8;
+    } else {
+      constexpr int CPR = R / 8;  // chunks per k-row
+      const int krow = c / CPR, mc = c % CPR;
+      pl.eoff[it] = (size_t)krow * ld + min(r0 + mc * 8, rdim - 8);
+      if constexpr (R == 128) pl.lds[it] = krow * G::kRowStride + (((mc >> 1) ^ mswz(krow)) << 4) + (mc & 1) * 8;
+      else pl.lds[it] = krow * G::kRowStride + mc * 8;
+      pl.kpos[it] = krow;
+    }
+  }
+}
+
+// global -> registers.  Branch-free: every load executes, on an in-range address.  Rows of the M/N dimension beyond
+// the matrix only feed output rows/columns that are never stored (clamped in the plan); positions beyond the K
+// range would enter every sum: their address falls back to the operand base and stage_store zeroes the chunk on its
+// way into LDS (nothing here *uses* a loaded value -- that would park an s_waitcnt right behind the load).
+// kbase = first k of this K step; koff = kbase (k-major) or kbase * ld (mn-major) elements, wave-uniform.
 template <int R, int BK, bool KMAJOR, bool F32>
-__device__ __forceinline__ void stage_load(StageRegs<R, BK, KMAJOR, F32>& regs, const uint16_t* __restrict__ P, int ld, int r0,
-                                           int rdim, int k0, int kend, int tid) {
-  // Branch-free: every load executes, on a clamped address.  Rows of the M/N dimension beyond the matrix only
-  // feed output rows/columns that are never stored, so they may hold anything; positions beyond the K range
-  // would enter every sum, so stage_store zeroes them on their way into LDS (a select, not a branch).
+__device__ __forceinline__ void stage_load(StageRegs<R, BK, KMAJOR, F32>& regs, const StagePlan<R, BK, KMAJOR>& pl,
+                                           const uint16_t* __restrict__ P, size_t koff, int kbase, int kend, int tid) {
   using G = TileGeom<R, BK, KMAJOR>;
   constexpr int ES = F32 ? 2 : 1;  // element size in uint16 units
 #pragma unroll
   for (int it = 0; it < G::kIters; ++it) {
-    const int c = tid + it * 256;
     uint4 v = make_uint4(0u, 0u, 0u, 0u), w = make_uint4(0u, 0u, 0u, 0u);
-    if (G::kChunks % 256 == 0 || c < G::kChunks) {
-      size_t off;
-      bool kok;
-      if constexpr (KMAJOR) {
-        constexpr int CPR = BK / 8;  // chunks per row
-        const int row = c / CPR, kc = c % CPR;
-        const int gr = min(r0 + row, rdim - 1), gk = k0 + kc * 8;
-        kok = gk < kend;
-        off = (size_t)gr * ld + (kok ? gk : 0);
-      } else {
-        constexpr int CPR = R / 8;  // chunks per k-row
-        const int krow = c / CPR, mc = c % CPR;
-        const int gk = k0 + krow, gr = min(r0 + mc * 8, rdim - 8);
-        kok = gk < kend;
-        off = (size_t)(kok ? gk : 0) * ld + gr;
-      }
-      const uint16_t* src = P + off * ES;
-      v = *reinterpret_cast<const uint4*>(src);  // NOT touched here (a select would park an s_waitcnt right after
-      if constexpr (F32) w = *reinterpret_cast<const uint4*>(src + 8);  // the load): stage_store zeroes beyond-K chunks
+    if (G::kChunks % 256 == 0 || tid + it * 256 < G::kChunks) {
+      const bool kok = kbase + pl.kpos[it] < kend;
+      const uint16_t* src = kok ? P + (pl.eoff[it] + koff) * ES : P;
+      v = *reinterpret_cast<const uint4*>(src);
+      if constexpr (F32) w = *reinterpret_cast<const uint4*>(src + 8);
     }
     if constexpr (F32) {
       regs.v[2 * it] = v;
@@ -116,17 +153,15 @@ __device__ __forceinline__ void stage_load(StageRegs<R, BK, KMAJOR, F32>& regs, 
   }
 }
 
-// registers -> LDS tile
-// (copy != nullptr, fp32 operands only: the bf16 image of the chunk is also written to HBM at the operand's own
-// [row][ld] position -- the backward GEMMs read that copy)
+// registers -> LDS tile (fp32 operands are rounded to bf16 here; copy != nullptr: the bf16 image of the chunk is also
+// written to HBM at the operand's own position -- the backward GEMMs read that copy)
 template <int R, int BK, bool KMAJOR, bool F32>
-__device__ __forceinline__ void stage_store(const StageRegs<R, BK, KMAJOR, F32>& regs, uint16_t* T, int tid, uint16_t* copy, int ld,
-                                            int r0, int rdim, int k0, int kend) {
+__device__ __forceinline__ void stage_store(const StageRegs<R, BK, KMAJOR, F32>& regs, const StagePlan<R, BK, KMAJOR>& pl, uint16_t* T,
+                                            int tid, uint16_t* copy, size_t koff, int kbase, int kend) {
   using G = TileGeom<R, BK, KMAJOR>;
 #pragma unroll
   for (int it = 0; it < G::kIters; ++it) {
-    const int c = tid + it * 256;
-    if (G::kChunks % 256 == 0 || c < G::kChunks) {
+    if (G::kChunks % 256 == 0 || tid + it * 256 < G::kChunks) {
       uint4 v;
       if constexpr (F32) {
         const uint4 a = regs.v[2 * it], b = regs.v[2 * it + 1];
@@ -134,26 +169,11 @@ __device__ __forceinline__ void stage_store(const StageRegs<R, BK, KMAJOR, F32>&
       } else {
         v = regs.v[it];
       }
-      {
-        const int kpos = KMAJOR ? (k0 + (c % (BK / 8)) * 8) : (k0 + c / (R / 8));
-        if (kpos >= kend) v = make_uint4(0u, 0u, 0u, 0u);  // beyond the K range: contributes nothing
-      }
-      if constexpr (KMAJOR) {
-        constexpr int CPR = BK / 8;
-        const int row = c / CPR, kc = c % CPR;
-        *reinterpret_cast<uint4*>(T + row * G::kRowStride + kc * 8) = v;
-        if constexpr (F32) {
-          const int gr = r0 + row, gk = k0 + kc * 8;
-          if (copy != nullptr && gr < rdim && gk < kend) *reinterpret_cast<uint4*>(copy + (size_t)gr * ld + gk) = v;
-        }
-      } else {
-        constexpr int CPR = R / 8;
-        const int krow = c / CPR, mc = c % CPR;
-        *reinterpret_cast<uint4*>(T + krow * G::kRowStride + mc * 8) = v;
-        if constexpr (F32) {
-          const int gk = k0 + krow, gr = r0 + mc * 8;
-          if (copy != nullptr && gk < kend && gr < rdim) *reinterpret_cast<uint4*>(copy + (size_t)gk * ld + gr) = v;
-        }
+      const bool kok = kbase + pl.kpos[it] < kend;
+      if (!kok) v = make_uint4(0u, 0u, 0u, 0u);  // beyond the K range: contributes nothing
+      *reinterpret_cast<uint4*>(T + pl.lds[it]) = v;
+      if constexpr (F32) {
+        if (copy != nullptr && kok) *reinterpret_cast<uint4*>(copy + pl.eoff[it] + koff) = v;
       }
     }
   }
@@ -166,15 +186,24 @@ __device__ __forceinline__ bf16x8 load_frag(const uint16_t* T, int r0, int kk, i
   using G = TileGeom<R, BK, KMAJOR>;
   const int i = lane & 15, g = lane >> 4;
   if constexpr (KMAJOR) {
-    return *reinterpret_cast<const bf16x8*>(T + (r0 + i) * G::kRowStride + kk * 32 + g * 8);
+    const int row = r0 + i;
+    return *reinterpret_cast<const bf16x8*>(T + row * G::kRowStride + kswz<BK>(row, kk * 4 + g) * 8);
   } else if constexpr (USE_TR) {
     // ds_read_b64_tr_b16: within each 16-lane group, source lane s supplies 4 contiguous bf16 =
     // row (s >> 2), columns 4*(s & 3).. of a 4 x 16 block; result lane i receives column i of that block.
     // (verified on MI355X by csrc/selftest "trdump")
-    const uint16_t* p = T + (kk * 32 + g * 8 + (i >> 2)) * G::kRowStride + r0 + (i & 3) * 4;
+    const int k = kk * 32 + g * 8 + (i >> 2);
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const uint16_t *p, *ph;
+    if constexpr (R == 128) {  // swizzled 32-byte column groups (mswz(k + 4) == mswz(k): one swizzle for both reads)
+      p = T + k * G::kRowStride + (((r0 >> 4) ^ mswz(k)) << 4) + (i & 3) * 4;
+      ph = p + 4 * G::kRowStride;
+    } else {
+      p = T + k * G::kRowStride + r0 + (i & 3) * 4;
+      ph = p + 4 * G::kRowStride;
+    }
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p + 4 * G::kRowStride));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(ph));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -182,9 +211,12 @@ __device__ __forceinline__ bf16x8 load_frag(const uint16_t* T, int r0, int kk, i
   } else {
     // plain 16-bit gathers (slow; kept as the cross-check of the transpose read)
     bf16x8 r;
-    const uint16_t* p = T + (kk * 32 + g * 8) * G::kRowStride + r0 + i;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (short)p[j * G::kRowStride];
+    for (int j = 0; j < 8; ++j) {
+      const int k = kk * 32 + g * 8 + j;
+      if constexpr (R == 128) r[j] = (short)T[k * G::kRowStride + (((r0 >> 4) ^ mswz(k)) << 4) + i];
+      else r[j] = (short)T[k * G::kRowStride + r0 + i];
+    }
     return r;
   }
 }
@@ -240,16 +272,27 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const Epi& epi, int
   // PF register stages: the loads of K steps t .. t+PF-1 are in flight together (a small-M launch is bound by
   // the latency of dependent loads, not by bandwidth); LDS is double-buffered, one barrier per K step.
   constexpr int kStageRegs = GA::kIters * (A_F32 ? 2 : 1) + GB::kIters * (B_F32 ? 2 : 1);
-  constexpr int PF = kStageRegs <= 6 ? 4 : ((kStageRegs <= 8 || (BM * BN <= 32 * 32 && kStageRegs <= 16)) ? 3 : 2);
+  // 128x128 tiles keep 64 accumulator registers per lane: two stages keep VGPR+AGPR <= 256, i.e. two waves per
+  // SIMD (the third stage cost a whole wave of occupancy: -25 % measured); small tiles are latency-bound and take
+  // as many stages as cover their K range.
+  constexpr int PF = (BM * BN >= 128 * 128) ? 2
+                     : (kStageRegs <= 6 ? 4 : ((kStageRegs <= 8 || (BM * BN <= 32 * 32 && kStageRegs <= 16)) ? 3 : 2));
   StageRegs<BM, BK, A_KMAJOR, A_F32> ra[PF];
   StageRegs<BN, BK, B_KMAJOR, B_F32> rb[PF];
+  StagePlan<BM, BK, A_KMAJOR> pa;
+  StagePlan<BN, BK, B_KMAJOR> pb;
+  stage_plan<BM, BK, A_KMAJOR>(pa, p.lda, m0, p.M, tid);
+  stage_plan<BN, BK, B_KMAJOR>(pb, p.ldb, n0, p.N, tid);
+  const size_t astep = A_KMAJOR ? (size_t)1 : (size_t)p.lda;  // operand elements per unit of k
+  const size_t bstep = B_KMAJOR ? (size_t)1 : (size_t)p.ldb;
   uint16_t* const acopy = (A_F32 && bx == 0) ? p.Acopy : nullptr;  // each operand row is copied by exactly one tile column/row
   uint16_t* const bcopy = (B_F32 && by == 0) ? p.Bcopy : nullptr;
 #pragma unroll
   for (int u = 0; u < PF; ++u)
     if (u < nt) {
-      stage_load<BM, BK, A_KMAJOR, A_F32>(ra[u], p.A, p.lda, m0, p.M, kbeg + u * BK, kend, tid);
-      stage_load<BN, BK, B_KMAJOR, B_F32>(rb[u], p.B, p.ldb, n0, p.N, kbeg + u * BK, kend, tid);
+      const int kb = kbeg + u * BK;
+      stage_load<BM, BK, A_KMAJOR, A_F32>(ra[u], pa, p.A, kb * astep, kb, kend, tid);
+      stage_load<BN, BK, B_KMAJOR, B_F32>(rb[u], pb, p.B, kb * bstep, kb, kend, tid);
     }
 
   // The epilogue's prefetched words are consumed HERE: they were issued before the tile loads, so this wait is a
@@ -266,14 +309,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const Epi& epi, int
         uint16_t* Ac = As0 + cur * GA::kElems;
         uint16_t* Bc = Bs0 + cur * GB::kElems;
         if (t == 0) DPRHOT_TM(1);
-        stage_store<BM, BK, A_KMAJOR, A_F32>(ra[u], Ac, tid, acopy, p.lda, m0, p.M, kbeg + t * BK, kend);
-        stage_store<BN, BK, B_KMAJOR, B_F32>(rb[u], Bc, tid, bcopy, p.ldb, n0, p.N, kbeg + t * BK, kend);
+        const int kb = kbeg + t * BK;
+        stage_store<BM, BK, A_KMAJOR, A_F32>(ra[u], pa, Ac, tid, acopy, kb * astep, kb, kend);
+        stage_store<BN, BK, B_KMAJOR, B_F32>(rb[u], pb, Bc, tid, bcopy, kb * bstep, kb, kend);
         if (t == 0) DPRHOT_TM(2);
         __syncthreads();  // tile t visible; every wave is past its MFMAs on this buffer (step t-2)
         if (t == 0) DPRHOT_TM(3);
         if (t + PF < nt) {
-          stage_load<BM, BK, A_KMAJOR, A_F32>(ra[u], p.A, p.lda, m0, p.M, kbeg + (t + PF) * BK, kend, tid);
-          stage_load<BN, BK, B_KMAJOR, B_F32>(rb[u], p.B, p.ldb, n0, p.N, kbeg + (t + PF) * BK, kend, tid);
+          const int kn = kbeg + (t + PF) * BK;
+          stage_load<BM, BK, A_KMAJOR, A_F32>(ra[u], pa, p.A, kn * astep, kn, kend, tid);
+          stage_load<BN, BK, B_KMAJOR, B_F32>(rb[u], pb, p.B, kn * bstep, kn, kend, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
@@ -300,7 +345,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const Epi& epi, int
 
 template <int BM, int BN, int BK, int WM, int WN, bool A_KMAJOR, bool B_KMAJOR, bool USE_TR, class Epi, bool A_F32 = false,
           bool B_F32 = false>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p, Epi epi) {
+__global__ __launch_bounds__(256, (A_F32 && B_F32) ? 1 : 2) void gemm_bf16_kernel(GemmArgs p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   gemm_tile<BM, BN, BK, WM, WN, A_KMAJOR, B_KMAJOR, USE_TR, Epi, A_F32, B_F32>(p, epi, blockIdx.x, blockIdx.y, blockIdx.z,
                                                                                 gridDim.x, smem);
@@ -317,7 +362,7 @@ struct GemmCfg {
 // problem 2 (with split-K slabs).  Used for the backward pair dC_part = G^T Q and dQ = G C, which share only
 // their input G.
 template <class Cfg1, class Cfg2, class Epi1, class Epi2>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs p1, Epi1 e1, int nbx1, int nby1, GemmArgs p2, Epi2 e2, int nbx2,
+__global__ __launch_bounds__(256, 2) void gemm_pair_kernel(GemmArgs p1, Epi1 e1, int nbx1, int nby1, GemmArgs p2, Epi2 e2, int nbx2,
                                                         int nby2) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int n1 = nbx1 * nby1;

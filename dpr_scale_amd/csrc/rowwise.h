@@ -209,22 +209,31 @@ __global__ __launch_bounds__(256) void gfinal_kernel(GFinalArgs p) {
     s_y[tid] = (int)(p.y[st_row0 + tid] + p.y_offset);
   }
   __syncthreads();
-  if (p.nt <= 32) {  // one thread per row
+  // Row logsumexp out of LDS in two short phases (cross-lane shuffles are ds_bpermute round trips, ~120 cycles
+  // each and serialised; plain LDS traffic is cheaper here): tpr threads per row fold nt/tpr pairs each, then one
+  // thread per row folds the tpr partial pairs.
+  if (p.nt <= 8) {  // a handful of pairs per row: one thread per row, no second phase
     if (tid < st_rows) {
       float m = -INFINITY, sm = 0.f;
       for (int t = 0; t < p.nt; ++t) ms_combine(m, sm, s_pm[tid * p.nt + t], s_ps[tid * p.nt + t]);
       s_lse[tid] = m + logf(sm);
     }
-  } else {  // one wave per row
-    for (int lr = wave; lr < st_rows; lr += 4) {
+  } else {
+    __shared__ float s2_m[256], s2_s[256];
+    int tpr = 16;
+    while (tpr > 1 && st_rows * tpr > 256) tpr >>= 1;
+    const int lr = tid / tpr, sub = tid - lr * tpr;
+    if (lr < st_rows) {
       float m = -INFINITY, sm = 0.f;
-      for (int t = lane; t < p.nt; t += 64) ms_combine(m, sm, s_pm[lr * p.nt + t], s_ps[lr * p.nt + t]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sm, o, 64);
-        ms_combine(m, sm, m2, s2);
-      }
-      if (lane == 0) s_lse[lr] = m + logf(sm);
+      for (int t = sub; t < p.nt; t += tpr) ms_combine(m, sm, s_pm[lr * p.nt + t], s_ps[lr * p.nt + t]);
+      s2_m[tid] = m;
+      s2_s[tid] = sm;
+    }
+    __syncthreads();
+    if (tid < st_rows) {
+      float m = s2_m[tid * tpr], sm = s2_s[tid * tpr];
+      for (int k = 1; k < tpr; ++k) ms_combine(m, sm, s2_m[tid * tpr + k], s2_s[tid * tpr + k]);
+      s_lse[tid] = m + logf(sm);
     }
   }
   __syncthreads();
