@@ -296,8 +296,15 @@ def main():
         dom = max(ktimes, key=lambda k: ktimes[k]["us"])
         by = kern[dom][1]
         us = ktimes[dom]["us"]
+        traffic, tsrc = None, None
+        tfile = os.path.join(ROOT, "profiles", "bench_cfg2_traffic.json")
+        if W == 1 and (B, K, d) == (32, 8, 768) and os.path.isfile(tfile):  # PMC bytes of this very workload (profiles/)
+            tj = json.load(open(tfile))
+            if dom in tj.get("kernels", {}):
+                traffic, tsrc = tj["kernels"][dom]["hbm_bytes_per_launch"], f"profiles/bench_cfg2_traffic.json ({tj['source']})"
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(by / us * 1e-3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_us": us, "algorithmic_bytes": by}
+                "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
+                "avg_launch_us": us, "algorithmic_bytes": by}
         other = "eager" if driver == "graph" else "graph"
         alt = None
         if W == 1:

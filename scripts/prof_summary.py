@@ -57,6 +57,22 @@ def main():
         for r in sorted(rows.values(), key=lambda r: -r.get("total_us", 0)):
             w.writerow({k: (f"{v:.3f}" if isinstance(v, float) else v) for k, v in r.items()})
     print(open(path).read())
+    # per-launch HBM traffic of the bench.py launches, in the names bench.py uses (read back by bench.py -> roofline.traffic)
+    import json
+    names = {"sim_stats_f32": "EpiSim", "softmax_finish": "gfinal_kernel", "bwd_pair": "gemm_pair_kernel"}
+    traffic = {}
+    for bname, pat in names.items():
+        for r in rows.values():
+            if pat in r["kernel"] and r.get("hbm_bytes_per_launch_corrected") is not None:
+                traffic[bname] = {"hbm_bytes_per_launch": round(r["hbm_bytes_per_launch_corrected"]),
+                                  "FETCH_SIZE_KiB": round(r["FETCH_SIZE_KiB_avg"], 2), "WRITE_SIZE_KiB": round(r["WRITE_SIZE_KiB_avg"], 2),
+                                  "rocprof_avg_us": round(r.get("avg_us", 0.0), 3), "kernel": r["kernel"][:120]}
+    if traffic:
+        jp = os.path.join(a.out, "bench_cfg2_traffic.json")
+        json.dump({"source": a.tag, "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py`; "
+                   "bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts 64 B per 128 B request)",
+                   "kernels": traffic}, open(jp, "w"), indent=1)
+        print("wrote", jp)
 
 
 if __name__ == "__main__":
