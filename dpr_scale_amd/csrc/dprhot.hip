@@ -134,14 +134,14 @@ int launch_gemm(int tile, const GemmArgs& a, const Epi& epi, int splits, hipStre
 
 // sim GEMM reading fp32 operands directly (AF: q is fp32, BF: c is fp32); bf16 copies go to a.Acopy / a.Bcopy
 template <bool AF, bool BF>
-int launch_sim_f32(int tile, const GemmArgs& a, const EpiSim& epi, hipStream_t st) {
+int launch_sim_f32(int tile, const GemmArgs& a, const EpiSim& epi, int splits, hipStream_t st) {
   switch (tile) {
-    case 0: return launch_one<128, 128, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
-    case 1: return launch_one<64, 128, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
-    case 2: return launch_one<64, 64, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
-    case 3: return launch_one<32, 64, 64, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
-    case 4: return launch_one<32, 64, 256, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
-    case 5: return launch_one<32, 32, 256, true, true, false, EpiSim, AF, BF>(a, epi, 1, st);
+    case 0: return launch_one<128, 128, 64, true, true, false, EpiSim, AF, BF>(a, epi, splits, st);
+    case 1: return launch_one<64, 128, 64, true, true, false, EpiSim, AF, BF>(a, epi, splits, st);
+    case 2: return launch_one<64, 64, 64, true, true, false, EpiSim, AF, BF>(a, epi, splits, st);
+    case 3: return launch_one<32, 64, 64, true, true, false, EpiSim, AF, BF>(a, epi, splits, st);
+    case 4: return launch_one<32, 64, 256, true, true, false, EpiSim, AF, BF>(a, epi, splits, st);
+    case 5: return launch_one<32, 32, 256, true, true, false, EpiSim, AF, BF>(a, epi, splits, st);
   }
   return fail(DPRHOT_E_UNSUPPORTED, "bad tile id %d", tile);
 }
@@ -224,11 +224,47 @@ WsLayout ws_layout(int B, int Nc, int d) {
   w.gold = off; off += align256((size_t)B * 4);
   w.part_m = off; off += align256((size_t)B * ntmax * 4);
   w.part_s = off; off += align256((size_t)B * ntmax * 4);
-  w.logits = off; off += align256((size_t)B * Nc * 4);
+  w.logits = off; off += align256((size_t)B * Nc * 4 * ((Nc <= 4096 && B <= 64) ? 4 : 1));  // short rows: up to 4 split-K slabs
   const DqPlan p = dq_plan(B, Nc, d);
   w.dq_part = off; off += align256((size_t)p.splits * B * d * 4);
   w.total = off;
   return w;
+}
+
+// Forward plan, a pure function of the shape (both forward launches derive it independently).
+//  short rows (the BASELINE training shapes): sim split over K into `splits` slabs, softmax with the row in registers
+//  long rows: sim with per-tile statistics, then the streaming gfinal kernel
+struct FwdPlan { bool short_rows; int tile, splits, kchunk, nt, tpr, cpt, threads, blocks; };
+bool no_short() {
+  static const bool v = []() { const char* e = getenv("DPRHOT_NO_SHORT"); return e && e[0] == '1'; }();
+  return v;
+}
+FwdPlan fwd_plan(int B, int Nc, int d) {
+  FwdPlan p{};
+  p.short_rows = Nc <= 4096 && B <= 64 && !no_short() && force_tile() < 0;
+  if (!p.short_rows) {
+    p.tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
+    p.splits = 1;
+    p.kchunk = cdiv(d, kTiles[p.tile].bk) * kTiles[p.tile].bk;
+    p.nt = cdiv(Nc, kTiles[p.tile].bn);
+    return p;
+  }
+  p.tile = B <= 32 ? (d >= 256 ? 5 : 3) : 2;
+  const int bk = kTiles[p.tile].bk, ksteps = cdiv(d, bk);
+  int splits = ksteps < 4 ? ksteps : 4;
+  p.kchunk = cdiv(ksteps, splits) * bk;
+  p.splits = cdiv(d, p.kchunk);
+  const int cpr = Nc / 8;
+  p.cpt = cpr > 256 ? 2 : 1;
+  int tpr = 16;
+  while (tpr * p.cpt < cpr) tpr <<= 1;
+  p.tpr = tpr;
+  int rpb = 1024 / tpr;
+  if (rpb > B) rpb = B;
+  if (rpb < 1) rpb = 1;
+  p.threads = rpb * tpr;
+  p.blocks = cdiv(B, rpb);
+  return p;
 }
 
 int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
@@ -414,12 +450,17 @@ int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, 
     return fail(DPRHOT_E_WORKSPACE, "sim_stats needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
   char* ws = static_cast<char*>(workspace);
+  const FwdPlan fp = fwd_plan(B, Nc, d);
+  GemmArgs a{Q, C, B, Nc, d, d, d, fp.kchunk};
+  if (fp.short_rows) {  // partial logits per K split; the softmax launch sums them (and fills S_out if asked)
+    EpiSim epi{reinterpret_cast<float*>(ws + wl.logits), colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr,
+               reinterpret_cast<unsigned long long*>(ws + wl.header), 2, (size_t)B * Nc};
+    return launch_gemm<true, true>(fp.tile, a, epi, fp.splits, (hipStream_t)stream);
+  }
   float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
-  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
-  GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
   EpiSim epi{S, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m), reinterpret_cast<float*>(ws + wl.part_s),
              y, y_offset, reinterpret_cast<float*>(ws + wl.gold), reinterpret_cast<unsigned long long*>(ws + wl.header), 2};
-  return launch_gemm<true, true>(tile, a, epi, 1, (hipStream_t)stream);
+  return launch_gemm<true, true>(fp.tile, a, epi, 1, (hipStream_t)stream);
 }
 
 // launch 1 with fp32 operands: q [B,d] fp32 always; c [Nc,d] fp32 when non-NULL (single rank: no gather), else
@@ -442,15 +483,21 @@ int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot
     if (int rc = dprhot_prep(q, (size_t)B * d, Qb, c, (size_t)Nc * d, Cb, stream)) return rc;
     return dprhot_sim_stats(Qb, B, Cb, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream);
   }
-  float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
-  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
-  GemmArgs a{reinterpret_cast<const uint16_t*>(q), c ? reinterpret_cast<const uint16_t*>(c) : Cb, B, Nc, d, d, d,
-             cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
+  const FwdPlan fp = fwd_plan(B, Nc, d);
+  GemmArgs a{reinterpret_cast<const uint16_t*>(q), c ? reinterpret_cast<const uint16_t*>(c) : Cb, B, Nc, d, d, d, fp.kchunk};
   a.Acopy = Qb;
   a.Bcopy = c ? Cb : nullptr;
+  if (fp.short_rows) {
+    EpiSim epi{reinterpret_cast<float*>(ws + wl.logits), colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr,
+               reinterpret_cast<unsigned long long*>(ws + wl.header), 2, (size_t)B * Nc};
+    return c ? launch_sim_f32<true, true>(fp.tile, a, epi, fp.splits, (hipStream_t)stream)
+             : launch_sim_f32<true, false>(fp.tile, a, epi, fp.splits, (hipStream_t)stream);
+  }
+  float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
   EpiSim epi{S, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m), reinterpret_cast<float*>(ws + wl.part_s),
              y, y_offset, reinterpret_cast<float*>(ws + wl.gold), reinterpret_cast<unsigned long long*>(ws + wl.header), 2};
-  return c ? launch_sim_f32<true, true>(tile, a, epi, (hipStream_t)stream) : launch_sim_f32<true, false>(tile, a, epi, (hipStream_t)stream);
+  return c ? launch_sim_f32<true, true>(fp.tile, a, epi, 1, (hipStream_t)stream)
+           : launch_sim_f32<true, false>(fp.tile, a, epi, 1, (hipStream_t)stream);
 }
 
 // launch 2 of the fused forward: logsumexp from the statistics, G in one pass over S, loss numerator
@@ -464,9 +511,18 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   if (workspace == nullptr || workspace_bytes < wl.total)
     return fail(DPRHOT_E_WORKSPACE, "softmax_finish needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   char* ws = static_cast<char*>(workspace);
+  const FwdPlan fp = fwd_plan(B, Nc, d);  // same plan as dprhot_sim_stats -> same intermediate layout
+  if (fp.short_rows) {
+    // S_in, when given, is where the caller wants the summed logits (the slabs always live in the workspace)
+    GShortArgs g{reinterpret_cast<const float*>(ws + wl.logits), fp.splits, (size_t)B * Nc, B, Nc, y, y_offset, grad_scale,
+                 const_cast<float*>(S_in), row_loss, row_lse, G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum, fp.tpr};
+    if (fp.cpt == 1) hipLaunchKernelGGL(gfinal_short_kernel<1>, dim3(fp.blocks), dim3(fp.threads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gfinal_short_kernel<2>, dim3(fp.blocks), dim3(fp.threads), 0, (hipStream_t)stream, g);
+    HIP_TRY(hipGetLastError());
+    return DPRHOT_OK;
+  }
   const float* S = S_in ? S_in : reinterpret_cast<const float*>(ws + wl.logits);
-  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);  // same choice as dprhot_sim_stats -> same statistics layout
-  const int nt = cdiv(Nc, kTiles[tile].bn);
+  const int nt = fp.nt;
   if (nt > kGfMaxPairs) return fail(DPRHOT_E_UNSUPPORTED, "Nc=%d too long for the statistics buffer (%d column tiles)", Nc, nt);
   GFinalArgs g{S, B, Nc, y, y_offset, grad_scale, reinterpret_cast<const float*>(ws + wl.part_m),
                reinterpret_cast<const float*>(ws + wl.part_s), nt, reinterpret_cast<const float*>(ws + wl.gold), row_loss, row_lse,

@@ -425,6 +425,7 @@ struct EpiSim {
   float* gold;       // [M] gold logit
   unsigned long long* zero_words;  // words to clear for the next kernel (tile (0,0) clears them), or nullptr
   int n_zero;
+  size_t slab_stride = 0;  // split-K (statistics off): split bz stores its partial logits at S + bz * slab_stride
 
   // begin(): raw loads only, issued back to back BEFORE the tile loads (nothing is used here, or the compiler
   // parks one s_waitcnt per load at the top of the kernel); settle(): turned into what finish() needs, after the
@@ -475,8 +476,9 @@ struct EpiSim {
   template <int BM, int BN, int WM, int WN, int TM, int TN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, const State<TM, TN>& st) const {
     const int i = c.lane & 15, g = c.lane >> 4;
-    if (zero_words != nullptr && c.bx == 0 && c.m0 == 0 && c.tid < n_zero) zero_words[c.tid] = 0ull;
+    if (zero_words != nullptr && c.bx == 0 && c.m0 == 0 && c.bz == 0 && c.tid < n_zero) zero_words[c.tid] = 0ull;
     const bool (&masked)[TN] = st.masked;
+    float* const S = this->S != nullptr ? this->S + (size_t)c.bz * slab_stride : nullptr;
     float* red_m = c.scratch;            // [BM][WN]
     float* red_s = c.scratch + BM * WN;  // [BM][WN]
 #pragma unroll

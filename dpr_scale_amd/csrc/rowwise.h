@@ -18,6 +18,24 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, rw_bf16x2));
 }
 
+template <int N>
+__device__ __forceinline__ float dprhot_dpp_ror(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xF, 0xF, false));
+}
+// reductions over the 16 lanes of a DPP row, all lanes receive the result (VALU only, no ds_bpermute round trips)
+__device__ __forceinline__ float dprhot_row16_max(float v) {
+  v = fmaxf(v, dprhot_dpp_ror<8>(v));
+  v = fmaxf(v, dprhot_dpp_ror<4>(v));
+  v = fmaxf(v, dprhot_dpp_ror<2>(v));
+  return fmaxf(v, dprhot_dpp_ror<1>(v));
+}
+__device__ __forceinline__ float dprhot_row16_sum(float v) {
+  v += dprhot_dpp_ror<8>(v);
+  v += dprhot_dpp_ror<4>(v);
+  v += dprhot_dpp_ror<2>(v);
+  return v + dprhot_dpp_ror<1>(v);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -278,15 +296,159 @@ __global__ __launch_bounds__(256) void gfinal_kernel(GFinalArgs p) {
       if (small || gridDim.y == 1) {
         p.loss_sum[0] = (float)tot;
       } else {
-        const long long fx = __double2ll_rn(tot * kLossFix);
-        const unsigned long long old = atomicAdd(&p.acc[0], (unsigned long long)fx);
-        asm volatile("" ::"v"(old) : "memory");  // the add has been performed at memory before the ticket is issued
-        const unsigned long long ticket = atomicAdd(&p.acc[1], 1ull);
-        if (ticket == (unsigned long long)gridDim.y - 1) {
-          const long long total_fx = (long long)atomicAdd(&p.acc[0], 0ull);
-          p.loss_sum[0] = (float)((double)total_fx / kLossFix);
-        }
+        // ticket (bits 48..63) and 2^-24 fixed-point sum (bits 0..47) in ONE atomic: one round trip
+        long long fx = __double2ll_rn(tot * kLossFix);
+        if (fx < 0) fx = 0;
+        const unsigned long long old = atomicAdd(&p.acc[0], (1ull << 48) | (unsigned long long)fx);
+        if ((old >> 48) == (unsigned long long)gridDim.y - 1)
+          p.loss_sum[0] = (float)((double)((old & ((1ull << 48) - 1)) + (unsigned long long)fx) / kLossFix);
       }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Short-row forward (Nc <= 4096, the BASELINE training shapes): the sim GEMM is split over K into `splits` slabs
+// of partial logits (more, thinner workgroups: these launches are bound by per-CU load latency, not by bandwidth
+// or MFMA) and THIS kernel does the whole row softmax with the row held in registers: sums the slabs, row
+// max / sum (DPP over 16 lanes, then LDS across the row's lane groups), logsumexp, loss, dScores -- one pass.
+// tpr (power of two, 16..1024) threads share a row; a 1024-thread workgroup holds 1024 / tpr rows.
+// Loss numerator across workgroups: ONE 64-bit atomic carries both the arrival ticket (bits 48..63) and the
+// 2^-24 fixed-point sum (bits 0..47): order-independent, hence deterministic, and a single round trip.
+// ----------------------------------------------------------------------------------------------------
+struct GShortArgs {
+  const float* slabs;  // [splits][B][Nc] partial logits (mask and 1/T already applied: -inf at masked columns)
+  int splits;
+  size_t slab_stride;
+  int B, Nc;
+  const int64_t* y;
+  int64_t y_offset;
+  float grad_scale;
+  float* S_out;  // optional [B][Nc]
+  float* row_loss;
+  float* row_lse;
+  uint16_t* G;
+  unsigned long long* acc;  // acc[0]: packed ticket|sum, zeroed by the sim kernel
+  float* loss_sum;
+  int tpr;
+};
+
+constexpr unsigned long long kTicketOne = 1ull << 48;
+constexpr unsigned long long kSumMask = kTicketOne - 1;
+
+template <int CPT>
+__global__ __launch_bounds__(1024) void gfinal_short_kernel(GShortArgs p) {
+  const int tid = threadIdx.x, tpr = p.tpr, rpb = blockDim.x / tpr;
+  const int lr = tid / tpr, j = tid - lr * tpr;
+  const int row = blockIdx.x * rpb + lr;
+  const int cpr = p.Nc >> 3;
+  const bool active = row < p.B;
+  __shared__ float s_red[64], s_red2[64], s_gold[64], s_rl[64];
+  float v[CPT][8];
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int chunk = j + k * tpr;
+    if (active && chunk < cpr) {
+      const float* src = p.slabs + (size_t)row * p.Nc + (size_t)chunk * 8;
+      float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+      for (int z = 1; z < p.splits; ++z) {
+        const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)z * p.slab_stride);
+        const float4 b2 = *reinterpret_cast<const float4*>(src + (size_t)z * p.slab_stride + 4);
+        a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+        b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+      }
+      v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w;
+      v[k][4] = b.x; v[k][5] = b.y; v[k][6] = b.z; v[k][7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = -INFINITY;
+    }
+  }
+  const int yi = active ? (int)(p.y[row] + p.y_offset) : -1;
+  // row max
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, v[k][e]);
+  m = dprhot_row16_max(m);
+  const int grp = tid >> 4, gpr = tpr >> 4;  // 16-lane groups; groups per row
+  if (tpr > 16) {
+    if ((tid & 15) == 0) s_red[grp] = m;
+    __syncthreads();
+    m = s_red[lr * gpr];
+    for (int g2 = 1; g2 < gpr; ++g2) m = fmaxf(m, s_red[lr * gpr + g2]);
+  }
+  // row sum of exp, gold logit
+  float sm = 0.f;
+  if (m != -INFINITY) {
+#pragma unroll
+    for (int k = 0; k < CPT; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += __expf(v[k][e] - m);
+  }
+  sm = dprhot_row16_sum(sm);
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int c0 = (j + k * tpr) * 8;
+    if (yi >= c0 && yi < c0 + 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (yi == c0 + e) s_gold[lr] = v[k][e];
+    }
+  }
+  if (tpr > 16) {
+    if ((tid & 15) == 0) s_red2[grp] = sm;
+    __syncthreads();
+    sm = s_red2[lr * gpr];
+    for (int g2 = 1; g2 < gpr; ++g2) sm += s_red2[lr * gpr + g2];
+  } else {
+    __syncthreads();  // s_gold
+  }
+  const float lse = m + logf(sm);
+  if (active && j == 0) {
+    const float l = lse - s_gold[lr];
+    s_rl[lr] = l;
+    if (p.row_lse) p.row_lse[row] = lse;
+    if (p.row_loss) p.row_loss[row] = l;
+  } else if (j == 0) {
+    s_rl[lr] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int chunk = j + k * tpr;
+    if (active && chunk < cpr) {
+      const int c0 = chunk * 8;
+      if (p.S_out != nullptr) {
+        float* dst = p.S_out + (size_t)row * p.Nc + c0;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[k][4], v[k][5], v[k][6], v[k][7]);
+      }
+      if (p.G != nullptr) {
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float pr = __expf(v[k][e] - lse);
+          if (c0 + e == yi) pr -= 1.0f;
+          g[e] = pr * p.grad_scale;
+        }
+        *reinterpret_cast<uint4*>(p.G + (size_t)row * p.Nc + c0) =
+            make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
+      }
+    }
+  }
+  __syncthreads();  // s_rl
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int r = 0; r < rpb; ++r) tot += (double)s_rl[r];
+    if (gridDim.x == 1) {
+      p.loss_sum[0] = (float)tot;
+    } else {
+      long long fx = __double2ll_rn(tot * kLossFix);
+      if (fx < 0) fx = 0;
+      const unsigned long long old = atomicAdd(&p.acc[0], kTicketOne | (unsigned long long)fx);
+      if ((old >> 48) == (unsigned long long)gridDim.x - 1)
+        p.loss_sum[0] = (float)((double)((old & kSumMask) + (unsigned long long)fx) / kLossFix);
     }
   }
 }

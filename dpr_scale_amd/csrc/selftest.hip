@@ -336,6 +336,8 @@ int main(int argc, char** argv) {
   run_case(100, 1000, 200, 10, 1.0f, true, false);
   run_case(64, 1024, 1024, 2, 1.0f, false, timing);
   run_case(8, 512, 768, 8, 0.05f, true, timing);
+  run_case(32, 2112, 768, 66, 1.0f, true, timing);   // cfg2 per rank at W=8 incl. the mask rows (two chunks per thread)
+  run_case(16, 4096, 128, 256, 2.0f, true, false);
   if (timing || big) run_case(128, 8192, 768, 8, 1.0f, true, timing);
   printf(g_fail ? "SELFTEST FAILED (%d)\n" : "SELFTEST PASSED\n", g_fail);
   return g_fail ? 1 : 0;

@@ -224,7 +224,8 @@ def test_non_inbatch_window_branch(kn, dev):
 
 
 # ---- size-independent properties at full size -----------------------------------------------------------
-@pytest.mark.parametrize("B,Nc,d", [(128, 8192, 768), (1024, 8192, 768), (64, 1024, 1024)])
+@pytest.mark.parametrize("B,Nc,d", [(128, 8192, 768), (1024, 8192, 768), (64, 1024, 1024), (32, 2112, 768), (16, 4096, 128),
+                                    (48, 264, 64)])
 def test_properties_full_size(B, Nc, d, kn, dev):
     gen = torch.Generator(device="cpu").manual_seed(7)
     q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16)
