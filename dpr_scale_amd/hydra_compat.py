@@ -140,14 +140,19 @@ def compose(conf_dir, config_name="config", overrides=()):
                 groups[k] = v
 
     recipe = {}
+    root_first = {}  # the root's own keys when its defaults list starts with _self_ (groups then override them)
     root_file = os.path.join(conf_dir, "config.yaml")
     if os.path.isfile(root_file):
         root_cfg, _ = _read(conf_dir, "config")
-        add_defaults(root_cfg.pop("defaults", []))
-        recipe = root_cfg
+        dl = root_cfg.pop("defaults", [])
+        add_defaults(dl)
+        if dl and dl[0] == "_self_":
+            root_first = root_cfg
+        else:
+            recipe = root_cfg
     else:
         add_defaults(ROOT_DEFAULTS)
-        recipe = {"test_only": False}
+        root_first = {"test_only": False}
     name = config_name[:-5] if config_name.endswith(".yaml") else config_name
     if name != "config":
         rc, _ = _read(conf_dir, name)
@@ -159,7 +164,7 @@ def compose(conf_dir, config_name="config", overrides=()):
             groups[k] = v
             if k not in order:
                 order.append(k)
-    cfg = {}
+    cfg = copy.deepcopy(root_first)
     for g in order:
         body, package = _read(conf_dir, os.path.join(g, str(groups[g])))
         body.pop("defaults", None)

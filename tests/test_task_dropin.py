@@ -62,6 +62,30 @@ def test_config_tree_composes_like_hydra():
     assert cfg.task.optim._target_ == "torch.optim.AdamW" and cfg.checkpoint_callback.monitor == "valid_mrr"
 
 
+def test_config_groups_defaults_overrides_interpolation(tmp_path):
+    """The Hydra mechanics the reference's recipes rely on, on a tree generated here: defaults list, `override`,
+    `# @package _group_` / `_global_`, `${}` interpolation, scientific-notation floats, k=v and group overrides."""
+    def w(rel, text):
+        f = tmp_path / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(text)
+
+    w("config.yaml", "defaults:\n  - _self_\n  - grp: a\n  - grp/sub: x\n  - other: one\nflag: false\n")
+    w("grp/a.yaml", "# @package _group_\nname: a\nlr: 1e-3\n")
+    w("grp/b.yaml", "# @package _group_\nname: b\nlr: 3e-5\n")
+    w("grp/sub/x.yaml", "# @package _group_\npath: base\n")
+    w("other/one.yaml", "# @package _group_\nref: ${grp.sub.path}\nmsg: at-${grp.name}\n")
+    w("other/two.yaml", "# @package _global_\nflag: true\nother:\n  ref: global\n")
+    w("recipe.yaml", "defaults:\n  - config\n  - override grp: b\ngrp:\n  extra: 7\n")
+    base = hydra_compat.compose(str(tmp_path), "config")
+    assert (base.grp.name, base.grp.lr, base.grp.sub.path, base.other.ref, base.other.msg, base.flag) == ("a", 1e-3, "base", "base", "at-a", False)
+    rec = hydra_compat.compose(str(tmp_path), "recipe.yaml", ["grp.sub.path=changed", "+grp.new=2", "other=two"])
+    assert (rec.grp.name, rec.grp.lr, rec.grp.extra, rec.grp.new, rec.grp.sub.path) == ("b", 3e-5, 7, 2, "changed")
+    assert rec.flag is True and rec.other.ref == "global"
+    obj = hydra_compat.instantiate({"_target_": "collections.OrderedDict", "a": 1})
+    assert dict(obj) == {"a": 1}
+
+
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted")
 def test_reference_conf_tree_loads_unchanged():
     cfg = hydra_compat.compose(os.path.join(REF, "dpr_scale", "conf"), "msmarco_baseline.yaml")
