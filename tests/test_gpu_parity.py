@@ -333,3 +333,69 @@ def test_bad_arguments_raise(kn, dev):
     Cb = torch.zeros((8, 60), dtype=torch.bfloat16, device=dev)
     with pytest.raises(DprhotError, match="multiple of 8"):
         kn.sim(Qb, Cb)
+
+
+# ---- operator-level variants ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("qdt,cdt", [(torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16), (torch.float16, torch.float32)])
+def test_operator_accepts_reduced_precision_inputs(qdt, cdt, dev):
+    """Encoder heads with a projection return bf16/fp16 under autocast: the operator takes them (values are
+    bf16-representable here, so the result is the fp32 fixture's)."""
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    meta, g = load_golden("cfg2_Ur_T0.05")
+    q, c, y, m = rank_inputs(meta)[0]
+    tq = t(q, dev).to(qdt).requires_grad_(True)
+    tc = t(c, dev).to(cdt).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), meta["T"])
+    loss.backward()
+    assert tq.grad.dtype == qdt and tc.grad.dtype == cdt
+    assert abs(loss.item() - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+    assert rel(tq.grad.float().cpu().numpy(), g["dQ"]) <= 2 * GRAD_RTOL
+    assert rel(tc.grad.float().cpu().numpy(), g["dC"]) <= 2 * GRAD_RTOL
+
+
+def test_operator_with_only_query_gradient_and_noncontiguous_inputs(dev):
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    meta, g = load_golden("cfg2_U_T1")
+    q, c, y, m = rank_inputs(meta)[0]
+    big = torch.zeros((q.shape[0], 2 * q.shape[1]), device=dev)
+    big[:, ::2] = t(q, dev)
+    tq = big[:, ::2].detach().requires_grad_(True)  # strided view
+    tc = t(c, dev)  # no grad wanted for the contexts
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), meta["T"])
+    loss.backward()
+    assert tc.grad is None
+    assert rel(tq.grad.cpu().numpy(), g["dQ"]) <= GRAD_RTOL
+
+
+def test_large_batch_takes_the_cast_then_bf16_path(kn, dev):
+    """B > 128 through the fp32 entry point (internally dprhot_prep + the bf16-operand GEMM) vs the oracle."""
+    q, c, y, m = O.synth_embeddings(21, 160, 4, 256, "U", True)
+    r = O.training_step_global(q, c, y, m, 1.0)
+    Qb = torch.empty((160, 256), dtype=torch.bfloat16, device=dev)
+    Cb = torch.empty((640, 256), dtype=torch.bfloat16, device=dev)
+    row_loss, lse, loss_sum, G, S = kn.inbatch_fwd_f32(t(q, dev), t(c, dev), Qb, Cb, t(y, dev), 0, t(m.astype(np.uint8), dev),
+                                                       1.0, 1.0 / 160, want_logits=True)
+    assert np.array_equal(Qb.float().cpu().numpy(), q) and np.array_equal(Cb.float().cpu().numpy(), c)
+    assert abs(loss_sum.item() / 160 - r["loss"]) <= LOSS_RTOL * max(1.0, abs(r["loss"]))
+    fin = np.isfinite(r["S"])
+    assert rel(S.cpu().numpy()[fin], r["S"][fin]) <= LOGIT_RTOL
+    dq, dcp = kn.inbatch_bwd(G, Qb, Cb, 1.0, torch.ones(1, device=dev))
+    assert rel(dq.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(dcp.cpu().numpy(), r["dC"]) <= GRAD_RTOL
+
+
+def test_short_and_long_forward_plans_agree(kn, dev, monkeypatch):
+    """The two forward plans (split-K slabs + in-register softmax vs per-tile statistics + streaming pass) on the
+    same inputs: B = 64 (short) against the same rows inside a B = 72 problem (long plan: B > 64)."""
+    q, c, y, m = O.synth_embeddings(33, 72, 8, 128, "U", True)
+    Cb, mask = bf16(c, dev), t(m.astype(np.uint8), dev)
+    outs = []
+    for B in (64, 72):
+        Qb = bf16(q[:B], dev)
+        row_loss, lse, _, G, S = kn.inbatch_fwd(Qb, Cb, t(y[:B], dev), 0, mask, 1.0, 1.0 / 72, want_logits=True)
+        outs.append((row_loss[:64].cpu().numpy(), lse[:64].cpu().numpy(), G[:64].float().cpu().numpy(), S[:64].cpu().numpy()))
+    assert rel(outs[0][0], outs[1][0]) <= 1e-5 and rel(outs[0][1], outs[1][1]) <= 1e-6
+    assert np.abs(outs[0][2] - outs[1][2]).max() <= 2.0 ** -8 * np.abs(outs[1][2]).max()  # bf16 G: at most 1 ulp apart
+    fin = np.isfinite(outs[1][3])
+    assert np.array_equal(fin, np.isfinite(outs[0][3])) and rel(outs[0][3][fin], outs[1][3][fin]) <= 1e-6

@@ -1,0 +1,71 @@
+"""Property tests of the oracle identities and of the host-side planning code (CPU only, hypothesis)."""
+import ctypes
+
+import numpy as np
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from oracle import inbatch_oracle as O
+
+
+@settings(max_examples=25, deadline=None)
+@given(W=st.integers(1, 4), B=st.integers(1, 6), K=st.integers(1, 4), d=st.sampled_from([8, 16, 64]),
+       T=st.sampled_from([0.5, 1.0, 4.0]), seed=st.integers(0, 10_000), ragged=st.booleans())
+def test_local_rows_plus_reduce_scatter_equals_global_step(W, B, K, d, T, seed, ragged):
+    """The identity the whole multi-rank design rests on, for arbitrary small shapes."""
+    parts = [O.synth_embeddings(seed + r, B, K, d, "U", ragged) for r in range(W)]
+    Q = np.concatenate([p[0] for p in parts])
+    C = np.concatenate([p[1] for p in parts])
+    y = O.gathered_labels(np.stack([p[2] for p in parts]), B * K)
+    m = np.concatenate([p[3] for p in parts])
+    ref = O.training_step_global(Q, C, y, m, T)
+    loss_sum, dC = 0.0, 0.0
+    for r in range(W):
+        o = O.training_step_rank(parts[r][0], C, y[r * B:(r + 1) * B], m, T, W * B)
+        loss_sum += o["loss_sum"]
+        dC = dC + o["dC_part"]
+        assert np.allclose(o["dq"], ref["dQ"][r * B:(r + 1) * B], rtol=1e-10, atol=1e-14)
+    assert abs(loss_sum / (W * B) - ref["loss"]) <= 1e-12 * max(1.0, abs(ref["loss"]))
+    assert np.allclose(dC, ref["dC"], rtol=1e-10, atol=1e-14)
+
+
+@settings(max_examples=50, deadline=None)
+@given(rows=st.integers(1, 8), cols=st.integers(1, 40), levels=st.integers(1, 5), seed=st.integers(0, 10_000))
+def test_rank_of_gold_is_position_in_stable_descending_sort(rows, cols, levels, seed):
+    rng = np.random.default_rng(seed)
+    S = rng.integers(0, levels, (rows, cols)).astype(np.float32)  # few distinct values: many ties
+    y = rng.integers(0, cols, rows)
+    order = np.argsort(-S, axis=1, kind="stable")
+    want = np.array([int(np.nonzero(order[i] == y[i])[0][0]) + 1 for i in range(rows)])
+    assert np.array_equal(O.rank_of_gold(S, y), want)
+    k = min(cols, 5)
+    v, idx = O.topk_stable(S, k)
+    assert np.array_equal(idx, order[:, :k])
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.floats(allow_nan=False, allow_infinity=False, width=32))
+def test_bf16_round_is_nearest_even(x):
+    x = np.float32(x)
+    r = O.bf16_round(np.array([x]))[0]
+    bits = np.array([r]).view(np.uint32)[0]
+    assert bits & 0xFFFF == 0  # representable in bf16
+    if np.isfinite(r) and x != 0 and abs(float(x)) > 1e-30:
+        assert abs(float(r) - float(x)) <= abs(float(x)) * 2.0 ** -8
+
+
+def test_host_side_plans_are_consistent():
+    """Pure host code of the C ABI: packed row count, workspace growth, argument validation paths."""
+    from dpr_scale_amd import _lib
+
+    for n_ctx, d in [(256, 768), (8, 8), (1024, 1024), (264, 136), (2048, 64)]:
+        rows = _lib.packed_rows(n_ctx, d)
+        assert rows % 8 == 0 and rows * d * 2 >= n_ctx * d * 2 + n_ctx and rows - n_ctx <= -(-n_ctx // (2 * d)) + 7
+    last = 0
+    for B in [8, 32, 128, 1024]:
+        w = _lib.workspace_bytes(B, 8192, 768)
+        assert w >= B * 8192 * 4 and w > last
+        last = w
+    out = ctypes.c_int(0)
+    assert _lib.lib.dprhot_packed_rows(0, 768, ctypes.byref(out)) == -1
+    assert _lib.lib.dprhot_pack_ctx(None, None, 8, 8, None, None) == -1
