@@ -40,6 +40,9 @@ SIGNATURES = {
     "dprhot_dc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "dprhot_rank_of_gold": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "dprhot_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dprhot_topk_update": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dprhot_search": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
+                              c_void_p, c_size_t, c_void_p]),
     "dprhot_inbatch_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
                                    c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),

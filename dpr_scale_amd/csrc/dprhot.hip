@@ -197,6 +197,10 @@ DqPlan dq_plan(int B, int Nc, int d) {
   if (B <= 32 && Nc >= 256) p.tile = 4;
   else if (B <= 256) p.tile = 2;
   else p.tile = 0;
+  {
+    static const int ft = []() { const char* e = getenv("DPRHOT_DQ_TILE"); return e ? atoi(e) : -1; }();
+    if (ft == 0 || ft == 2 || ft == 4) p.tile = ft;  // tuning aid
+  }
   const TileSpec ts = kTiles[p.tile];
   const int tiles = cdiv(B, ts.bm) * cdiv(d, ts.bn);
   const int ksteps = cdiv(Nc, ts.bk);
@@ -204,6 +208,10 @@ DqPlan dq_plan(int B, int Nc, int d) {
   const int min_steps = ts.bk >= 256 ? 1 : 2;
   if (splits > ksteps / min_steps) splits = ksteps / min_steps;
   if (splits > 16) splits = 16;  // bounds the fp32 slab traffic (splits * B * d * 4 bytes each way)
+  {
+    static const int forced = []() { const char* e = getenv("DPRHOT_DQ_SPLITS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) splits = forced < ksteps ? forced : ksteps;  // tuning aid
+  }
   if (splits < 1) splits = 1;
   p.kchunk = cdiv(ksteps, splits) * ts.bk;
   p.splits = cdiv(Nc, p.kchunk);
@@ -430,11 +438,41 @@ int dprhot_rank_of_gold(const float* S, int rows, int cols, const int64_t* y, in
   return DPRHOT_OK;
 }
 
-int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream) {
+int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values,
+                       int64_t* indices, int first, void* stream) {
   REQUIRE(S && values && indices, "NULL pointer");
-  REQUIRE(rows > 0 && cols > 0 && k > 0 && k <= 128 && k <= cols, "bad shape rows=%d cols=%d k=%d", rows, cols, k);
-  hipLaunchKernelGGL(topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, S, rows, cols, k, values, indices);
+  REQUIRE(rows > 0 && cols > 0 && ld >= cols && k > 0 && k <= TK_KMAX, "bad shape rows=%d cols=%d ld=%lld k=%d", rows, cols,
+          (long long)ld, k);
+  REQUIRE(col_offset >= 0, "negative col_offset");
+  TopkArgs p{S, rows, cols, (long long)ld, (long long)col_offset, k, values, indices, first ? 1 : 0};
+  hipLaunchKernelGGL(topk_stream_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream) {
+  REQUIRE(k <= cols, "k=%d > cols=%d", k, cols);
+  return dprhot_topk_update(S, rows, cols, cols, 0, k, values, indices, 1, stream);
+}
+
+int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_ctx, int d, int64_t id_offset, int k, int chunk,
+                  float* values, int64_t* indices, int first, void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(Q && C && values && indices, "NULL pointer");
+  REQUIRE(nq > 0 && n_ctx > 0 && d > 0 && d % 8 == 0, "bad shape nq=%d n_ctx=%lld d=%d", nq, (long long)n_ctx, d);
+  REQUIRE(n_ctx % 8 == 0 && chunk > 0 && chunk % 8 == 0, "n_ctx=%lld and chunk=%d must be multiples of 8", (long long)n_ctx, chunk);
+  REQUIRE(k > 0 && k <= TK_KMAX, "k=%d out of range (1..%d)", k, TK_KMAX);
+  REQUIRE(aligned16(Q) && aligned16(C), "pointers must be 16-byte aligned");
+  const size_t need = (size_t)nq * (size_t)chunk * sizeof(float);
+  if (workspace == nullptr || workspace_bytes < need)
+    return fail(DPRHOT_E_WORKSPACE, "search needs %zu workspace bytes (nq x chunk fp32 scores), got %zu", need, workspace_bytes);
+  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  float* S = static_cast<float*>(workspace);
+  for (int64_t j0 = 0; j0 < n_ctx; j0 += chunk) {
+    const int cols = (int)((n_ctx - j0 < chunk) ? (n_ctx - j0) : chunk);
+    if (int rc = dprhot_sim_fwd(Q, nq, C + (size_t)j0 * d, cols, d, nullptr, 1.0f, S, stream)) return rc;
+    if (int rc = dprhot_topk_update(S, nq, cols, cols, id_offset + j0, k, values, indices, (first && j0 == 0) ? 1 : 0, stream))
+      return rc;
+  }
   return DPRHOT_OK;
 }
 

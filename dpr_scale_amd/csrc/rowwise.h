@@ -604,51 +604,140 @@ __global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, 
 }
 
 // ----------------------------------------------------------------------------------------------------
-// top-k per row by repeated selection in the total order (score desc, column asc): round r picks the
-// best element strictly after the previous pick.  O(k * cols) reads of an L2-resident row; exact and
-// deterministic (ties by lower column).  One workgroup per row.
+// Streaming top-k per row (torch.topk of run_retrieval_pytorch.py:149-150,156-157, and its shard re-merge
+// :272-277), in the total order (score desc, column asc).  State = the k best so far, sorted, in HBM
+// ([rows][k] values + int64 columns); one workgroup per row folds one chunk of columns into it:
+//   scan the chunk in windows of 8192 columns (32 values per thread in registers, ONE barrier per window),
+//   append the values that beat the current k-th entry to an LDS buffer, and whenever the buffer fills up
+//   bitonic-sort buffer + state (2048 slots) and keep the k best -- the threshold only ever rises, so after the
+//   first windows almost nothing is appended and the kernel is a pure stream over the scores.
+// Exact and deterministic (the buffer order is arbitrary, the sort is by the total order).  k <= 128.
 // ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool before(float v1, int j1, float v2, int j2) {  // (v1,j1) ranks ahead of (v2,j2)
+__device__ __forceinline__ bool tk_before(float v1, long long j1, float v2, long long j2) {  // (v1,j1) ranks ahead of (v2,j2)
   return v1 > v2 || (v1 == v2 && j1 < j2);
 }
 
-__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ S, int rows, int cols, int k, float* __restrict__ values,
-                                                   int64_t* __restrict__ indices) {
-  const int row = blockIdx.x;
-  const float* Srow = S + (size_t)row * cols;
-  __shared__ float sv[4];
-  __shared__ int sj[4];
-  __shared__ float pv;
-  __shared__ int pj;
-  float lastv = INFINITY;
-  int lastj = -1;
-  for (int r = 0; r < k; ++r) {
-    float bv = -INFINITY;
-    int bj = 0x7fffffff;
-    for (int j = threadIdx.x; j < cols; j += 256) {
-      const float v = Srow[j];
-      if (v != v) continue;  // NaN never selected
-      const bool after_last = (lastj < 0) || before(lastv, lastj, v, j);
-      if (after_last && before(v, j, bv, bj)) { bv = v; bj = j; }
+constexpr int TK_P = 2048;           // sort size
+constexpr int TK_KMAX = 128;
+constexpr int TK_CAP = TK_P - TK_KMAX;  // candidate slots
+constexpr int TK_WIN = 8;            // 1024-column steps per window
+
+struct TopkArgs {
+  const float* S;  // [rows][ld]
+  int rows, cols;
+  long long ld;
+  long long col_offset;  // global column index of S[:, 0]
+  int k;
+  float* vals;     // [rows][k]
+  int64_t* idx;    // [rows][k]
+  int first;       // 1: start from an empty state
+};
+
+__device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cnt, int tid) {
+  // sort the first TK_P slots (state [0,k) + candidates [k, k+cnt) + padding) best-first
+  for (int i = k + cnt + tid; i < TK_P; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
+  __syncthreads();
+  for (int size = 2; size <= TK_P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < TK_P / 2; t += 256) {
+        const int lo = (t / stride) * 2 * stride + (t % stride), hi = lo + stride;
+        const bool up = (lo & size) == 0;  // this block sorts best-first
+        const float a = sv[lo], b = sv[hi];
+        const long long ia = si[lo], ib = si[hi];
+        const bool swap = up ? tk_before(b, ib, a, ia) : tk_before(a, ia, b, ib);
+        if (swap) { sv[lo] = b; sv[hi] = a; si[lo] = ib; si[hi] = ia; }
+      }
+      __syncthreads();
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
+  __shared__ float sv[TK_P];
+  __shared__ long long si[TK_P];
+  __shared__ int s_cnt, s_win;
+  const int row = blockIdx.x, tid = threadIdx.x, k = p.k;
+  const float* Srow = p.S + (size_t)row * p.ld;
+  for (int i = tid; i < k; i += 256) {
+    sv[i] = p.first ? -INFINITY : p.vals[(size_t)row * k + i];
+    si[i] = p.first ? 0x7fffffffffffffffLL : (long long)p.idx[(size_t)row * k + i];
+  }
+  if (tid == 0) { s_cnt = 0; s_win = 0; }
+  __syncthreads();
+  float tv = sv[k - 1];
+  long long ti = si[k - 1];
+  const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.S) & 15) == 0);
+  for (int base = 0; base < p.cols; base += TK_WIN * 1024) {
+    float v[TK_WIN][4];
+    int mine = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float v2 = __shfl_xor(bv, o, 64);
-      const int j2 = __shfl_xor(bj, o, 64);
-      if (before(v2, j2, bv, bj)) { bv = v2; bj = j2; }
+    for (int w = 0; w < TK_WIN; ++w) {
+      const int j = base + w * 1024 + tid * 4;
+      if (vec && j + 3 < p.cols) {
+        const float4 x = *reinterpret_cast<const float4*>(Srow + j);
+        v[w][0] = x.x; v[w][1] = x.y; v[w][2] = x.z; v[w][3] = x.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[w][e] = (j + e < p.cols) ? Srow[j + e] : NAN;  // NaN never qualifies
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mine += tk_before(v[w][e], p.col_offset + j + e, tv, ti) ? 1 : 0;
     }
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; sj[threadIdx.x >> 6] = bj; }
+    if (mine) atomicAdd(&s_win, mine);
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float v = sv[0]; int j = sj[0];
-      for (int w = 1; w < 4; ++w) if (before(sv[w], sj[w], v, j)) { v = sv[w]; j = sj[w]; }
-      pv = v; pj = j;
-      values[(size_t)row * k + r] = v;
-      indices[(size_t)row * k + r] = (j == 0x7fffffff) ? -1 : (int64_t)j;
+    const int win = s_win, cnt0 = s_cnt;
+    __syncthreads();
+    if (tid == 0) s_win = 0;
+    if (win == 0) continue;  // (uniform) the common case once the threshold has risen
+    if (cnt0 + win <= TK_CAP) {
+#pragma unroll
+      for (int w = 0; w < TK_WIN; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const long long gj = p.col_offset + base + w * 1024 + tid * 4 + e;
+          if (tk_before(v[w][e], gj, tv, ti)) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            sv[k + pos] = v[w][e];
+            si[k + pos] = gj;
+          }
+        }
+      __syncthreads();
+      if (s_cnt > TK_CAP / 2) {  // uniform
+        tk_flush(sv, si, k, s_cnt, tid);
+        if (tid == 0) s_cnt = 0;
+        tv = sv[k - 1];
+        ti = si[k - 1];
+        __syncthreads();
+      }
+    } else {
+      // too many qualifiers for the buffer: fold step by step (<= 1024 appended per step), flushing as needed
+#pragma unroll
+      for (int w = 0; w < TK_WIN; ++w) {
+        if (s_cnt > TK_CAP - 1024) {  // uniform (read after a barrier)
+          tk_flush(sv, si, k, s_cnt, tid);
+          if (tid == 0) s_cnt = 0;
+          tv = sv[k - 1];
+          ti = si[k - 1];
+          __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const long long gj = p.col_offset + base + w * 1024 + tid * 4 + e;
+          if (tk_before(v[w][e], gj, tv, ti)) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            sv[k + pos] = v[w][e];
+            si[k + pos] = gj;
+          }
+        }
+        __syncthreads();
+      }
     }
-    __syncthreads();
-    lastv = pv; lastj = pj;
-    __syncthreads();
+  }
+  if (s_cnt > 0) tk_flush(sv, si, k, s_cnt, tid);
+  __syncthreads();
+  for (int i = tid; i < k; i += 256) {
+    p.vals[(size_t)row * k + i] = sv[i];
+    p.idx[(size_t)row * k + i] = si[i] == 0x7fffffffffffffffLL ? -1 : (int64_t)si[i];
   }
 }
 

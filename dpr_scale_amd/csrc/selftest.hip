@@ -229,6 +229,22 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
       for (int r = 0; r < k; ++r) bad += (idx[(size_t)i * k + r] != ord[r]) || (v[(size_t)i * k + r] != row[ord[r]]);
     }
     report("topk mismatches", bad, 0);
+    // the same columns folded in three ragged pieces must give the same state
+    Dev<float> dv2((size_t)B * k);
+    Dev<int64_t> di2((size_t)B * k);
+    const int cut1 = Nc / 3, cut2 = Nc / 3 + Nc / 2;
+    const int cuts[4] = {0, cut1, cut2 < Nc ? cut2 : Nc, Nc};
+    bool first = true;
+    for (int c = 0; c < 3; ++c) {
+      if (cuts[c + 1] == cuts[c]) continue;
+      OK(dprhot_topk_update(dS.p + cuts[c], B, cuts[c + 1] - cuts[c], Nc, cuts[c], k, dv2.p, di2.p, first, nullptr));
+      first = false;
+    }
+    CK(hipDeviceSynchronize());
+    auto v2 = dv2.down(); auto i2 = di2.down();
+    int bad2 = 0;
+    for (size_t e = 0; e < (size_t)B * k; ++e) bad2 += (v2[e] != v[e]) || (i2[e] != idx[e]);
+    report("topk streamed mismatches", bad2, 0);
   }
   // ---- fused entry points agree with the pieces ----
   {
@@ -312,6 +328,67 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
   }
 }
 
+// dprhot_search against a host top-k of the full score matrix (scores from dprhot_sim_fwd: the test is about the
+// selection, score values are checked in run_case)
+static void search_case(int nq, int n, int d, int k, int chunk, bool quantise, bool timing) {
+  printf("search nq=%d n=%d d=%d k=%d chunk=%d%s\n", nq, n, d, k, chunk, quantise ? " (quantised: many ties)" : "");
+  std::vector<uint16_t> hq((size_t)nq * d), hc((size_t)n * d);
+  for (auto& x : hq) x = f2bf(quantise ? (float)(int)(urand() * 3 - 1) : nrand());
+  for (auto& x : hc) x = f2bf(quantise ? (float)(int)(urand() * 3 - 1) : nrand());
+  Dev<uint16_t> dq(hq.size()), dc(hc.size());
+  dq.up(hq); dc.up(hc);
+  Dev<float> dS((size_t)nq * n), dv((size_t)nq * k), ws((size_t)nq * chunk);
+  Dev<int64_t> di((size_t)nq * k);
+  OK(dprhot_sim_fwd(dq.p, nq, dc.p, n, d, nullptr, 1.0f, dS.p, nullptr));
+  OK(dprhot_search(dq.p, nq, dc.p, n, d, 1000, k, chunk, dv.p, di.p, 1, ws.p, ws.n * sizeof(float), nullptr));
+  CK(hipDeviceSynchronize());
+  auto S = dS.down(); auto v = dv.down(); auto idx = di.down();
+  int bad = 0;
+  std::vector<int> ord(n);
+  for (int i = 0; i < nq; ++i) {
+    for (int j = 0; j < n; ++j) ord[j] = j;
+    const float* row = &S[(size_t)i * n];
+    std::partial_sort(ord.begin(), ord.begin() + k, ord.end(),
+                      [&](int a, int b) { return row[a] > row[b] || (row[a] == row[b] && a < b); });
+    for (int r = 0; r < k; ++r) bad += (idx[(size_t)i * k + r] != 1000 + ord[r]) || (v[(size_t)i * k + r] != row[ord[r]]);
+  }
+  report("search top-k mismatches", bad, 0);
+  if (timing) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) OK(dprhot_search(dq.p, nq, dc.p, n, d, 0, k, chunk, dv.p, di.p, 1, ws.p, ws.n * sizeof(float), nullptr));
+    CK(hipEventRecord(e0, nullptr));
+    const int it = 5;
+    for (int w = 0; w < it; ++w) OK(dprhot_search(dq.p, nq, dc.p, n, d, 0, k, chunk, dv.p, di.p, 1, ws.p, ws.n * sizeof(float), nullptr));
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= it;
+    printf("    search: %.3f ms  (%.1f TFLOP/s scoring, %.2f M query-passage scores/us)\n", ms, 2.0 * nq * n * d / ms * 1e-9,
+           (double)nq * n / ms * 1e-9);
+    // the pieces
+    CK(hipEventRecord(e0, nullptr));
+    for (int w = 0; w < it; ++w) OK(dprhot_sim_fwd(dq.p, nq, dc.p, chunk, d, nullptr, 1.0f, ws.p, nullptr));
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("    one chunk: sim %.1f us", ms / it * 1e3);
+    CK(hipEventRecord(e0, nullptr));
+    for (int w = 0; w < it; ++w) OK(dprhot_topk_update(ws.p, nq, chunk, chunk, 0, k, dv.p, di.p, 1, nullptr));
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf(", top-k from empty %.1f us", ms / it * 1e3);
+    CK(hipEventRecord(e0, nullptr));
+    for (int w = 0; w < it; ++w) OK(dprhot_topk_update(ws.p, nq, chunk, chunk, chunk, k, dv.p, di.p, 0, nullptr));
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf(", top-k warm %.1f us (%.0f GB/s)\n", ms / it * 1e3, (double)nq * chunk * 4 / (ms / it) * 1e-6);
+  }
+}
+
 int main(int argc, char** argv) {
   const bool timing = argc > 1 && strstr(argv[1], "time");
   const bool big = argc > 1 && strstr(argv[1], "big");
@@ -339,6 +416,10 @@ int main(int argc, char** argv) {
   run_case(32, 2112, 768, 66, 1.0f, true, timing);   // cfg2 per rank at W=8 incl. the mask rows (two chunks per thread)
   run_case(16, 4096, 128, 256, 2.0f, true, false);
   if (timing || big) run_case(128, 8192, 768, 8, 1.0f, true, timing);
+  search_case(16, 5000 / 8 * 8, 64, 10, 1024, true, false);
+  search_case(40, 30000, 128, 100, 8192, false, false);
+  search_case(3, 20000, 768, 128, 4096, true, false);
+  if (timing || big) search_case(1024, 1 << 20, 768, 100, 65536, false, timing);
   printf(g_fail ? "SELFTEST FAILED (%d)\n" : "SELFTEST PASSED\n", g_fail);
   return g_fail ? 1 : 0;
 }

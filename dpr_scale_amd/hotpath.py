@@ -216,6 +216,20 @@ class HipKernels:
         self._lib.check(self.lib.dprhot_topk(_ptr(S), rows, cols, k, _ptr(v), _ptr(i), self._stream()), "dprhot_topk")
         return v, i
 
+    def topk_update(self, S, cols, col_offset, values, indices, first):
+        self._require_gpu(S, values, indices)
+        rows, k = values.shape
+        self._lib.check(self.lib.dprhot_topk_update(_ptr(S), rows, int(cols), S.stride(0), int(col_offset), k, _ptr(values),
+                                                    _ptr(indices), int(bool(first)), self._stream()), "dprhot_topk_update")
+
+    def search(self, Qb, Cb, id_offset, values, indices, first, chunk, ws):
+        self._require_gpu(Qb, Cb, values, indices, ws)
+        nq, d = Qb.shape
+        k = values.shape[1]
+        self._lib.check(self.lib.dprhot_search(_ptr(Qb), nq, _ptr(Cb), Cb.shape[0], d, int(id_offset), k, int(chunk),
+                                               _ptr(values), _ptr(indices), int(bool(first)), _ptr(ws), ws.numel(),
+                                               self._stream()), "dprhot_search")
+
 
 _DEFAULT = None
 
@@ -416,3 +430,49 @@ def rank_of_gold(S, labels, kernels=None):
 def topk(S, k, kernels=None):
     kn = kernels if kernels is not None else default_kernels()
     return kn.topk(S.contiguous(), k)
+
+
+class CorpusSearch:
+    """search_index of run_retrieval_pytorch.py:141-166 plus its shard loop (:196-243) and re-merge (:272-277):
+
+        s = CorpusSearch(query_embs, topk)      # [nq, d] fp32/bf16 on the GPU
+        for shard, first_id in shards:          # each [n, d] corpus shard resident on the GPU, any n
+            s.add(shard, first_id)
+        scores, ids = s.result()                # [nq, topk] fp32 / int64, best first, ties by lower id
+
+    The [nq, n] score matrix never exists: each `chunk` of passages is scored on the bf16 MFMA path and folded
+    into the running top-k on the device (dprhot_search)."""
+
+    def __init__(self, query_embs, k, chunk=None, kernels=None):
+        self.kn = kernels if kernels is not None else default_kernels()
+        nq, d = query_embs.shape
+        self.Qb = self.kn.empty((nq, d), _BF16, query_embs)
+        self.kn.cast_bf16(query_embs, self.Qb)
+        if chunk is None:  # keep the score chunk around 256 MiB
+            chunk = max(1024, min(65536, (1 << 26) // max(nq, 1) // 8 * 8))
+        self.chunk = int(chunk) // 8 * 8
+        self.values = torch.empty((nq, k), dtype=torch.float32, device=query_embs.device)
+        self.indices = torch.empty((nq, k), dtype=torch.int64, device=query_embs.device)
+        self.ws = torch.empty(nq * self.chunk * 4, dtype=torch.uint8, device=query_embs.device)
+        self.first = True
+
+    def add(self, corpus_embs, first_id=0):
+        n, d = corpus_embs.shape
+        if corpus_embs.dtype == _BF16 and corpus_embs.is_contiguous():
+            Cb = corpus_embs
+        else:
+            Cb = self.kn.empty((n, d), _BF16, corpus_embs)
+            self.kn.cast_bf16(corpus_embs, Cb)
+        n8 = n // 8 * 8
+        if n8:
+            self.kn.search(self.Qb, Cb[:n8], first_id, self.values, self.indices, self.first, self.chunk, self.ws)
+            self.first = False
+        if n8 != n:  # ragged tail: 8 padded rows, only the real columns are scanned
+            tail = torch.zeros((8, d), dtype=_BF16, device=Cb.device)
+            tail[: n - n8].copy_(Cb[n8:])
+            S = self.kn.sim(self.Qb, tail, None, 1.0)
+            self.kn.topk_update(S, n - n8, first_id + n8, self.values, self.indices, self.first)
+            self.first = False
+
+    def result(self):
+        return self.values, self.indices

@@ -157,8 +157,26 @@ int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprh
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
- * their column indices, descending, ties by lower column index.  k <= 128. */
+ * their column indices, descending, ties by lower column index.  k <= 128, k <= cols. */
 int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream);
+
+/* The same as a streaming update, for a corpus that is scored in pieces (the shard loop of
+ * run_retrieval_pytorch.py:196-243 and its "sort the score again if shard > 1" re-merge at :272-277):
+ * folds the scores S[rows][0..cols) (row stride ld, global column index = col_offset + j) into the running
+ * per-row top-k state values/indices [rows,k] (sorted; total order score desc, column asc).  first != 0 starts
+ * from an empty state (slots not yet filled hold -inf / -1).  The result after any sequence of updates equals
+ * dprhot_topk of the concatenated score matrix. */
+int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values,
+                       int64_t* indices, int first, void* stream);
+
+/* search_index (run_retrieval_pytorch.py:141-166) for one resident corpus shard: scores = Q x C^T on bf16 MFMA
+ * (fp32 scores; the reference scores in fp16), chunk columns at a time, each chunk folded into the running
+ * top-k -- the [nq, n_ctx] score matrix never exists.  Q [nq,d], C [n_ctx,d] bf16; passage ids are
+ * id_offset + row.  n_ctx and chunk multiples of 8 (a ragged tail goes through sim_fwd + topk_update with
+ * cols < ld).  workspace >= nq*chunk*4 bytes.  first as in dprhot_topk_update. */
+int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_ctx, int d, int64_t id_offset,
+                  int k, int chunk, float* values, int64_t* indices, int first, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

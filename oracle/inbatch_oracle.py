@@ -144,6 +144,30 @@ def topk_stable(S, k):
     return np.take_along_axis(S, idx, axis=1), idx.astype(np.int64)
 
 
+def topk_merge(state, S, col_offset, k):
+    """The shard loop of run_retrieval_pytorch.py:196-243 with the re-merge of :272-277 restated as a fold:
+    state = (values [rows,k], ids [rows,k]) of everything scored so far (or None), S = scores of the next
+    piece whose columns carry the ids col_offset + j.  Same frozen order (score desc, id asc); unfilled slots
+    are (-inf, -1).  Folding pieces in increasing id order equals topk_stable of the concatenation."""
+    S = np.asarray(S, dtype=np.float32)
+    rows = S.shape[0]
+    ids = np.broadcast_to(col_offset + np.arange(S.shape[1], dtype=np.int64), S.shape)
+    if state is not None:
+        v0, i0 = state
+        keep = np.asarray(i0) >= 0
+        S = np.concatenate([np.where(keep, v0, -np.inf).astype(np.float32), S], axis=1)
+        ids = np.concatenate([np.where(keep, i0, np.iinfo(np.int64).max), ids], axis=1)
+    order = np.lexsort((ids, -S), axis=1)[:, :k]  # primary key -S (desc score), secondary id asc
+    v = np.take_along_axis(S, order, axis=1)
+    i = np.take_along_axis(ids, order, axis=1)
+    if v.shape[1] < k:
+        pad = k - v.shape[1]
+        v = np.concatenate([v, np.full((rows, pad), -np.inf, np.float32)], axis=1)
+        i = np.concatenate([i, np.full((rows, pad), -1, np.int64)], axis=1)
+    i = np.where(i == np.iinfo(np.int64).max, -1, i)
+    return v.astype(np.float32), i.astype(np.int64)
+
+
 def non_inbatch_query_ctx_mask(pos_idx, ctx_mask, n_queries):
     """dpr_task.py:198-207 -- in_batch_negatives=False: query i sees only its own K contexts."""
     m = np.asarray(ctx_mask, dtype=bool)

@@ -84,3 +84,14 @@ class OracleKernels:
     def topk(self, S, k):
         v, i = O.topk_stable(S.numpy(), k)
         return torch.from_numpy(v), torch.from_numpy(i)
+
+    def topk_update(self, S, cols, col_offset, values, indices, first):
+        v, i = O.topk_merge(None if first else (values.numpy(), indices.numpy()), S.numpy()[:, :cols], col_offset,
+                            values.shape[1])
+        values.copy_(torch.from_numpy(v))
+        indices.copy_(torch.from_numpy(i))
+
+    def search(self, Qb, Cb, id_offset, values, indices, first, chunk, ws):
+        for j0 in range(0, Cb.shape[0], chunk):
+            S = self.sim(Qb, Cb[j0:j0 + chunk])
+            self.topk_update(S, S.shape[1], id_offset + j0, values, indices, first and j0 == 0)

@@ -210,6 +210,71 @@ def test_tie_rule_bit_exact(dev):
     assert np.array_equal(v.cpu().numpy(), g["topk_values"])
 
 
+@pytest.mark.parametrize("rows,cols,k,levels", [(5, 1000, 10, 4), (3, 70000, 100, 0), (64, 9000, 128, 50), (2, 3, 3, 2),
+                                               (4, 20000, 1, 0)])
+def test_streaming_topk_equals_stable_sort_prefix(rows, cols, k, levels, kn, dev):
+    """torch.topk of run_retrieval_pytorch.py:149-150 under the frozen tie rule, in one piece and folded over pieces
+    (the shard re-merge of :272-277); indices bit-exact."""
+    g = torch.Generator().manual_seed(cols)
+    S = (torch.randint(0, levels, (rows, cols), generator=g).float() if levels else torch.randn(rows, cols, generator=g)).to(dev)
+    if cols > 100:
+        S[:, 17] = float("-inf")
+    order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
+    v, i = kn.topk(S, k)
+    assert torch.equal(i, order) and torch.equal(v, S.gather(1, order))
+    v2 = torch.empty_like(v)
+    i2 = torch.empty_like(i)
+    edges = [0, cols // 5, cols // 5 + 1, cols // 2, cols]
+    first = True
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b > a:
+            kn.topk_update(S[:, a:], b - a, 7 + a, v2, i2, first)
+            first = False
+    assert torch.equal(i2, order + 7) and torch.equal(v2, v)
+    # against the oracle fold as well (small cases)
+    if rows * cols <= 100000:
+        st = None
+        for a, b in zip(edges[:-1], edges[1:]):
+            if b > a:
+                st = O.topk_merge(st, S[:, a:b].cpu().numpy(), 7 + a, k)
+        assert np.array_equal(st[1], i2.cpu().numpy()) and np.array_equal(st[0], v2.cpu().numpy())
+
+
+def test_topk_state_with_fewer_columns_than_k(kn, dev):
+    S = torch.tensor([[1.0, 3.0, 2.0, 3.0]], device=dev)
+    v = torch.empty((1, 6), device=dev)
+    i = torch.empty((1, 6), dtype=torch.int64, device=dev)
+    kn.topk_update(S, 4, 10, v, i, True)
+    assert i.tolist() == [[11, 13, 12, 10, -1, -1]] and v[0, :4].tolist() == [3.0, 3.0, 2.0, 1.0]
+    assert torch.isneginf(v[0, 4:]).all()
+    kn.topk_update(torch.tensor([[5.0, 0.0, 3.0, 1.0]], device=dev), 3, 0, v, i, False)  # 4th column not scanned
+    assert i.tolist() == [[0, 2, 11, 13, 12, 10]]
+
+
+@pytest.mark.parametrize("nq,shards,d,k,chunk", [(9, (4000, 13, 8, 2051), 64, 20, 1024), (130, (50000,), 768, 100, 8192)])
+def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk, kn, dev):
+    """search_index + shard loop (run_retrieval_pytorch.py:141-166, :196-243, :272-277): ids bit-exact against
+    the stable top-k of the full score matrix computed by the same similarity kernel; scores against fp32 torch."""
+    from dpr_scale_amd.hotpath import CorpusSearch, sim_score
+
+    g = torch.Generator().manual_seed(nq)
+    q = torch.randn(nq, d, generator=g).to(dev)
+    parts = [torch.randn(n, d, generator=g).to(dev) for n in shards]
+    parts[0][100:140] = parts[0][60:100]  # duplicated passages: exact score ties
+    s = CorpusSearch(q, k, chunk=chunk, kernels=kn)
+    first = 0
+    for p in parts:
+        s.add(p.to(torch.bfloat16) if first == 0 else p, first)  # bf16-resident and fp32 shards
+        first += p.shape[0]
+    v, i = s.result()
+    C = torch.cat(parts)
+    S = sim_score(q, C, kernels=kn)
+    order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
+    assert torch.equal(i, order) and torch.equal(v, S.gather(1, order))
+    ref = q.to(torch.bfloat16).float() @ C.to(torch.bfloat16).float().T
+    assert (v - ref.gather(1, i)).abs().max().item() <= 1e-3 * ref.abs().max().item()
+
+
 def test_non_inbatch_window_branch(kn, dev):
     """in_batch_negatives=False (dpr_task.py:198-207): row i sees only its own K columns."""
     meta, g = load_golden("nib")

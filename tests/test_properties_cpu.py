@@ -43,6 +43,44 @@ def test_rank_of_gold_is_position_in_stable_descending_sort(rows, cols, levels, 
     assert np.array_equal(idx, order[:, :k])
 
 
+@settings(max_examples=50, deadline=None)
+@given(rows=st.integers(1, 5), cols=st.integers(1, 60), k=st.integers(1, 12), levels=st.integers(1, 6),
+       cuts=st.lists(st.integers(0, 60), max_size=4), seed=st.integers(0, 10_000))
+def test_topk_fold_over_pieces_equals_topk_of_the_concatenation(rows, cols, k, levels, cuts, seed):
+    """run_retrieval_pytorch.py:196-243 + :272-277 as a fold (oracle.topk_merge): any split into pieces, many ties."""
+    rng = np.random.default_rng(seed)
+    S = rng.integers(0, levels, (rows, cols)).astype(np.float32)
+    S[rng.random(S.shape) < 0.1] = -np.inf
+    edges = sorted({0, cols, *[c for c in cuts if c < cols]})
+    state = None
+    for a, b in zip(edges[:-1], edges[1:]):
+        state = O.topk_merge(state, S[:, a:b], 100 + a, k)
+    kk = min(k, cols)
+    v, i = O.topk_stable(S, kk)
+    assert np.array_equal(state[0][:, :kk], v) and np.array_equal(state[1][:, :kk], i + 100)
+    assert np.all(state[1][:, kk:] == -1) and np.all(np.isneginf(state[0][:, kk:]))
+
+
+def test_corpus_search_host_logic_with_ragged_shards():
+    """CorpusSearch (host side of dprhot_search): shards of any length, id offsets, chunking -- against one big top-k."""
+    import torch
+    from _oracle_kernels import OracleKernels
+    from dpr_scale_amd.hotpath import CorpusSearch
+
+    rng = np.random.default_rng(5)
+    q = torch.from_numpy(rng.integers(-2, 3, (7, 16)).astype(np.float32))
+    shards = [torch.from_numpy(rng.integers(-2, 3, (n, 16)).astype(np.float32)) for n in (37, 8, 5, 120)]
+    s = CorpusSearch(q, 9, chunk=16, kernels=OracleKernels())
+    first = 0
+    for sh in shards:
+        s.add(sh, first)
+        first += sh.shape[0]
+    v, i = s.result()
+    S = (q.double() @ torch.cat(shards).double().T).float().numpy()
+    wv, wi = O.topk_stable(S, 9)
+    assert np.array_equal(i.numpy(), wi) and np.array_equal(v.numpy(), wv)
+
+
 @settings(max_examples=100, deadline=None)
 @given(st.floats(allow_nan=False, allow_infinity=False, width=32))
 def test_bf16_round_is_nearest_even(x):
