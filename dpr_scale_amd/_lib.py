@@ -41,6 +41,7 @@ SIGNATURES = {
     "dprhot_rank_of_gold": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "dprhot_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dprhot_topk_update": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dprhot_search_workspace_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "dprhot_search": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
                               c_void_p, c_size_t, c_void_p]),
     "dprhot_inbatch_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
@@ -77,6 +78,12 @@ def check(rc: int, what: str = ""):
 
 def version() -> int:
     return lib.dprhot_version()
+
+
+def search_workspace_bytes(nq, chunk):
+    out = c_size_t(0)
+    check(lib.dprhot_search_workspace_bytes(int(nq), int(chunk), ctypes.byref(out)), "dprhot_search_workspace_bytes")
+    return out.value
 
 
 def packed_rows(n_ctx: int, d: int) -> int:

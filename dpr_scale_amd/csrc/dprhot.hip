@@ -444,7 +444,7 @@ int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t c
   REQUIRE(rows > 0 && cols > 0 && ld >= cols && k > 0 && k <= TK_KMAX, "bad shape rows=%d cols=%d ld=%lld k=%d", rows, cols,
           (long long)ld, k);
   REQUIRE(col_offset >= 0, "negative col_offset");
-  TopkArgs p{S, rows, cols, (long long)ld, (long long)col_offset, k, values, indices, first ? 1 : 0};
+  TopkArgs p{S, rows, cols, (long long)ld, (long long)col_offset, k, values, indices, first ? 1 : 0, nullptr, nullptr};
   hipLaunchKernelGGL(topk_stream_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
@@ -455,23 +455,55 @@ int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_
   return dprhot_topk_update(S, rows, cols, cols, 0, k, values, indices, 1, stream);
 }
 
+// workspace of dprhot_search: [nq x chunk] fp32 (scores of the first chunk / candidate values) + [nq x chunk] int32
+// (candidate columns) + [nq] int32 (candidate counts)
+static size_t search_ws_bytes(int nq, int chunk) {
+  return (size_t)nq * (size_t)chunk * 8 + ((size_t)nq * 4 + 255) / 256 * 256;
+}
+
+int dprhot_search_workspace_bytes(int nq, int chunk, size_t* h_out) {
+  REQUIRE(h_out != nullptr, "NULL out pointer");
+  REQUIRE(nq > 0 && chunk > 0 && chunk % 8 == 0, "bad shape nq=%d chunk=%d", nq, chunk);
+  *h_out = search_ws_bytes(nq, chunk);
+  return DPRHOT_OK;
+}
+
 int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_ctx, int d, int64_t id_offset, int k, int chunk,
                   float* values, int64_t* indices, int first, void* workspace, size_t workspace_bytes, void* stream) {
   REQUIRE(Q && C && values && indices, "NULL pointer");
   REQUIRE(nq > 0 && n_ctx > 0 && d > 0 && d % 8 == 0, "bad shape nq=%d n_ctx=%lld d=%d", nq, (long long)n_ctx, d);
   REQUIRE(n_ctx % 8 == 0 && chunk > 0 && chunk % 8 == 0, "n_ctx=%lld and chunk=%d must be multiples of 8", (long long)n_ctx, chunk);
   REQUIRE(k > 0 && k <= TK_KMAX, "k=%d out of range (1..%d)", k, TK_KMAX);
+  REQUIRE(id_offset >= 0, "negative id_offset");
   REQUIRE(aligned16(Q) && aligned16(C), "pointers must be 16-byte aligned");
-  const size_t need = (size_t)nq * (size_t)chunk * sizeof(float);
+  const size_t need = search_ws_bytes(nq, chunk);
   if (workspace == nullptr || workspace_bytes < need)
-    return fail(DPRHOT_E_WORKSPACE, "search needs %zu workspace bytes (nq x chunk fp32 scores), got %zu", need, workspace_bytes);
+    return fail(DPRHOT_E_WORKSPACE, "search needs %zu workspace bytes (dprhot_search_workspace_bytes), got %zu", need, workspace_bytes);
   REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
   float* S = static_cast<float*>(workspace);
+  int* cand_j = reinterpret_cast<int*>(static_cast<char*>(workspace) + (size_t)nq * chunk * 4);
+  int* cnt = reinterpret_cast<int*>(static_cast<char*>(workspace) + (size_t)nq * chunk * 8);
+  static const bool unfused = getenv("DPRHOT_SEARCH_UNFUSED") != nullptr;
+  HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(int), st));
   for (int64_t j0 = 0; j0 < n_ctx; j0 += chunk) {
     const int cols = (int)((n_ctx - j0 < chunk) ? (n_ctx - j0) : chunk);
-    if (int rc = dprhot_sim_fwd(Q, nq, C + (size_t)j0 * d, cols, d, nullptr, 1.0f, S, stream)) return rc;
-    if (int rc = dprhot_topk_update(S, nq, cols, cols, id_offset + j0, k, values, indices, (first && j0 == 0) ? 1 : 0, stream))
-      return rc;
+    const dprhot_bf16* Cj = C + (size_t)j0 * d;
+    if ((first && j0 == 0) || unfused) {
+      // nothing to filter against yet: materialise this chunk's scores and select from them
+      if (int rc = dprhot_sim_fwd(Q, nq, Cj, cols, d, nullptr, 1.0f, S, stream)) return rc;
+      if (int rc = dprhot_topk_update(S, nq, cols, cols, id_offset + j0, k, values, indices, (first && j0 == 0) ? 1 : 0, stream))
+        return rc;
+      continue;
+    }
+    // scores that cannot enter the top-k never leave the GEMM tile
+    const int tile = pick_tile(nq, cols, d, 1, 2 * kNumCU);
+    GemmArgs a{Q, Cj, nq, cols, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
+    EpiFilter epi{values, indices, k, nq, cols, (long long)(id_offset + j0), cnt, S, cand_j};
+    if (int rc = launch_gemm<true, true>(tile, a, epi, 1, st)) return rc;
+    TopkArgs p{S, nq, cols, (long long)cols, (long long)(id_offset + j0), k, values, indices, 0, cand_j, cnt};
+    hipLaunchKernelGGL(topk_stream_kernel, dim3(nq), dim3(256), 0, st, p);
+    HIP_TRY(hipGetLastError());
   }
   return DPRHOT_OK;
 }

@@ -531,6 +531,68 @@ struct EpiSim {
   }
 };
 
+// Retrieval epilogue (run_retrieval_pytorch.py:149-150 without the score matrix): a score only leaves the tile when it
+// ranks ahead of the row's current k-th best (score desc, passage id asc); such scores are appended to the row's
+// candidate list (value + local column), which the top-k merge kernel folds into the state.  Once a few chunks have
+// been seen almost nothing qualifies, so the GEMM writes next to nothing.
+struct EpiFilter {
+  const float* kth_val;     // state values  [M][k]
+  const int64_t* kth_idx;   // state ids     [M][k]  (-1: slot unfilled)
+  int k;
+  int M, N;
+  long long col_offset;     // passage id of column 0
+  int* cnt;                 // [M] candidates appended so far (the merge kernel resets it)
+  float* cand_v;            // [M][N]
+  int* cand_j;              // [M][N]
+
+  template <int TM, int TN>
+  struct Raw {
+    float tv[TM][4];
+    int64_t ti[TM][4];
+  };
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ Raw<TM, TN> begin(const TileCtx& c) const {
+    const int g = c.lane >> 4;
+    Raw<TM, TN> st;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = min(c.m0 + c.wm * (BM / WM) + a * 16 + g * 4 + r, M - 1);
+        st.tv[a][r] = kth_val[(size_t)m * k + k - 1];
+        st.ti[a][r] = kth_idx[(size_t)m * k + k - 1];
+      }
+    return st;
+  }
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ Raw<TM, TN> settle(const TileCtx&, const Raw<TM, TN>& raw) const {
+    return raw;
+  }
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, const Raw<TM, TN>& st) const {
+    const int i = c.lane & 15, g = c.lane >> 4;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = c.m0 + c.wm * (BM / WM) + a * 16 + g * 4 + r;
+        if (m >= M) continue;
+        const float tv = st.tv[a][r];
+        const long long ti = st.ti[a][r] < 0 ? 0x7fffffffffffffffLL : (long long)st.ti[a][r];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int n = c.n0 + c.wn * (BN / WN) + b * 16 + i;
+          const float v = acc[a][b][r];
+          if (n < N && (v > tv || (v == tv && col_offset + n < ti))) {
+            const int pos = atomicAdd(&cnt[m], 1);
+            cand_v[(size_t)m * N + pos] = v;
+            cand_j[(size_t)m * N + pos] = n;
+          }
+        }
+      }
+  }
+};
+
 // fp32 store with a scale that may live on the device (autograd grad_output); bz selects a split-K slab
 struct EpiScaleF32 {
   float* out;  // [splits][M][N]

@@ -631,15 +631,21 @@ struct TopkArgs {
   float* vals;     // [rows][k]
   int64_t* idx;    // [rows][k]
   int first;       // 1: start from an empty state
+  // candidate-list mode (EpiFilter output): S[row][0..cnt[row]) are scores whose columns are cand_j[row][..];
+  // cnt[row] is reset to 0 for the next chunk
+  const int* cand_j;
+  int* cnt;
 };
 
 __device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cnt, int tid) {
-  // sort the first TK_P slots (state [0,k) + candidates [k, k+cnt) + padding) best-first
-  for (int i = k + cnt + tid; i < TK_P; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
+  // sort state [0,k) + candidates [k, k+cnt) (padded to a power of two P) best-first
+  int P = 64;
+  while (P < k + cnt) P <<= 1;
+  for (int i = k + cnt + tid; i < P; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
   __syncthreads();
-  for (int size = 2; size <= TK_P; size <<= 1) {
+  for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < TK_P / 2; t += 256) {
+      for (int t = tid; t < P / 2; t += 256) {
         const int lo = (t / stride) * 2 * stride + (t % stride), hi = lo + stride;
         const bool up = (lo & size) == 0;  // this block sorts best-first
         const float a = sv[lo], b = sv[hi];
@@ -658,30 +664,47 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
   __shared__ int s_cnt, s_win;
   const int row = blockIdx.x, tid = threadIdx.x, k = p.k;
   const float* Srow = p.S + (size_t)row * p.ld;
+  const int* Jrow = p.cand_j != nullptr ? p.cand_j + (size_t)row * p.ld : nullptr;
+  const int ncols = p.cnt != nullptr ? p.cnt[row] : p.cols;
+  if (p.cnt != nullptr && ncols == 0) return;  // (uniform) nothing qualified for this row in this chunk
   for (int i = tid; i < k; i += 256) {
-    sv[i] = p.first ? -INFINITY : p.vals[(size_t)row * k + i];
-    si[i] = p.first ? 0x7fffffffffffffffLL : (long long)p.idx[(size_t)row * k + i];
+    const long long j = p.first ? -1 : (long long)p.idx[(size_t)row * k + i];
+    sv[i] = (p.first || j < 0) ? -INFINITY : p.vals[(size_t)row * k + i];
+    si[i] = j < 0 ? 0x7fffffffffffffffLL : j;
   }
   if (tid == 0) { s_cnt = 0; s_win = 0; }
   __syncthreads();
+  if (p.cnt != nullptr && tid == 0) p.cnt[row] = 0;
   float tv = sv[k - 1];
   long long ti = si[k - 1];
   const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.S) & 15) == 0);
-  for (int base = 0; base < p.cols; base += TK_WIN * 1024) {
+  for (int base = 0; base < ncols; base += TK_WIN * 1024) {
     float v[TK_WIN][4];
+    int cj[TK_WIN][4];  // column of each value (implicit for a score matrix, loaded for a candidate list)
     int mine = 0;
 #pragma unroll
     for (int w = 0; w < TK_WIN; ++w) {
       const int j = base + w * 1024 + tid * 4;
-      if (vec && j + 3 < p.cols) {
+      if (vec && j + 3 < ncols) {
         const float4 x = *reinterpret_cast<const float4*>(Srow + j);
         v[w][0] = x.x; v[w][1] = x.y; v[w][2] = x.z; v[w][3] = x.w;
+        if (Jrow != nullptr) {
+          const int4 y = *reinterpret_cast<const int4*>(Jrow + j);
+          cj[w][0] = y.x; cj[w][1] = y.y; cj[w][2] = y.z; cj[w][3] = y.w;
+        }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[w][e] = (j + e < p.cols) ? Srow[j + e] : NAN;  // NaN never qualifies
+        for (int e = 0; e < 4; ++e) {
+          v[w][e] = (j + e < ncols) ? Srow[j + e] : NAN;  // NaN never qualifies
+          if (Jrow != nullptr) cj[w][e] = (j + e < ncols) ? Jrow[j + e] : 0;
+        }
+      }
+      if (Jrow == nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cj[w][e] = j + e;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) mine += tk_before(v[w][e], p.col_offset + j + e, tv, ti) ? 1 : 0;
+      for (int e = 0; e < 4; ++e) mine += tk_before(v[w][e], p.col_offset + cj[w][e], tv, ti) ? 1 : 0;
     }
     if (mine) atomicAdd(&s_win, mine);
     __syncthreads();
@@ -694,7 +717,7 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
       for (int w = 0; w < TK_WIN; ++w)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const long long gj = p.col_offset + base + w * 1024 + tid * 4 + e;
+          const long long gj = p.col_offset + cj[w][e];
           if (tk_before(v[w][e], gj, tv, ti)) {
             const int pos = atomicAdd(&s_cnt, 1);
             sv[k + pos] = v[w][e];
@@ -722,7 +745,7 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const long long gj = p.col_offset + base + w * 1024 + tid * 4 + e;
+          const long long gj = p.col_offset + cj[w][e];
           if (tk_before(v[w][e], gj, tv, ti)) {
             const int pos = atomicAdd(&s_cnt, 1);
             sv[k + pos] = v[w][e];

@@ -337,7 +337,9 @@ static void search_case(int nq, int n, int d, int k, int chunk, bool quantise, b
   for (auto& x : hc) x = f2bf(quantise ? (float)(int)(urand() * 3 - 1) : nrand());
   Dev<uint16_t> dq(hq.size()), dc(hc.size());
   dq.up(hq); dc.up(hc);
-  Dev<float> dS((size_t)nq * n), dv((size_t)nq * k), ws((size_t)nq * chunk);
+  size_t wsb = 0;
+  OK(dprhot_search_workspace_bytes(nq, chunk, &wsb));
+  Dev<float> dS((size_t)nq * n), dv((size_t)nq * k), ws(wsb / sizeof(float));
   Dev<int64_t> di((size_t)nq * k);
   OK(dprhot_sim_fwd(dq.p, nq, dc.p, n, d, nullptr, 1.0f, dS.p, nullptr));
   OK(dprhot_search(dq.p, nq, dc.p, n, d, 1000, k, chunk, dv.p, di.p, 1, ws.p, ws.n * sizeof(float), nullptr));

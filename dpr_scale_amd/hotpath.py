@@ -222,6 +222,9 @@ class HipKernels:
         self._lib.check(self.lib.dprhot_topk_update(_ptr(S), rows, int(cols), S.stride(0), int(col_offset), k, _ptr(values),
                                                     _ptr(indices), int(bool(first)), self._stream()), "dprhot_topk_update")
 
+    def search_workspace(self, nq, chunk, like):
+        return torch.empty(self._lib.search_workspace_bytes(nq, chunk), dtype=torch.uint8, device=like.device)
+
     def search(self, Qb, Cb, id_offset, values, indices, first, chunk, ws):
         self._require_gpu(Qb, Cb, values, indices, ws)
         nq, d = Qb.shape
@@ -453,7 +456,7 @@ class CorpusSearch:
         self.chunk = int(chunk) // 8 * 8
         self.values = torch.empty((nq, k), dtype=torch.float32, device=query_embs.device)
         self.indices = torch.empty((nq, k), dtype=torch.int64, device=query_embs.device)
-        self.ws = torch.empty(nq * self.chunk * 4, dtype=torch.uint8, device=query_embs.device)
+        self.ws = self.kn.search_workspace(nq, self.chunk, query_embs)
         self.first = True
 
     def add(self, corpus_embs, first_id=0):

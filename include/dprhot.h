@@ -173,7 +173,11 @@ int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t c
  * (fp32 scores; the reference scores in fp16), chunk columns at a time, each chunk folded into the running
  * top-k -- the [nq, n_ctx] score matrix never exists.  Q [nq,d], C [n_ctx,d] bf16; passage ids are
  * id_offset + row.  n_ctx and chunk multiples of 8 (a ragged tail goes through sim_fwd + topk_update with
- * cols < ld).  workspace >= nq*chunk*4 bytes.  first as in dprhot_topk_update. */
+ * cols < ld).  first as in dprhot_topk_update.  The first chunk of an empty state is scored into the workspace
+ * and selected from; for every later chunk the GEMM epilogue compares each score with the row's current k-th best
+ * and only appends the few that beat it to a candidate list, which a merge kernel folds into the state.
+ * workspace: dprhot_search_workspace_bytes(nq, chunk). */
+int dprhot_search_workspace_bytes(int nq, int chunk, size_t* h_out);
 int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_ctx, int d, int64_t id_offset,
                   int k, int chunk, float* values, int64_t* indices, int first, void* workspace,
                   size_t workspace_bytes, void* stream);

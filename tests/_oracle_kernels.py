@@ -91,6 +91,9 @@ class OracleKernels:
         values.copy_(torch.from_numpy(v))
         indices.copy_(torch.from_numpy(i))
 
+    def search_workspace(self, nq, chunk, like):
+        return torch.empty(0, dtype=torch.uint8)
+
     def search(self, Qb, Cb, id_offset, values, indices, first, chunk, ws):
         for j0 in range(0, Cb.shape[0], chunk):
             S = self.sim(Qb, Cb[j0:j0 + chunk])

@@ -275,6 +275,26 @@ def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk,
     assert (v - ref.gather(1, i)).abs().max().item() <= 1e-3 * ref.abs().max().item()
 
 
+def test_corpus_search_worst_case_order_and_reversed_shards(kn, dev):
+    """Every later passage beats everything seen so far (all scores pass the in-GEMM filter), duplicated passages
+    tie exactly, and the shards arrive in decreasing id order -- the result is still the stable top-k."""
+    from dpr_scale_amd.hotpath import CorpusSearch, sim_score
+
+    d, n, k = 64, 6000, 50
+    q = torch.ones(5, d, device=dev)
+    scale = torch.arange(n, device=dev).float().div(64).floor()  # groups of 64 identical passages, increasing score
+    C = (scale[:, None] * torch.ones(n, d, device=dev) / 64).to(torch.bfloat16)
+    S = sim_score(q, C, kernels=kn)
+    order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
+    for bounds in ([0, 1000, 2048, 6000], [6000, 2048, 1000, 0]):
+        s = CorpusSearch(q, k, chunk=512, kernels=kn)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            lo, hi = min(a, b), max(a, b)
+            s.add(C[lo:hi], lo)
+        v, i = s.result()
+        assert torch.equal(i, order) and torch.equal(v, S.gather(1, order))
+
+
 def test_non_inbatch_window_branch(kn, dev):
     """in_batch_negatives=False (dpr_task.py:198-207): row i sees only its own K columns."""
     meta, g = load_golden("nib")
