@@ -12,7 +12,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include "gemm_bf16.h"
+#include "gemm256.h"
 #include "rowwise.h"
 
 using namespace dprhot;
@@ -72,14 +74,28 @@ constexpr int kNumCU = 256;
 
 // tile configurations {BM, BN, BK}
 struct TileSpec { int bm, bn, bk; };
-constexpr int kNumTiles = 6;
-constexpr TileSpec kTiles[kNumTiles] = {{128, 128, 64}, {64, 128, 64}, {64, 64, 64}, {32, 64, 64}, {32, 64, 256}, {32, 32, 256}};
+constexpr int kNumTiles = 7;  // 0-5: gemm_bf16.h (register staging); 6: gemm256.h (k-major x k-major, K % 64 == 0 only)
+constexpr int kBigTile = 6;
+constexpr TileSpec kTiles[kNumTiles] = {{128, 128, 64}, {64, 128, 64}, {64, 64, 64}, {32, 64, 64}, {32, 64, 256}, {32, 32, 256},
+                                        {256, 256, 64}};
+
+int big_min_wgs() {  // DPRHOT_BIG_MIN: fewest 256x256 tiles for which the large-shape kernel is chosen (0 = never)
+  static const int v = []() {
+    const char* e = getenv("DPRHOT_BIG_MIN");
+    return e ? atoi(e) : 256;
+  }();
+  return v;
+}
+bool big_ok(int M, int N, int K) {
+  const long wgs = (long)((M + 255) / 256) * ((N + 255) / 256);
+  return M > 128 && K % 64 == 0 && K >= 128 && big_min_wgs() > 0 && wgs >= big_min_wgs();
+}
 
 // Tile for D[M,N] with contraction length K: the largest tile (BM capped by M) that still yields `want`
 // workgroups, else the smallest; small-M problems with a long K use the BK=256 variants (latency-bound:
 // fewer, fatter K steps keep a whole K range in flight).
 int pick_tile(int M, int N, int K, int splits_hint, int want) {
-  if (force_tile() >= 0 && force_tile() < kNumTiles) return force_tile();
+  if (force_tile() >= 0 && force_tile() < kBigTile) return force_tile();
   if (M <= 32) {
     if (K < 256) return 3;
     const long wg64 = (long)cdiv(N, 64) * splits_hint;
@@ -108,8 +124,32 @@ int launch_one(const GemmArgs& a, const Epi& epi, int splits, hipStream_t st) {
   return DPRHOT_OK;
 }
 
+// persistent (one workgroup per CU walking its tiles with the K pipeline running across tile boundaries) when the
+// epilogue stores next to nothing; one workgroup per tile when it stores the whole tile: a finished workgroup's stores
+// drain while its successor on the CU is already loading, a persistent one would have to wait for them
+template <class Epi, bool PERSIST>
+int launch_big(const GemmArgs& a, const Epi& epi, hipStream_t st) {
+  auto kern = gemm256_kernel<Epi, PERSIST>;
+  static bool attr_done = false;  // benign race: idempotent
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2_lds_total));
+    attr_done = true;
+  }
+  const int nbx = cdiv(a.N, G2_B), nby = cdiv(a.M, G2_B);
+  const int grid = (!PERSIST || nbx * nby < kNumCU) ? nbx * nby : kNumCU;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g2_lds_total, st, a, epi, nbx, nby);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 template <bool AK, bool BKM, class Epi>
 int launch_gemm(int tile, const GemmArgs& a, const Epi& epi, int splits, hipStream_t st) {
+  if constexpr (AK && BKM) {
+    if (tile == kBigTile) {
+      if (splits != 1 || a.K % 64 != 0) return fail(DPRHOT_E_UNSUPPORTED, "256x256 tile: no split-K, K %% 64 == 0");
+      return launch_big<Epi, std::is_same<Epi, EpiFilter>::value>(a, epi, st);
+    }
+  }
   constexpr bool needs_tr = !(AK && BKM);
   const bool tr = needs_tr ? use_tr() : false;
 #define DPRHOT_TILE_CASE(T, BM, BN, BK_)                                                       \
@@ -251,7 +291,7 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
   FwdPlan p{};
   p.short_rows = Nc <= 4096 && B <= 64 && !no_short() && force_tile() < 0;
   if (!p.short_rows) {
-    p.tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
+    p.tile = (force_tile() < 0 && big_ok(B, Nc, d)) ? kBigTile : pick_tile(B, Nc, d, 1, 2 * kNumCU);
     p.splits = 1;
     p.kchunk = cdiv(d, kTiles[p.tile].bk) * kTiles[p.tile].bk;
     p.nt = cdiv(Nc, kTiles[p.tile].bn);
@@ -372,7 +412,7 @@ int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, in
   REQUIRE(Q && C && S, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   REQUIRE(aligned16(Q) && aligned16(C) && aligned16(S), "pointers must be 16-byte aligned");
-  const int tile = pick_tile(B, Nc, d, 1, 2 * kNumCU);
+  const int tile = (force_tile() < 0 && big_ok(B, Nc, d)) ? kBigTile : pick_tile(B, Nc, d, 1, 2 * kNumCU);
   GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
   EpiSim epi{S, colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
   return launch_gemm<true, true>(tile, a, epi, 1, (hipStream_t)stream);
@@ -497,7 +537,7 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
       continue;
     }
     // scores that cannot enter the top-k never leave the GEMM tile
-    const int tile = pick_tile(nq, cols, d, 1, 2 * kNumCU);
+    const int tile = (force_tile() < 0 && big_ok(nq, cols, d)) ? kBigTile : pick_tile(nq, cols, d, 1, 2 * kNumCU);
     GemmArgs a{Q, Cj, nq, cols, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
     EpiFilter epi{values, indices, k, nq, cols, (long long)(id_offset + j0), cnt, S, cand_j};
     if (int rc = launch_gemm<true, true>(tile, a, epi, 1, st)) return rc;
@@ -547,10 +587,14 @@ int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot
     return fail(DPRHOT_E_WORKSPACE, "sim_stats needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
   char* ws = static_cast<char*>(workspace);
-  if (B > 128 && c != nullptr) {
+  if (B > 128) {
     // Beyond the latency-bound sizes reading fp32 operands in the GEMM costs more than it saves (twice the staging
-    // registers and bytes per tile, measured 250 vs 580 TFLOP/s at 8192^2): cast once, then the bf16 kernel.
-    if (int rc = dprhot_prep(q, (size_t)B * d, Qb, c, (size_t)Nc * d, Cb, stream)) return rc;
+    // registers and bytes per tile, measured 250 vs 580 TFLOP/s at 8192^2): cast once, then the bf16 kernels.
+    if (c != nullptr) {
+      if (int rc = dprhot_prep(q, (size_t)B * d, Qb, c, (size_t)Nc * d, Cb, stream)) return rc;
+    } else {
+      if (int rc = dprhot_cast_bf16(q, Qb, (size_t)B * d, stream)) return rc;
+    }
     return dprhot_sim_stats(Qb, B, Cb, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream);
   }
   const FwdPlan fp = fwd_plan(B, Nc, d);

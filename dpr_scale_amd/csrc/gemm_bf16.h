@@ -473,6 +473,33 @@ struct EpiSim {
     return st;
   }
 
+  // gemm256.h keeps no epilogue state in registers across its K loop: thread t < BM fetches the label of row t and
+  // the mask byte of column t of the NEXT tile (big_load, a tile ahead), parks them in LDS (big_store) and the
+  // epilogue rebuilds its State from there (big_state).
+  struct BigRegs { int64_t y; uint8_t m; };
+  __device__ __forceinline__ BigRegs big_load(int m0, int n0, int t) const {
+    BigRegs r;
+    r.y = part_m != nullptr ? y[min(m0 + t, M - 1)] : (int64_t)-1;
+    r.m = colmask != nullptr ? colmask[min(n0 + t, N - 1)] : (uint8_t)0;
+    return r;
+  }
+  __device__ __forceinline__ void big_store(const BigRegs& r, int n0, int t, int* meta, int BM) const {
+    meta[t] = part_m != nullptr ? (int)(r.y + y_offset) : -1;
+    meta[BM + t] = (n0 + t >= N || r.m != 0) ? 1 : 0;
+  }
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ State<TM, TN> big_state(const TileCtx& c, const int* meta) const {
+    const int i = c.lane & 15, g = c.lane >> 4;
+    State<TM, TN> st;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) st.masked[b] = meta[BM + c.wn * (BN / WN) + b * 16 + i] != 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.yi[a][r] = meta[c.wm * (BM / WM) + a * 16 + g * 4 + r];
+    return st;
+  }
+
   template <int BM, int BN, int WM, int WN, int TM, int TN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, const State<TM, TN>& st) const {
     const int i = c.lane & 15, g = c.lane >> 4;
@@ -547,8 +574,7 @@ struct EpiFilter {
 
   template <int TM, int TN>
   struct Raw {
-    float tv[TM][4];
-    int64_t ti[TM][4];
+    float tv[TM][4];  // the id of the k-th best is only needed on an exact score tie: fetched there
   };
   template <int BM, int BN, int WM, int WN, int TM, int TN>
   __device__ __forceinline__ Raw<TM, TN> begin(const TileCtx& c) const {
@@ -560,7 +586,6 @@ struct EpiFilter {
       for (int r = 0; r < 4; ++r) {
         const int m = min(c.m0 + c.wm * (BM / WM) + a * 16 + g * 4 + r, M - 1);
         st.tv[a][r] = kth_val[(size_t)m * k + k - 1];
-        st.ti[a][r] = kth_idx[(size_t)m * k + k - 1];
       }
     return st;
   }
@@ -568,9 +593,37 @@ struct EpiFilter {
   __device__ __forceinline__ Raw<TM, TN> settle(const TileCtx&, const Raw<TM, TN>& raw) const {
     return raw;
   }
+  struct BigRegs { float tv; };
+  __device__ __forceinline__ BigRegs big_load(int m0, int n0, int t) const {
+    return BigRegs{kth_val[(size_t)min(m0 + t, M - 1) * k + k - 1]};
+  }
+  __device__ __forceinline__ void big_store(const BigRegs& r, int n0, int t, int* meta, int BM) const {
+    meta[t] = __float_as_int(r.tv);
+  }
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ Raw<TM, TN> big_state(const TileCtx& c, const int* meta) const {
+    const int g = c.lane >> 4;
+    Raw<TM, TN> st;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st.tv[a][r] = __int_as_float(meta[c.wm * (BM / WM) + a * 16 + g * 4 + r]);
+    return st;
+  }
+
   template <int BM, int BN, int WM, int WN, int TM, int TN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, const Raw<TM, TN>& st) const {
     const int i = c.lane & 15, g = c.lane >> 4;
+    // Branch-free screen first: once the thresholds have risen almost no tile holds a score that reaches its row's
+    // k-th best, and 2 x TM*TN*4 divergent branches per lane would cost more than the K loop of a d=768 tile.
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) any |= acc[a][b][r] >= st.tv[a][r];
+    if (!any) return;
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -578,12 +631,17 @@ struct EpiFilter {
         const int m = c.m0 + c.wm * (BM / WM) + a * 16 + g * 4 + r;
         if (m >= M) continue;
         const float tv = st.tv[a][r];
-        const long long ti = st.ti[a][r] < 0 ? 0x7fffffffffffffffLL : (long long)st.ti[a][r];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
           const int n = c.n0 + c.wn * (BN / WN) + b * 16 + i;
           const float v = acc[a][b][r];
-          if (n < N && (v > tv || (v == tv && col_offset + n < ti))) {
+          if (!(n < N && v >= tv)) continue;
+          bool take = v > tv;
+          if (!take) {  // exact tie with the k-th best -> lower passage id wins (-1: slot unfilled)
+            const long long ti = kth_idx[(size_t)m * k + k - 1];
+            take = ti < 0 || col_offset + n < ti;
+          }
+          if (take) {
             const int pos = atomicAdd(&cnt[m], 1);
             cand_v[(size_t)m * N + pos] = v;
             cand_j[(size_t)m * N + pos] = n;

@@ -418,6 +418,8 @@ int main(int argc, char** argv) {
   run_case(32, 2112, 768, 66, 1.0f, true, timing);   // cfg2 per rank at W=8 incl. the mask rows (two chunks per thread)
   run_case(16, 4096, 128, 256, 2.0f, true, false);
   if (timing || big) run_case(128, 8192, 768, 8, 1.0f, true, timing);
+  run_case(300, 1000, 192, 4, 1.0f, true, false);   // ragged in M and N; with DPRHOT_BIG_MIN=1 through the 256x256 kernel
+  run_case(520, 520, 128, 1, 0.5f, false, false);
   search_case(16, 5000 / 8 * 8, 64, 10, 1024, true, false);
   search_case(40, 30000, 128, 100, 8192, false, false);
   search_case(3, 20000, 768, 128, 4096, true, false);
