@@ -16,6 +16,7 @@
 #include "gemm_bf16.h"
 #include "gemm256.h"
 #include "rowwise.h"
+#include "step_small.h"
 
 using namespace dprhot;
 
@@ -697,6 +698,57 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
                           : launch_pair_tr<false>(t1, p.tile, a1, e1, a2, e2, p.splits, st);
   if (rc) return rc;
   return launch_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, ws, wl, st, /*gemm_too=*/false);
+}
+
+// A whole training step (forward AND backward) in one call.  At the latency-bound shapes (step_small.h) it is TWO
+// launches: the sim GEMM (partial-logit slabs) and one kernel that does softmax-CE, dScores and both backward GEMMs;
+// every other shape runs the three launches of dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd.
+static bool small_step_ok(int B, int Nc, int d) {
+  static const bool off = getenv("DPRHOT_NO_SMALL_STEP") != nullptr;
+  return !off && B <= SS_ROWS && Nc <= SS_MAXNC && d % 16 == 0 && fwd_plan(B, Nc, d).short_rows && !unfused_bwd();
+}
+
+int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
+                            int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float h_scale, const float* d_scale,
+                            float* S_out, float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G, float* dQ, float* dC_part,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(loss_sum && G && dQ && dC_part, "NULL pointer (loss_sum, G, dQ and dC_part are required)");
+  REQUIRE(aligned16(G) && aligned16(dQ) && aligned16(dC_part), "pointers must be 16-byte aligned");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  if (!small_step_ok(B, Nc, d)) {
+    if (int rc = dprhot_inbatch_fwd_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, S_out, row_loss, row_lse,
+                                        loss_sum, G, workspace, workspace_bytes, stream))
+      return rc;
+    return dprhot_inbatch_bwd(G, Qb, Cb, B, Nc, d, h_scale, d_scale, dQ, dC_part, workspace, workspace_bytes, stream);
+  }
+  if (int rc = dprhot_sim_stats_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, nullptr, workspace, workspace_bytes, stream))
+    return rc;
+  const WsLayout wl = ws_layout(B, Nc, d);
+  const FwdPlan fp = fwd_plan(B, Nc, d);
+  char* ws = static_cast<char*>(workspace);
+  StepSmallArgs a{reinterpret_cast<const float*>(ws + wl.logits), fp.splits, (size_t)B * Nc, B, Nc, d, y, y_offset, grad_scale,
+                  Qb, Cb, h_scale, d_scale, dQ, dC_part, S_out, row_loss, row_lse, loss_sum, G};
+  // 16 columns of d per workgroup: every workgroup repeats the softmax, the narrow tile only shortens the GEMM / store tail
+  constexpr int tw = 16;
+  const size_t lds = step_small_lds(Nc, tw);
+  const int ncp = (Nc + 31) / 32 * 32;
+  const dim3 grid(d / tw), block(1024);
+  hipStream_t st = (hipStream_t)stream;
+#define DPRHOT_SS_LAUNCH(CPT)                                                                                                  \
+  do {                                                                                                                         \
+    auto kern = step_small_kernel<CPT, tw>;                                                                                    \
+    static size_t attr = 0; /* benign race: idempotent */                                                                      \
+    if (lds > 48 * 1024 && attr < lds) {                                                                                       \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      attr = lds;                                                                                                              \
+    }                                                                                                                          \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                                         \
+  } while (0)
+  if (ncp <= 256) DPRHOT_SS_LAUNCH(1);
+  else DPRHOT_SS_LAUNCH(2);
+#undef DPRHOT_SS_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
 }
 
 }  // extern "C"

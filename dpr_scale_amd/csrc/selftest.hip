@@ -281,6 +281,34 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
     auto x = q2.down(), y0 = ddq.down(), z = c2.down(), w = ddc.down();
     report("inbatch_bwd dQ == pieces", memcmp(x.data(), y0.data(), x.size() * 4) != 0, 0);
     report("inbatch_bwd dC == pieces", memcmp(z.data(), w.data(), z.size() * 4) != 0, 0);
+    // whole step in one call (two launches at the small shapes): loss / G against the host reference, gradients against
+    // dprhot_inbatch_bwd fed with the step's own G
+    {
+      Dev<float> fq((size_t)B * d), fc((size_t)Nc * d);
+      fq.up(fQ); fc.up(fC);
+      Dev<uint16_t> oq((size_t)B * d), oc((size_t)Nc * d), G4((size_t)B * Nc);
+      Dev<float> l4(B), lse4(B), s4(1), dq4((size_t)B * d), dc4((size_t)Nc * d), dq5((size_t)B * d), dc5((size_t)Nc * d), S4((size_t)B * Nc);
+      OK(dprhot_inbatch_step_f32(fq.p, fc.p, oq.p, oc.p, B, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, 2.0f, dgo.p, S4.p, l4.p, lse4.p,
+                                 s4.p, G4.p, dq4.p, dc4.p, ws.p, wsb, nullptr));
+      CK(hipDeviceSynchronize());
+      OK(dprhot_inbatch_bwd(G4.p, oq.p, oc.p, B, Nc, d, 2.0f, dgo.p, dq5.p, dc5.p, ws.p, wsb, nullptr));
+      CK(hipDeviceSynchronize());
+      auto g4 = G4.down(); auto l4h = l4.down(); auto s4h = s4.down();
+      auto a4 = dq4.down(), a5 = dq5.down(), b4 = dc4.down(), b5 = dc5.down(), s4m = S4.down(), sref = dS.down();
+      double eg = 0, el = 0, eq = 0, mq = 0, ec = 0, mc = 0, es = 0;
+      for (size_t i = 0; i < g4.size(); ++i) eg = std::max(eg, fabs(bf2f(g4[i]) - rG[i]));
+      for (int i = 0; i < B; ++i) el = std::max(el, fabs(l4h[i] - rloss[i]) / std::max(1.0, fabs(rloss[i])));
+      for (size_t i = 0; i < a4.size(); ++i) { eq = std::max(eq, (double)fabs(a4[i] - a5[i])); mq = std::max(mq, (double)fabs(a5[i])); }
+      for (size_t i = 0; i < b4.size(); ++i) { ec = std::max(ec, (double)fabs(b4[i] - b5[i])); mc = std::max(mc, (double)fabs(b5[i])); }
+      for (size_t i = 0; i < s4m.size(); ++i)
+        if (std::isfinite(sref[i]) || std::isfinite(s4m[i])) es = std::max(es, (double)fabs(s4m[i] - sref[i]) / std::max(1.0, (double)fabs(sref[i])));
+      report("step G bf16 (rel max)", eg / gm, 4.5e-3);
+      report("step row_loss", el, 1e-5);
+      report("step loss_sum", fabs(s4h[0] - tot) / std::max(1.0, fabs(tot)), 1e-5);
+      report("step logits", es, 1e-5);
+      report("step dQ vs bwd(G) (rel max)", eq / std::max(mq, 1e-30), 1e-5);
+      report("step dC vs bwd(G) (rel max)", ec / std::max(mc, 1e-30), 1e-5);
+    }
   }
   if (timing) {
     hipEvent_t e0, e1;
@@ -313,6 +341,12 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
     timeit("softmax_ce_fwd_bwd", [&] { OK(dprhot_softmax_ce_fwd_bwd(dS.p, B, Nc, dy.p, 0, (float)gscale, nullptr, 0, dloss.p, dlse.p, dG.p, nullptr)); }, 6 * bn, 0);
     timeit("dq", [&] { OK(dprhot_dq(dG.p, dC_.p, B, Nc, d, 2.0f, dgo.p, ddq.p, ws.p, wsb, nullptr)); }, 2 * bn + 2 * nd + 4 * bd, 2 * bn * d);
     timeit("dc", [&] { OK(dprhot_dc(dG.p, dQ_.p, B, Nc, d, 2.0f, dgo.p, ddc.p, nullptr)); }, 2 * bn + 2 * bd + 4 * nd, 2 * bn * d);
+    {
+      Dev<float> fq((size_t)B * d), fc((size_t)Nc * d), dq4((size_t)B * d), dc4((size_t)Nc * d);
+      fq.up(fQ); fc.up(fC);
+      Dev<uint16_t> oq((size_t)B * d), oc((size_t)Nc * d);
+      timeit("step_f32 (fwd + bwd)", [&] { OK(dprhot_inbatch_step_f32(fq.p, fc.p, oq.p, oc.p, B, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, 1.0f, dgo.p, nullptr, dloss.p, dlse.p, dsum.p, dG.p, dq4.p, dc4.p, ws.p, wsb, nullptr)); }, 0, 6 * bn * d);
+    }
     timeit("rank_of_gold", [&] { OK(dprhot_rank_of_gold(dS.p, B, Nc, dy.p, 0, drank.p, nullptr)); }, 4 * bn, 0);
     timeit("inbatch_fwd", [&] { OK(dprhot_inbatch_fwd(dQ_.p, B, dC_.p, Nc, d, dy.p, 0, dm.p, 1.0f / T, (float)gscale, nullptr, dloss.p, dlse.p, dsum.p, dG.p, ws.p, wsb, nullptr)); }, 2 * (bd + nd) + 10 * bn, 2 * bn * d);
     {
@@ -418,6 +452,9 @@ int main(int argc, char** argv) {
   run_case(32, 2112, 768, 66, 1.0f, true, timing);   // cfg2 per rank at W=8 incl. the mask rows (two chunks per thread)
   run_case(16, 4096, 128, 256, 2.0f, true, false);
   if (timing || big) run_case(128, 8192, 768, 8, 1.0f, true, timing);
+  run_case(5, 40, 64, 8, 1.0f, true, false);       // small-step shapes with ragged Nc (not a multiple of 32 / 16)
+  run_case(32, 264, 192, 8, 0.5f, true, false);
+  run_case(20, 488, 128, 24, 1.0f, true, false);
   run_case(300, 1000, 192, 4, 1.0f, true, false);   // ragged in M and N; with DPRHOT_BIG_MIN=1 through the 256x256 kernel
   run_case(520, 520, 128, 1, 0.5f, false, false);
   search_case(16, 5000 / 8 * 8, 64, 10, 1024, true, false);

@@ -156,6 +156,19 @@ int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprh
                            float* S_out, float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* One training step -- forward and backward of dpr_task.py:197-212 -- in a single call, for callers that know a
+ * backward will follow (autograd: any input requires grad).  Arguments as dprhot_inbatch_fwd_f32 followed by those
+ * of dprhot_inbatch_bwd; loss_sum, G, dQ and dC_part are required.  dQ / dC_part are scaled by
+ * h_scale * (d_scale ? *d_scale : 1): pass the autograd grad_output there if it is known at forward time, or 1 and
+ * multiply later.  At the latency-bound shapes (B <= 32, Nc <= 512, d % 16 == 0) this is TWO launches -- the sim GEMM,
+ * then one kernel doing softmax-CE, dScores and both backward GEMMs from an LDS-resident G; otherwise it equals
+ * dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd (three launches). */
+int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,
+                            const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale,
+                            float h_scale, const float* d_scale, float* S_out, float* row_loss, float* row_lse,
+                            float* loss_sum, dprhot_bf16* G, float* dQ, float* dC_part, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
  * their column indices, descending, ties by lower column index.  k <= 128, k <= cols. */
 int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream);

@@ -59,7 +59,7 @@ def main():
     print(open(path).read())
     # per-launch HBM traffic of the bench.py launches, in the names bench.py uses (read back by bench.py -> roofline.traffic)
     import json
-    names = {"sim_stats_f32": "EpiSim", "softmax_finish": "gfinal", "bwd_pair": "gemm_pair_kernel"}
+    names = {"sim_stats_f32": "EpiSim", "softmax_finish": "gfinal", "bwd_pair": "gemm_pair_kernel", "softmax_bwd_fused": "step_small_kernel"}
     traffic = {}
     for bname, pat in names.items():
         for r in rows.values():

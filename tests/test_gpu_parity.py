@@ -295,6 +295,34 @@ def test_corpus_search_worst_case_order_and_reversed_shards(kn, dev):
         assert torch.equal(i, order) and torch.equal(v, S.gather(1, order))
 
 
+@pytest.mark.parametrize("B,K,d", [(32, 8, 768), (4, 2, 128), (8, 64, 768), (5, 5, 80), (64, 16, 768), (32, 66, 768)])
+def test_whole_step_call_equals_forward_plus_backward(B, K, d, kn, dev):
+    """dprhot_inbatch_step_f32 (sim + ONE softmax/dScores/dQ/dC kernel at the small shapes; three launches otherwise)
+    against dprhot_inbatch_fwd_f32 followed by dprhot_inbatch_bwd, and against the oracle."""
+    n = B * K
+    Nc = (n + 7) // 8 * 8
+    q, c, y, m = O.synth_embeddings(B * 1000 + K, B, K, d, "U", True)
+    cp = np.zeros((Nc, d), np.float32)
+    cp[:n] = c
+    mp = np.ones(Nc, np.uint8)
+    mp[:n] = m
+    tq, tc, ty, tm = t(q, dev), t(cp, dev), t(y, dev), t(mp, dev)
+    T = 0.7
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    Cb = torch.empty((Nc, d), dtype=torch.bfloat16, device=dev)
+    rl, lse, ls, G, dQ, dC = kn.inbatch_step_f32(tq, tc, Qb, Cb, ty, 0, tm, 1.0 / T, 1.0 / (T * B))
+    Qb2, Cb2 = torch.empty_like(Qb), torch.empty_like(Cb)
+    rl2, lse2, ls2, G2, _ = kn.inbatch_fwd_f32(tq, tc, Qb2, Cb2, ty, 0, tm, 1.0 / T, 1.0 / (T * B))
+    dQ2, dC2 = kn.inbatch_bwd(G2, Qb2, Cb2, 1.0, None)
+    assert torch.equal(Qb, Qb2) and torch.equal(Cb, Cb2)
+    assert rel(rl.cpu().numpy(), rl2.cpu().numpy()) <= 1e-6 and abs(ls.item() - ls2.item()) <= 1e-5 * max(1.0, abs(ls2.item()))
+    assert rel(G.float().cpu().numpy(), G2.float().cpu().numpy()) <= 8e-3  # one bf16 ulp where the logsumexp differs in its last bit
+    assert rel(dQ.cpu().numpy(), dQ2.cpu().numpy()) <= 2e-3 and rel(dC.cpu().numpy(), dC2.cpu().numpy()) <= 2e-3
+    r = O.training_step_global(O.bf16_round(q), O.bf16_round(c), y, m, T)
+    assert abs(ls.item() / B - r["loss"]) <= 1e-3 * max(1.0, abs(r["loss"]))
+    assert rel(dQ.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(dC[:n].cpu().numpy(), r["dC"]) <= GRAD_RTOL
+
+
 def test_non_inbatch_window_branch(kn, dev):
     """in_batch_negatives=False (dpr_task.py:198-207): row i sees only its own K columns."""
     meta, g = load_golden("nib")
