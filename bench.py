@@ -62,7 +62,7 @@ class HotPathStep:
     def __init__(self, B, K, d, T, W, r, dev, group=None):
         from dpr_scale_amd import _lib
         from dpr_scale_amd import dist as D
-        from oracle.inbatch_oracle import synth_embeddings  # input generator only (shared with the tests)
+        from dpr_scale_amd.datamodule.synthetic import unit_logit_embeddings
 
         self.lib, self._lib, self.D = _lib.lib, _lib, D
         self.B, self.K, self.d, self.T, self.W, self.r, self.group = B, K, d, T, W, r, group
@@ -72,7 +72,7 @@ class HotPathStep:
         self.rows_c = self.n_ctx if W == 1 else _lib.packed_rows(self.n_ctx, d)
         self.Nc = W * self.rows_c
         self.Nq = W * B
-        q, c, y, m = synth_embeddings(1234 + r, B, K, d, "U", False)
+        q, c, y, m = unit_logit_embeddings(1234 + r, B, K, d)
         f32, bf16 = torch.float32, torch.bfloat16
         self.q = torch.from_numpy(q).to(dev)
         self.c = torch.from_numpy(c).to(dev)

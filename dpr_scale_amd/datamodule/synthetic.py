@@ -2,7 +2,33 @@
 query_ids / contexts_ids (token dicts), pos_ctx_indices [B] = i*K (:164-166), ctx_mask [B*K] bool (:143-157),
 scores.  Replaces the reference's mmap JSONL datamodule for measurement and plumbing tests (no datasets offline).
 """
+import numpy as np
 import torch
+
+
+def unit_logit_embeddings(seed, B, K, d, ragged=False):
+    """Embedding-level synthetic step inputs (distribution "U"): q [B,d], c [B*K,d] ~
+    N(0,1)*d^(-1/4) so that logits are ~N(0,1), positives c[i*K] = (4/sqrt(d))*q[i] + noise (every column matters
+    in the softmax), values rounded to bf16-representable fp32; pos_idx[i] = i*K (dpr_transform.py:164-166);
+    `ragged` marks ~5 % of the non-positive columns as padded dummy contexts (dpr_transform.py:143-157).
+    Returns numpy (q, c, pos_idx int64, ctx_mask bool)."""
+    rng = np.random.default_rng(seed)
+    s = np.float32(d ** -0.25)
+    q = rng.standard_normal((B, d), dtype=np.float32) * s
+    c = rng.standard_normal((B * K, d), dtype=np.float32) * s
+    pos = np.arange(B, dtype=np.int64) * K
+    c[pos] += np.float32(4.0 / np.sqrt(d)) * q
+    mask = np.zeros(B * K, dtype=bool)
+    if ragged:
+        mask = rng.random(B * K) < 0.05
+        mask[pos] = False
+
+    def to_bf16_grid(x):  # round-to-nearest-even onto the bf16 grid, kept as fp32
+        u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+
+    return to_bf16_grid(q), to_bf16_grid(c), pos, mask
 
 
 class SyntheticDPRDataModule:

@@ -382,7 +382,17 @@ class InBatchContrastive(torch.autograd.Function):
         return dq, dc, None, None, None, None, None
 
 
+def _pad_hidden(q, c):
+    """Hidden sizes that are not a multiple of 8 (16-byte bf16 rows) get zero columns appended: dot products are
+    unchanged and autograd slices the gradients back (e.g. 30522-wide router vectors, citadel_task.py:249-262)."""
+    pad = (-q.shape[1]) % 8
+    if pad == 0:
+        return q, c
+    return torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(c, (0, pad))
+
+
 def inbatch_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, group=None, kernels=None):
+    q, c = _pad_hidden(q, c)
     return InBatchContrastive.apply(q, c, pos_idx, ctx_mask, temperature, group, kernels)
 
 
@@ -423,6 +433,7 @@ class WindowedContrastive(torch.autograd.Function):
 
 
 def windowed_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, kernels=None):
+    q, c = _pad_hidden(q, c)
     return WindowedContrastive.apply(q, c, pos_idx, ctx_mask, temperature, kernels)
 
 
@@ -431,6 +442,7 @@ def sim_score(q, c, colmask=None, inv_T=1.0, kernels=None):
     """dpr_task.py:98-105 on the device: fp32 logits [Nq, Nc] from fp32/bf16 embeddings; colmask is the [Nc]
     dummy-context mask (the row the reference broadcasts at :197)."""
     kn = kernels if kernels is not None else default_kernels()
+    q, c = _pad_hidden(q, c)
     Nc = c.shape[0]
     Nc_pad = _pad_cols(Nc)
     Qb = kn.empty(tuple(q.shape), _BF16, q)

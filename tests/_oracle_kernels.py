@@ -59,6 +59,18 @@ class OracleKernels:
         dC = torch.from_numpy((g.T @ _np(Qb).astype(np.float64) * s).astype(np.float32)) if need_dc else None
         return dQ, dC
 
+    # fp32-operand forms: the product rounds to bf16 while staging and leaves the bf16 images in Qb / Cb
+    def inbatch_fwd_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
+        self.cast_bf16(q, Qb)
+        if c is not None:
+            self.cast_bf16(c, Cb)
+        return self.inbatch_fwd(Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits, want_G)
+
+    def inbatch_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale):
+        row_loss, lse, loss_sum, G, _ = self.inbatch_fwd_f32(q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale)
+        dQ, dC = self.inbatch_bwd(G, Qb, Cb, 1.0, None)
+        return row_loss, lse, loss_sum, G, dQ, dC
+
     # ---- forward-only / piecewise ops (eval path, windowed branch) ----
     def sim(self, Qb, Cb, colmask=None, inv_T=1.0):
         m = None if colmask is None else colmask.numpy().astype(bool)

@@ -323,6 +323,26 @@ def test_whole_step_call_equals_forward_plus_backward(B, K, d, kn, dev):
     assert rel(dQ.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(dC[:n].cpu().numpy(), r["dC"]) <= GRAD_RTOL
 
 
+def test_hidden_size_not_a_multiple_of_8_is_zero_padded(dev):
+    """Router-style wide vectors (citadel_task.py:249-262 scores [B, vocab = 30522] representations with the same
+    sim_score + CrossEntropyLoss): d % 8 != 0 goes through zero padding, gradients come back in the original width."""
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss, sim_score
+
+    B, K, d = 6, 3, 1002
+    q, c, y, m = O.synth_embeddings(11, B, K, d, "U", True)
+    r = O.training_step_global(q, c, y, m, 1.0)
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), 1.0, False)
+    loss.backward()
+    assert abs(loss.item() - r["loss"]) <= 1e-3 * max(1.0, abs(r["loss"]))
+    assert tq.grad.shape == (B, d) and tc.grad.shape == (B * K, d)
+    assert rel(tq.grad.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy(), r["dC"]) <= GRAD_RTOL
+    S = sim_score(t(q, dev), t(c, dev)).cpu().numpy()
+    Sm = np.where(m[None, :], -np.inf, r["S"])
+    fin = np.isfinite(Sm)
+    assert np.abs(S[:, ~m] - r["S"][:, ~m]).max() <= 1e-3 * np.abs(r["S"][fin]).max()
+
+
 def test_non_inbatch_window_branch(kn, dev):
     """in_batch_negatives=False (dpr_task.py:198-207): row i sees only its own K columns."""
     meta, g = load_golden("nib")
