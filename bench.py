@@ -161,16 +161,17 @@ class HotPathStep:
 
     def step(self):
         # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
-        h = None
         if self.W > 1:
             self.k_pack()
             self.D.all_gather_rows(self.send, self.Cb, self.group)  # the one forward collective
             self.k_unpack()
         self.k_step()  # forward + backward of the local rows: one call into the library
         if self.W > 1:
-            h = self.D.all_reduce_sum(self.loss_sum, self.group, async_op=True)  # logging value: off the critical path
             self.D.reduce_scatter_rows(self.dC, self.dc, self.group)  # the one backward collective
-            h.wait()
+            # the loss numerator (one float).  Plain call: it is enqueued behind the reduce-scatter on RCCL's stream and
+            # nothing on the host waits for it -- an async_op handle + wait() costs 3x the host time of the call itself
+            # (36 vs 11 us, scratch/dist_overhead.py)
+            self.D.all_reduce_sum(self.loss_sum, self.group)
 
 
 def capture(hp, fn, repeat=1):
