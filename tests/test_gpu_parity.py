@@ -323,12 +323,12 @@ def test_whole_step_call_equals_forward_plus_backward(B, K, d, kn, dev):
     assert rel(dQ.cpu().numpy(), r["dQ"]) <= GRAD_RTOL and rel(dC[:n].cpu().numpy(), r["dC"]) <= GRAD_RTOL
 
 
-def test_hidden_size_not_a_multiple_of_8_is_zero_padded(dev):
+@pytest.mark.parametrize("B,K,d", [(6, 3, 1002), (4, 2, 30522)])
+def test_hidden_size_not_a_multiple_of_8_is_zero_padded(B, K, d, dev):
     """Router-style wide vectors (citadel_task.py:249-262 scores [B, vocab = 30522] representations with the same
     sim_score + CrossEntropyLoss): d % 8 != 0 goes through zero padding, gradients come back in the original width."""
     from dpr_scale_amd.hotpath import inbatch_contrastive_loss, sim_score
 
-    B, K, d = 6, 3, 1002
     q, c, y, m = O.synth_embeddings(11, B, K, d, "U", True)
     r = O.training_step_global(q, c, y, m, 1.0)
     tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
