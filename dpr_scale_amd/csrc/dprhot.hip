@@ -232,9 +232,31 @@ int check_shape(int B, int Nc, int d) {
 }
 
 // split-K plan of dQ = G x C  (M = B, N = d, K = Nc); tile restricted to what the fused pair kernel has
-struct DqPlan { int tile, splits, kchunk; };
+struct DqPlan { int tile, splits, kchunk; bool big; };
+// the 256x256 LDS-DMA backward pair (gemm256.h): both contraction lengths multiples of 64, enough 256-row blocks to
+// matter, operands addressable with 32-bit element offsets
+bool big_bwd_ok(int B, int Nc, int d) {
+  static const bool off = getenv("DPRHOT_NO_BIG_BWD") != nullptr;
+  if (off || force_tile() >= 0 || big_min_wgs() <= 0 || unfused_bwd()) return false;
+  if (B % 64 != 0 || Nc % 64 != 0) return false;
+  if ((double)B * Nc >= 4.0e9 || (double)Nc * d >= 4.0e9) return false;
+  const long units = (long)((Nc + 255) / 256 + (B + 255) / 256) * ((d + 255) / 256);
+  if (big_min_wgs() < 96) return units >= big_min_wgs();  // DPRHOT_BIG_MIN lowered: tests push small shapes through
+  return B >= 256 && Nc >= 1024 && d >= 256 && units >= 96;
+}
 DqPlan dq_plan(int B, int Nc, int d) {
   DqPlan p;
+  p.big = big_bwd_ok(B, Nc, d);
+  if (p.big) {
+    // dQ units as long as dC units (K = B each): split Nc into ~Nc/B slices, at most 16
+    int splits = (Nc + B - 1) / B;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+    p.tile = kBigTile;
+    p.kchunk = cdiv(cdiv(Nc, 64), splits) * 64;
+    p.splits = cdiv(Nc, p.kchunk);
+    return p;
+  }
   if (B <= 32 && Nc >= 256) p.tile = 4;
   else if (B <= 256) p.tile = 2;
   else p.tile = 0;
@@ -318,7 +340,8 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
 
 int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
               char* ws, const WsLayout& wl, hipStream_t st, bool gemm_too) {
-  const DqPlan p = dq_plan(B, Nc, d);
+  DqPlan p = dq_plan(B, Nc, d);
+  if (p.big) p.tile = 0;  // stand-alone dQ (dprhot_dq): same K slices on the 128x128 tile
   if (gemm_too) {
     GemmArgs a{G, C, B, d, Nc, Nc, d, p.kchunk};
     if (p.splits == 1) {
@@ -693,6 +716,20 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
   GemmArgs a2{G, C, B, d, Nc, Nc, d, p.kchunk};
   EpiScaleF32 e2 = p.splits == 1 ? EpiScaleF32{dQ, B, d, h_scale, d_scale}
                                  : EpiScaleF32{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
+  if (p.big) {
+    auto kern = gemm256_bwd_kernel<EpiScaleF32>;
+    static bool attr_done = false;  // benign race: idempotent
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2_lds_total));
+      attr_done = true;
+    }
+    const int nbx1 = cdiv(d, G2_B), nby1 = cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
+    a1.kchunk = B;  // dC: one K range (B % 64 == 0)
+    const int grid = nbx1 * nby1 + nbx2 * nby2 * p.splits;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g2_lds_total, st, a1, e1, nbx1, nby1, a2, e2, nbx2, nby2, p.splits);
+    HIP_TRY(hipGetLastError());
+    return launch_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, ws, wl, st, /*gemm_too=*/false);
+  }
   const int t1 = dc_tile(B, Nc, d);
   const int rc = use_tr() ? launch_pair_tr<true>(t1, p.tile, a1, e1, a2, e2, p.splits, st)
                           : launch_pair_tr<false>(t1, p.tile, a1, e1, a2, e2, p.splits, st);

@@ -156,4 +156,128 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(GemmArgs p, Epi 
   }
 }
 
+// ---- backward GEMMs at MFMA-bound sizes: operands that are mn-major in HBM ------------------------------------------
+// dC_part = G^T Q reads both operands, dQ = G C its B operand, with the contraction index as the ROW of the matrix in
+// HBM (dpr_task.py:98-105 backward).  Tile image [64 k][256 mn] bf16 (512-byte rows); the MFMA fragment (16 mn values x
+// 32 k) comes out of ds_read_b64_tr_b16.  32 lanes of such a read are served together and touch rows k0..k0+3 and
+// k0+8..k0+11 of ONE 32-byte column group, so group cg of row k is stored at slot cg ^ mswz(k) (8 distinct slots of the
+// 256-byte bank row; the XOR stays inside the group's half row).  The DMA writes lane-linearly -- one instruction =
+// two k rows -- so lane l fetches the column group that belongs at its slot: source swizzle, as for k-major tiles.
+__device__ __forceinline__ bf16x8 g2_tr_frag(const uint16_t* T, int r0, int kk, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  const int k = kk * 32 + g * 8 + (i >> 2);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const uint16_t* p = T + k * G2_B + (((r0 >> 4) ^ mswz(k)) << 4) + (i & 3) * 4;  // mswz(k + 4) == mswz(k)
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_bf16x4*)(p + 4 * G2_B));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// One 256x256 tile over the K range of slice bz (p.kchunk, a multiple of 64; K % 64 == 0), one workgroup per tile.
+template <bool A_KMAJOR, bool B_KMAJOR, class Epi>
+__device__ __forceinline__ void g2_tile_once(const GemmArgs& p, const Epi& epi, int bx, int by, int bz, int nbx, uint16_t* smem) {
+  constexpr int WM = 2, WN = 4, TM = 8, TN = 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int m0 = by * G2_B, n0 = bx * G2_B;
+  const int kbeg = bz * p.kchunk;
+  const int kend = min(p.K, kbeg + p.kchunk);
+  const int nt = (kend - kbeg) / G2_BK;
+  float* const scratch = reinterpret_cast<float*>(smem + 4 * G2_TILE);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const TileCtx ctx{m0, n0, wm, wn, lane, tid, bx, nbx, bz, scratch};
+  const auto eraw = epi.template begin<G2_B, G2_B, WM, WN, TM, TN>(ctx);
+
+  // per-lane source offsets (elements) of this wave's 4 DMA instructions per operand; the K step adds a uniform term
+  unsigned oa[4], ob[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if constexpr (A_KMAJOR) {
+      const int row = wave * 32 + j * 8 + (lane >> 3);
+      oa[j] = (unsigned)min(m0 + row, p.M - 1) * (unsigned)p.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    } else {
+      const int krow = (wave * 4 + j) * 2 + (lane >> 5), pos = lane & 31;
+      const int col = ((((pos >> 1) ^ mswz(krow))) << 4) + (pos & 1) * 8;
+      oa[j] = (unsigned)krow * (unsigned)p.lda + (unsigned)min(m0 + col, p.M - 8);
+    }
+    if constexpr (B_KMAJOR) {
+      const int row = wave * 32 + j * 8 + (lane >> 3);
+      ob[j] = (unsigned)min(n0 + row, p.N - 1) * (unsigned)p.ldb + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    } else {
+      const int krow = (wave * 4 + j) * 2 + (lane >> 5), pos = lane & 31;
+      const int col = ((((pos >> 1) ^ mswz(krow))) << 4) + (pos & 1) * 8;
+      ob[j] = (unsigned)krow * (unsigned)p.ldb + (unsigned)min(n0 + col, p.N - 8);
+    }
+  }
+  auto issue = [&](int t, int buf) {
+    uint16_t* As = smem + buf * 2 * G2_TILE;
+    uint16_t* Bs = As + G2_TILE;
+    const int k0 = kbeg + t * G2_BK;
+    const uint16_t* Ab = p.A + (A_KMAJOR ? (size_t)k0 : (size_t)k0 * p.lda);
+    const uint16_t* Bb = p.B + (B_KMAJOR ? (size_t)k0 : (size_t)k0 * p.ldb);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(Ab + oa[j]), (g2_lds_ptr*)(As + (wave * 4 + j) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(Bb + ob[j]), (g2_lds_ptr*)(Bs + (wave * 4 + j) * 512), 16, 0, 0);
+    }
+  };
+  issue(0, 0);
+  const auto est = epi.template settle<G2_B, G2_B, WM, WN, TM, TN>(ctx, eraw);
+  for (int t = 0; t < nt; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+    const uint16_t* Ac = smem + (t & 1) * 2 * G2_TILE;
+    const uint16_t* Bc = Ac + G2_TILE;
+#pragma unroll
+    for (int kk = 0; kk < G2_BK / 32; ++kk) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        if constexpr (B_KMAJOR) bfr[b] = load_frag<G2_B, G2_BK, true, false>(Bc, wn * 64 + b * 16, kk, lane);
+        else bfr[b] = g2_tr_frag(Bc, wn * 64 + b * 16, kk, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        if constexpr (A_KMAJOR) af[a] = load_frag<G2_B, G2_BK, true, false>(Ac, wm * 128 + a * 16, kk, lane);
+        else af[a] = g2_tr_frag(Ac, wm * 128 + a * 16, kk, lane);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  epi.template finish<G2_B, G2_B, WM, WN, TM, TN>(acc, ctx, est);
+}
+
+// dC_part = G^T Q (both operands mn-major) and dQ = G C (A k-major, B mn-major, split over K) in ONE launch: neither
+// fills the chip alone when d is a few hundred (d / 256 column tiles).  Unit u -> XCD-contiguous order, then
+// [dC tiles: context block major, d block minor | dQ units: (K slice, query block) major, d block minor], so that the
+// units an XCD runs together share their G block in its L2.
+template <class Epi>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm256_bwd_kernel(GemmArgs p1, Epi e1, int nbx1, int nby1, GemmArgs p2, Epi e2, int nbx2,
+                                                                    int nby2, int splits2) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int n1 = nbx1 * nby1, n2 = nbx2 * nby2 * splits2, nwg = n1 + n2;
+  const int wg = blockIdx.x, xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+  int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  if (t < n1) {
+    g2_tile_once<false, false, Epi>(p1, e1, t % nbx1, t / nbx1, 0, nbx1, smem);
+  } else {
+    t -= n1;
+    const int bx = t % nbx2, rest = t / nbx2;
+    g2_tile_once<true, false, Epi>(p2, e2, bx, rest % nby2, rest / nby2, nbx2, smem);
+  }
+}
+
 }  // namespace dprhot

@@ -457,6 +457,8 @@ int main(int argc, char** argv) {
   run_case(20, 488, 128, 24, 1.0f, true, false);
   run_case(300, 1000, 192, 4, 1.0f, true, false);   // ragged in M and N; with DPRHOT_BIG_MIN=1 through the 256x256 kernel
   run_case(520, 520, 128, 1, 0.5f, false, false);
+  run_case(128, 320, 200, 2, 1.0f, true, false);    // B, Nc multiples of 64: with DPRHOT_BIG_MIN=1 the 256x256 backward pair,
+  run_case(320, 1088, 136, 3, 1.0f, true, false);   // ragged tiles in every dimension, dQ split over K
   search_case(16, 5000 / 8 * 8, 64, 10, 1024, true, false);
   search_case(40, 30000, 128, 100, 8192, false, false);
   search_case(3, 20000, 768, 128, 4096, true, false);
