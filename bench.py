@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--driver", choices=["auto", "graph", "eager"], default="auto")
+    ap.add_argument("--no-scale-roofline", action="store_true", help="skip the extra 8192x8192 per-kernel roofline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true")
     return ap.parse_args()
@@ -231,6 +232,30 @@ def cpu_baseline(B, K, d, T, budget_s=12.0):
             "sample": f"{n} steps of the same B={B} K={K} d={d} workload in {el:.1f} s (oracle/inbatch_oracle.c, OpenMP)"}
 
 
+def roofline_at_scale(dev, d, B=8192, Nc=8192):
+    """Extra information (never `value`): the same three kernels families at a size where a roofline means something
+    -- B x Nc = 8192 x 8192 logits per rank (one large-batch step on one GPU), per-launch HIP-event timing as above."""
+    hp = HotPathStep(B, Nc // B, d, 1.0, 1, 0, dev)
+    bn, bd, nd = float(B) * Nc, float(B) * d, float(Nc) * d
+    hp.k_prep()
+    out = {"workload": f"B={B} x Nc={Nc} x d={d} (bf16 operands resident), per launch"}
+    for name, fn, by, fl, bound in (("sim_gemm", hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d, "mfma"),
+                                    ("softmax_dscores", hp.k_softmax, 6 * bn, 0.0, "hbm"),
+                                    ("backward_gemms", hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d, "mfma")):
+        us = time_kernel(hp, fn, reps=20, iters=3)
+        if bound == "mfma":
+            ach = fl / us * 1e-6
+            out[name] = {"us": round(us, 1), "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4)}
+        else:
+            ach = by / us * 1e-3
+            out[name] = {"us": round(us, 1), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4)}
+    del hp
+    torch.cuda.empty_cache()
+    return out
+
+
 def timed_loop(run, steps, W):
     torch.cuda.synchronize()
     if W > 1:
@@ -340,6 +365,8 @@ def main():
                        "driver": driver},
             "roofline": roof, "kernels": ktimes, "other_driver": alt,
         }
+        if W == 1 and not a.no_scale_roofline:
+            out["roofline_at_scale"] = roofline_at_scale(dev, d)
         if not a.no_cpu_baseline and W == 1:
             out["cpu_baseline"] = cpu_baseline(B, K, d, T)
     if a.e2e and W == 1:
