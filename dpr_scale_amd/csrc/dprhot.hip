@@ -1,10 +1,13 @@
-// dprhot.hip -- C ABI (include/dprhot.h) over the gfx950 kernels in gemm_bf16.h / rowwise.h.
+// dprhot.hip -- C ABI (include/dprhot.h) over the gfx950 kernels in gemm_bf16.h / gemm256.h / step_small.h / rowwise.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC dprhot.hip -o libdprhot.so
 //
 // Launch structure of one training step on one rank:
-//   dprhot_prep         1 launch   fp32 -> bf16 of q and of this rank's context rows
-//   dprhot_inbatch_fwd  2 launches sim GEMM (+mask, 1/T, per-tile softmax stats, gold logit)  ->  G + loss
-//   dprhot_inbatch_bwd  1 launch   dC_part = G^T Q  and  dQ = G C  side by side (+1 when dQ is split over Nc)
+//   dprhot_inbatch_step_f32   2 launches at the BASELINE shapes: sim GEMM (fp32 in, partial-logit slabs) -> one kernel
+//                             for softmax-CE, dScores, dQ and dC (step_small.h); elsewhere = the two calls below
+//   dprhot_inbatch_fwd(_f32)  2 launches: sim GEMM (+mask, 1/T, softmax statistics or K-split slabs) -> G + loss
+//   dprhot_inbatch_bwd        1 launch: dC_part = G^T Q and dQ = G C side by side (+1 when dQ is split over Nc)
+// Plans (tile, split-K, kernel family) are pure functions of the shape: pick_tile / fwd_plan / dq_plan / big_ok /
+// big_bwd_ok / small_step_ok below.
 #include "../../include/dprhot.h"
 
 #include <hip/hip_runtime.h>

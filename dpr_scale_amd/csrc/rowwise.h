@@ -1,7 +1,7 @@
 // rowwise.h -- HBM-bound row kernels of the in-batch contrastive path (gfx950, wave64).
 //   softmax_ce_kernel : nn.CrossEntropyLoss (dpr_task.py:46,212) + its backward into dScores, one launch
 //   rank_kernel       : compute_rank_metrics (dpr_task.py:235-246) as a count, no sort
-//   topk_kernel       : torch.topk epilogue of run_retrieval_pytorch.py:149-150
+//   topk_stream_kernel: torch.topk of run_retrieval_pytorch.py:149-150 and its shard re-merge (:272-277), streaming
 //   cast / reduce helpers
 // All global accesses are 16-byte vectors, lanes consecutive (1 KiB per wave instruction).
 #pragma once

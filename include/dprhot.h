@@ -135,7 +135,11 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
 /* The two launches of dprhot_inbatch_fwd, individually (profiling, or a caller that wants the logits
  * before deciding on the softmax): dprhot_sim_stats leaves logits (S_out, or the workspace when NULL) and
  * the per-tile statistics in `workspace`; dprhot_softmax_finish consumes them (S_in NULL = the workspace
- * logits).  Same B, Nc, d and workspace for both calls. */
+ * logits).  Same B, Nc, d and workspace for both calls.
+ * Short rows (Nc <= 4096 and B <= 64): dprhot_sim_stats writes up to 4 split-K slabs of PARTIAL logits into the
+ * workspace and leaves S_out alone; the summed logits exist only after dprhot_softmax_finish, which writes
+ * them to its S_in argument when that is non-NULL (there S_in is an output).  Callers that want logits from
+ * one call use dprhot_sim_fwd. */
 int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y,
                      int64_t y_offset, const uint8_t* colmask, float inv_T, float* S_out, void* workspace,
                      size_t workspace_bytes, void* stream);
