@@ -272,6 +272,70 @@ def _pad_cols(n):
     return (n + 7) // 8 * 8
 
 
+class ContextGather:
+    """The forward collective, started as soon as the context tower has produced its rows:
+    pack (bf16 rows + mask bytes) on the compute stream, then ONE all-gather with async_op=True -- it runs on RCCL's
+    own stream while the query tower keeps the compute stream busy.  InBatchContrastive waits on it right before
+    the sim GEMM.  Usage (what DenseRetrieverTask.training_step does):
+
+        c  = encode_contexts(...)
+        c, pending = defer_context_grad(c)            # see below: lets the reduce-scatter overlap the query-tower backward
+        g  = ContextGather(c, ctx_mask, group)        # all-gather in flight ...
+        q  = encode_queries(...)                      # ... under the query tower
+        loss = inbatch_contrastive_loss(q, c, pos, ctx_mask, T, group, gather=g, pending=pending)
+    """
+
+    def __init__(self, c, ctx_mask, group=None, kernels=None):
+        kn = kernels if kernels is not None else default_kernels()
+        W, r = D.world(group)
+        assert W > 1, "ContextGather is for world size > 1"
+        n_ctx, d = c.shape
+        m8 = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask.to(torch.uint8)
+        self.rows_c = kn.packed_rows(n_ctx, d)
+        self.send = kn.empty((self.rows_c, d), _BF16, c)
+        kn.pack_ctx(c.detach(), m8, self.send)
+        self.Cb = kn.empty((W * self.rows_c, d), _BF16, c)
+        self.work = D.all_gather_rows(self.send, self.Cb, group, async_op=True)
+        self.shape = (n_ctx, d)
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()  # the compute stream waits for RCCL's stream; the host does not block
+            self.work = None
+        return self.Cb
+
+
+class PendingGrad:
+    """Carries the reduce-scatter started in InBatchContrastive.backward to the point where its result is consumed."""
+
+    def __init__(self):
+        self.work = None
+
+
+class _DeferContextGrad(torch.autograd.Function):
+    """Identity on the context rows whose backward first waits for the pending reduce-scatter.  Placed right after
+    the context tower and BEFORE the query tower runs, its autograd node is older than every query-tower node, so
+    the engine runs the whole query-tower backward (it only needs dq) before it gets here: the collective overlaps
+    it on RCCL's stream."""
+
+    @staticmethod
+    def forward(ctx, c, pending):
+        ctx.pending = pending
+        return c.view_as(c)
+
+    @staticmethod
+    def backward(ctx, grad):
+        w, ctx.pending.work = ctx.pending.work, None
+        if w is not None:
+            w.wait()
+        return grad, None
+
+
+def defer_context_grad(c):
+    pending = PendingGrad()
+    return _DeferContextGrad.apply(c, pending), pending
+
+
 class InBatchContrastive(torch.autograd.Function):
     """loss = InBatchContrastive.apply(q_local, c_local, pos_idx, ctx_mask, temperature, group, kernels)
 
@@ -283,7 +347,7 @@ class InBatchContrastive(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, q, c, pos_idx, ctx_mask, temperature, group, kernels):
+    def forward(ctx, q, c, pos_idx, ctx_mask, temperature, group, kernels, gather=None, pending=None):
         kn = kernels if kernels is not None else default_kernels()
         W, r = (1, 0) if group is False else D.world(group)  # group=False: single-device strategy, never gather
         B, d = q.shape
@@ -317,10 +381,14 @@ class InBatchContrastive(torch.autograd.Function):
             # rows become always-masked extra columns (the reference issues 4 fp32 all_gathers, :169-176)
             rows_c = kn.packed_rows(n_ctx, d)
             Nc = W * rows_c
-            send = kn.empty((rows_c, d), _BF16, c)
-            kn.pack_ctx(c, m8, send)
-            Cb = kn.empty((Nc, d), _BF16, c)
-            D.all_gather_rows(send, Cb, group)
+            if gather is not None:  # started under the query tower (ContextGather): only wait here
+                assert gather.shape == (n_ctx, d)
+                Cb = gather.wait()
+            else:
+                send = kn.empty((rows_c, d), _BF16, c)
+                kn.pack_ctx(c, m8, send)
+                Cb = kn.empty((Nc, d), _BF16, c)
+                D.all_gather_rows(send, Cb, group)
             colmask = kn.empty((Nc,), torch.uint8, c)
             kn.unpack_mask(Cb, W, n_ctx, colmask)
             c_direct = False
@@ -350,6 +418,7 @@ class InBatchContrastive(torch.autograd.Function):
         ctx.dims = (W, r, B, d, n_ctx, rows_c)
         ctx.in_dtypes = (q.dtype, c.dtype)
         ctx.eager = eager
+        ctx.pending = pending if W > 1 else None
         if eager is None:
             ctx.save_for_backward(Qb, Cb, G)
         ctx.row_lse = row_lse
@@ -374,12 +443,19 @@ class InBatchContrastive(torch.autograd.Function):
         if need_dc:
             if W == 1:
                 dc = dC_part[:n_ctx]
+                dc = (dc if go is None else dc * go).to(ctx.in_dtypes[1])
             else:
                 mine = kn.empty((rows_c, d), torch.float32, dC_part)
-                D.reduce_scatter_rows(dC_part, mine, group)  # sum over ranks of the partials of MY columns
-                dc = mine[:n_ctx]
-            dc = (dc if go is None else dc * go).to(ctx.in_dtypes[1])
-        return dq, dc, None, None, None, None, None
+                if go is not None:
+                    dC_part = dC_part * go  # scale before the collective: nothing is left to do after it
+                if ctx.pending is not None and ctx.in_dtypes[1] == torch.float32:
+                    # reduce-scatter on RCCL's stream; whoever consumes dc (defer_context_grad, after the query-tower
+                    # backward has been enqueued) waits for it
+                    ctx.pending.work = D.reduce_scatter_rows(dC_part, mine, group, async_op=True)
+                else:
+                    D.reduce_scatter_rows(dC_part, mine, group)  # sum over ranks of the partials of MY columns
+                dc = mine[:n_ctx].to(ctx.in_dtypes[1])
+        return dq, dc, None, None, None, None, None, None, None
 
 
 def _pad_hidden(q, c):
@@ -391,9 +467,10 @@ def _pad_hidden(q, c):
     return torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(c, (0, pad))
 
 
-def inbatch_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, group=None, kernels=None):
-    q, c = _pad_hidden(q, c)
-    return InBatchContrastive.apply(q, c, pos_idx, ctx_mask, temperature, group, kernels)
+def inbatch_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, group=None, kernels=None, gather=None, pending=None):
+    if gather is None:
+        q, c = _pad_hidden(q, c)
+    return InBatchContrastive.apply(q, c, pos_idx, ctx_mask, temperature, group, kernels, gather, pending)
 
 
 class WindowedContrastive(torch.autograd.Function):

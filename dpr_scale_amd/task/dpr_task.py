@@ -182,9 +182,23 @@ class DenseRetrieverTask(LightningModule):
         return isinstance(getattr(self.trainer, "strategy", None), (DDPStrategy, DDPShardedStrategy))
 
     def training_step(self, batch, batch_idx):
-        q, c = self(batch["query_ids"], batch["contexts_ids"])
         pos, mask = batch["pos_ctx_indices"], batch["ctx_mask"]
         T = self.softmax_temperature
+        if (self.in_batch_negatives and self._is_distributed() and hotpath.D.world(None)[0] > 1
+                and type(self).forward is DenseRetrieverTask.forward):
+            # Multi-GPU (reference :163-195).  Context tower FIRST: its rows go into the one all-gather, which then
+            # runs on RCCL's stream underneath the query tower; in backward the reduce-scatter of dC overlaps the
+            # query-tower backward the same way (hotpath.ContextGather / defer_context_grad).  The encoders are
+            # independent, so the order does not change q or c.  A subclass that overrides forward() keeps the
+            # reference's call below.
+            c = self.encode_contexts(batch["contexts_ids"])
+            c, pending = hotpath.defer_context_grad(c)
+            gather = hotpath.ContextGather(c, mask, None, self.kernels)
+            q = self.encode_queries(batch["query_ids"])
+            loss = hotpath.inbatch_contrastive_loss(q, c, pos, mask, T, None, self.kernels, gather, pending)
+            self.log("train_loss", loss, prog_bar=True)
+            return loss
+        q, c = self(batch["query_ids"], batch["contexts_ids"])
         if self.in_batch_negatives:
             group = None if self._is_distributed() else False  # False: never gather (single-device strategies)
             loss = hotpath.inbatch_contrastive_loss(q, c, pos, mask, T, group, self.kernels)

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, load_golden
 
 
-def _worker(rank, W, port, meta, q):
+def _worker(rank, W, port, meta, q, overlapped=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -22,25 +22,35 @@ def _worker(rank, W, port, meta, q):
     dist.init_process_group("gloo", rank=rank, world_size=W)
     from _oracle_kernels import OracleKernels
     from oracle.inbatch_oracle import synth_embeddings
-    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+    from dpr_scale_amd.hotpath import ContextGather, defer_context_grad, inbatch_contrastive_loss
 
     qv, cv, y, m = synth_embeddings(meta["seed"] + rank, meta["B"], meta["K"], meta["d"], meta["dist"], meta["ragged"])
     tq = torch.from_numpy(qv).requires_grad_(True)
     tc = torch.from_numpy(cv).requires_grad_(True)
-    loss = inbatch_contrastive_loss(tq, tc, torch.from_numpy(y), torch.from_numpy(m), meta["T"], None, OracleKernels())
+    kn = OracleKernels()
+    if overlapped:
+        # the order DenseRetrieverTask.training_step uses on several GPUs: context rows first, gather in flight under the
+        # "query tower" (here an identity op that stands for it), reduce-scatter waited for by the deferred-grad node
+        c1 = tc * 1.0
+        c2, pending = defer_context_grad(c1)
+        g = ContextGather(c2, torch.from_numpy(m), None, kn)
+        q1 = tq * 1.0
+        loss = inbatch_contrastive_loss(q1, c2, torch.from_numpy(y), torch.from_numpy(m), meta["T"], None, kn, g, pending)
+    else:
+        loss = inbatch_contrastive_loss(tq, tc, torch.from_numpy(y), torch.from_numpy(m), meta["T"], None, kn)
     (loss * 3.0).backward()  # grad_output != 1 exercises the device-scalar path
     q.put((rank, loss.item(), tq.grad.numpy() / 3.0, tc.grad.numpy() / 3.0))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,port", [("w2_ddp", 29711), ("w4_ddp", 29712)])
-def test_ddp_branch_matches_reference(name, port):
+@pytest.mark.parametrize("name,port,overlapped", [("w2_ddp", 29711, False), ("w4_ddp", 29712, False), ("w2_ddp", 29713, True)])
+def test_ddp_branch_matches_reference(name, port, overlapped):
     meta, g = load_golden(name)
     W = meta["W"]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, W, port, meta, q)) for r in range(W)]
+    procs = [ctx.Process(target=_worker, args=(r, W, port, meta, q, overlapped)) for r in range(W)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=90) for _ in range(W)], key=lambda t: t[0])
@@ -79,3 +89,110 @@ def test_product_path_refuses_cpu_tensors():
     c = torch.zeros(8, 128, requires_grad=True)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         inbatch_contrastive_loss(q, c, torch.arange(4) * 2, torch.zeros(8, dtype=torch.bool))
+
+
+def _task_worker(rank, W, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from _oracle_kernels import OracleKernels
+    from dpr_scale_amd import hotpath, hydra_compat, lightning_compat
+    from dpr_scale_amd.task.dpr_task import DenseRetrieverTask
+
+    cfg = hydra_compat.compose(os.path.join(ROOT, "dpr_scale_amd", "conf"), "tiny_cpu.yaml", ["task.shared_model=false"])
+    started = []
+
+    class CountingGather(hotpath.ContextGather):
+        def __init__(self, *a, **k):
+            started.append(1)
+            super().__init__(*a, **k)
+
+    hotpath.ContextGather = CountingGather
+    out = {}
+    for mode in ("overlapped", "plain"):
+        torch.manual_seed(0)  # same weights on every rank and in both modes
+        task = hydra_compat.instantiate(cfg.task, _recursive_=False)
+        task.kernels = OracleKernels()
+        task.trainer = lightning_compat.Trainer(device="cpu")  # world size 2 -> DDPStrategy marker
+        task.setup("fit")
+        dm = hydra_compat.instantiate(cfg.datamodule, seed=100 + rank)
+        batch = dm.train_dataloader()[0]
+        if mode == "plain":  # a subclass overriding forward() takes the reference's call order
+            class Plain(DenseRetrieverTask):
+                def forward(self, query_ids, contexts_ids):
+                    return self.encode_queries(query_ids), self.encode_contexts(contexts_ids)
+            task.__class__ = Plain
+        loss = task.training_step(batch, 0)
+        loss.backward()
+        grads = torch.cat([p.grad.flatten() for p in task.parameters() if p.grad is not None])
+        out[mode] = (loss.item(), grads)
+    assert len(started) == 1, started  # the early gather ran in exactly one of the two modes
+    q.put((rank, out["overlapped"][0], out["plain"][0], (out["overlapped"][1] - out["plain"][1]).abs().max().item(),
+           out["plain"][1].abs().max().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_task_training_step_overlapped_order_equals_plain_order():
+    """DenseRetrieverTask.training_step on 2 ranks: context tower first + early all-gather + deferred reduce-scatter
+    (what runs under DDP) gives the same loss and the same encoder gradients as the reference's call order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_task_worker, args=(r, 2, 29721, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    assert abs(res[0][1] - res[1][1]) <= 1e-6  # the loss is the global mean: identical on both ranks
+    for r, lo, lp, gdiff, gmax in res:
+        assert abs(lo - lp) <= 1e-6 * max(1.0, abs(lp))
+        assert gmax > 0 and gdiff <= 1e-6 * gmax
+
+
+def _gpu_worker(rank, W, port, meta, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from oracle.inbatch_oracle import synth_embeddings
+    from dpr_scale_amd.hotpath import ContextGather, defer_context_grad, inbatch_contrastive_loss
+
+    dev = torch.device("cuda", 0)  # every rank on the one GPU of the box; gloo moves the bytes (RCCL refuses that)
+    qv, cv, y, m = synth_embeddings(meta["seed"] + rank, meta["B"], meta["K"], meta["d"], meta["dist"], meta["ragged"])
+    tq = torch.from_numpy(qv).to(dev).requires_grad_(True)
+    tc = torch.from_numpy(cv).to(dev).requires_grad_(True)
+    ty, tm = torch.from_numpy(y).to(dev), torch.from_numpy(m).to(dev)
+    c1 = tc * 1.0
+    c2, pending = defer_context_grad(c1)
+    g = ContextGather(c2, tm, None)
+    q1 = tq * 1.0
+    loss = inbatch_contrastive_loss(q1, c2, ty, tm, meta["T"], None, None, g, pending)
+    (loss * 3.0).backward()
+    torch.cuda.synchronize()
+    q.put((rank, loss.item(), tq.grad.cpu().numpy() / 3.0, tc.grad.cpu().numpy() / 3.0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_through_libdprhot_on_one_gpu_match_reference_ddp():
+    """The whole multi-rank operator -- pack kernel, early all-gather, mask unpack, one-call step (sim + softmax + both
+    backward GEMMs), scaled reduce-scatter, deferred context gradient -- with the real HIP kernels, two processes on
+    one device over gloo, against the reference's own 2-rank DDP fixture."""
+    meta, g = load_golden("w2_ddp")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, 29731, meta, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r, loss, dq, dc in res:
+        assert abs(loss - g["loss_per_rank"][r]) <= 1e-3 * max(1.0, abs(g["loss_per_rank"][r]))
+        assert np.abs(dq - g["dq_per_rank"][r]).max() <= 1e-2 * np.abs(g["dq_per_rank"][r]).max()
+        assert np.abs(dc - g["dc_per_rank"][r]).max() <= 1e-2 * np.abs(g["dc_per_rank"][r]).max()
