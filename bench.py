@@ -60,13 +60,14 @@ def P(t):
 class HotPathStep:
     """Pre-allocated buffers + the C-ABI call sequence of one step on one rank."""
 
-    def __init__(self, B, K, d, T, W, r, dev, group=None):
+    def __init__(self, B, K, d, T, W, r, dev, group=None, comm=None):
         from dpr_scale_amd import _lib
         from dpr_scale_amd import dist as D
         from dpr_scale_amd.datamodule.synthetic import unit_logit_embeddings
 
         self.lib, self._lib, self.D = _lib.lib, _lib, D
         self.B, self.K, self.d, self.T, self.W, self.r, self.group = B, K, d, T, W, r, group
+        self.comm = comm  # dist.DirectComm (collectives on this stream through the C ABI) or None (torch.distributed)
         self.n_ctx = B * K
         # W>1: every rank ships ONE buffer (context rows + mask bytes in trailing rows, dprhot_pack_ctx); the
         # trailing rows are extra, always-masked columns of the gathered matrix
@@ -164,11 +165,17 @@ class HotPathStep:
         # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
         if self.W > 1:
             self.k_pack()
-            self.D.all_gather_rows(self.send, self.Cb, self.group)  # the one forward collective
+            if self.comm is not None:
+                self.comm.all_gather_rows(self.send, self.Cb)  # the one forward collective
+            else:
+                self.D.all_gather_rows(self.send, self.Cb, self.group)
             self.k_unpack()
         self.k_step()  # forward + backward of the local rows: one call into the library
-        if self.W > 1:
-            self.D.reduce_scatter_rows(self.dC, self.dc, self.group)  # the one backward collective
+        if self.W > 1 and self.comm is not None:
+            self.comm.reduce_scatter_rows(self.dC, self.dc)  # the one backward collective
+            self.comm.all_reduce_sum(self.loss_sum)            # the loss numerator (one float)
+        elif self.W > 1:
+            self.D.reduce_scatter_rows(self.dC, self.dc, self.group)
             # the loss numerator (one float).  Plain call: it is enqueued behind the reduce-scatter on RCCL's stream and
             # nothing on the host waits for it -- an async_op handle + wait() costs 3x the host time of the call itself
             # (36 vs 11 us, scratch/dist_overhead.py)
@@ -289,7 +296,11 @@ def main():
     if W > 1:
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     B, K, d, T = a.batch, 1 + a.negatives, a.dim, a.temperature
-    hp = HotPathStep(B, K, d, T, W, rank, dev)
+    comm = None
+    if W > 1 and backend == "nccl" and os.environ.get("DPRHOT_DIRECT_RCCL", "1") != "0":
+        from dpr_scale_amd import dist as D
+        comm = D.try_direct_comm(dev)  # collective: all ranks get one, or all fall back to torch.distributed
+    hp = HotPathStep(B, K, d, T, W, rank, dev, comm=comm)
     driver = a.driver
     if W > 1:
         driver = "eager"  # the collectives stay outside graphs
@@ -362,7 +373,8 @@ def main():
             "config": {"workload": f"cfg2-shaped per GPU: B={B} queries x (1+{a.negatives}) contexts, d={d}, T={T}; "
                                    f"global Nq={W * B}, Nc={hp.Nc}; embeddings resident in HBM, step driven through the C ABI",
                        "global_batch": W * B, "global_negatives_per_query": W * hp.n_ctx - 1, "parallelism": f"dp{W}",
-                       "driver": driver},
+                       "driver": driver, "collectives": ("none" if W == 1 else ("rccl via the C ABI communicator" if comm is not None
+                                                                              else "torch.distributed"))},
             "roofline": roof, "kernels": ktimes, "other_driver": alt,
         }
         if W == 1 and not a.no_scale_roofline:
@@ -378,6 +390,9 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if W > 1:
+        torch.cuda.synchronize()
+        if comm is not None:
+            comm.close()
         dist.barrier()
         dist.destroy_process_group()
 

@@ -59,6 +59,12 @@ SIGNATURES = {
     "dprhot_inbatch_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,
                                         c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_comm_unique_id": (c_int, [c_void_p]),
+    "dprhot_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "dprhot_comm_destroy": (c_int, [c_void_p]),
+    "dprhot_allgather_ctx": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_reducescatter_dc": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_allreduce_sum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_inbatch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
 }

@@ -14,6 +14,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <dlfcn.h>
 
 #include <type_traits>
 #include "gemm_bf16.h"
@@ -788,6 +790,105 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   else DPRHOT_SS_LAUNCH(2);
 #undef DPRHOT_SS_LAUNCH
   HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+}  // extern "C"
+
+// ---- optional communicator: the path's collectives issued straight on the caller's stream ----
+// torch.distributed wraps every collective in a stream hand-over (event to RCCL's stream and back) and ~17 us of host
+// work; the path's three collectives are tiny and sit on the critical path of a ~10 us step.  RCCL is taken from the
+// process (the librccl.so PyTorch already loaded) with dlopen/dlsym -- no link-time dependency, and the selftest and
+// single-GPU users never touch it.
+namespace {
+struct RcclUniqueId { char internal[128]; };
+typedef void* RcclComm;
+struct RcclApi {
+  int (*GetUniqueId)(RcclUniqueId*);
+  int (*CommInitRank)(RcclComm*, int, RcclUniqueId, int);
+  int (*CommDestroy)(RcclComm);
+  int (*AllGather)(const void*, void*, size_t, int, RcclComm, hipStream_t);
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t);
+  int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t);
+  const char* (*GetErrorString)(int);
+  bool ok;
+};
+constexpr int kRcclInt8 = 0, kRcclFloat32 = 7, kRcclSum = 0;
+
+const RcclApi& rccl() {
+  static const RcclApi api = []() {
+    RcclApi a{};
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
+    if (!h) return a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.ReduceScatter && a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+struct DprhotComm { RcclComm comm; int W, rank; };
+#define RCCL_TRY(expr)                                                                              \
+  do {                                                                                              \
+    const int r_ = (expr);                                                                          \
+    if (r_ != 0) return fail(DPRHOT_E_HIP, "%s: %s", #expr, rccl().GetErrorString(r_));             \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+int dprhot_comm_unique_id(void* id128) {
+  REQUIRE(id128 != nullptr, "NULL pointer");
+  if (!rccl().ok) return fail(DPRHOT_E_UNSUPPORTED, "librccl.so (ncclGetUniqueId ...) not found in this process");
+  RCCL_TRY(rccl().GetUniqueId(static_cast<RcclUniqueId*>(id128)));
+  return DPRHOT_OK;
+}
+
+int dprhot_comm_init(const void* id128, int W, int rank, void** h_out) {
+  REQUIRE(id128 && h_out && W > 0 && rank >= 0 && rank < W, "bad argument");
+  if (!rccl().ok) return fail(DPRHOT_E_UNSUPPORTED, "librccl.so not found in this process");
+  RcclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  RcclComm c = nullptr;
+  RCCL_TRY(rccl().CommInitRank(&c, W, id, rank));  // collective over all W ranks, on the current HIP device
+  *h_out = new DprhotComm{c, W, rank};
+  return DPRHOT_OK;
+}
+
+int dprhot_comm_destroy(void* h) {
+  if (h == nullptr) return DPRHOT_OK;
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  const int r = rccl().CommDestroy(c->comm);
+  delete c;
+  if (r != 0) return fail(DPRHOT_E_HIP, "ncclCommDestroy: %s", rccl().GetErrorString(r));
+  return DPRHOT_OK;
+}
+
+int dprhot_allgather_ctx(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+  REQUIRE(h && send && recv && bytes_per_rank > 0, "bad argument");
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  RCCL_TRY(rccl().AllGather(send, recv, bytes_per_rank, kRcclInt8, c->comm, (hipStream_t)stream));
+  return DPRHOT_OK;
+}
+
+int dprhot_reducescatter_dc(void* h, const float* send, float* recv, size_t count_per_rank, void* stream) {
+  REQUIRE(h && send && recv && count_per_rank > 0, "bad argument");
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  RCCL_TRY(rccl().ReduceScatter(send, recv, count_per_rank, kRcclFloat32, kRcclSum, c->comm, (hipStream_t)stream));
+  return DPRHOT_OK;
+}
+
+int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream) {
+  REQUIRE(h && buf && count > 0, "bad argument");
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  RCCL_TRY(rccl().AllReduce(buf, buf, count, kRcclFloat32, kRcclSum, c->comm, (hipStream_t)stream));
   return DPRHOT_OK;
 }
 

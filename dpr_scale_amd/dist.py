@@ -51,3 +51,111 @@ def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_
 
 def all_reduce_sum(t: torch.Tensor, group=None, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class DirectComm:
+    """The path's collectives issued straight on the caller's HIP stream through the C ABI's optional communicator
+    (dprhot_comm_* / dprhot_allgather_ctx / dprhot_reducescatter_dc / dprhot_allreduce_sum: RCCL taken from the
+    process with dlopen).  No hand-over to RCCL's stream and back, ~3x less host time per call than torch.distributed.
+    Build it with try_direct_comm(): construction is COLLECTIVE and falls back as a group."""
+
+    def __init__(self, world_size, rank, unique_id):
+        import ctypes
+
+        from . import _lib
+
+        self._lib, self.W, self.rank = _lib, world_size, rank
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib.dprhot_comm_init(unique_id, world_size, rank, ctypes.byref(h)), "dprhot_comm_init")
+        self.h = h
+
+    @staticmethod
+    def new_unique_id():
+        import ctypes
+
+        from . import _lib
+
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.lib.dprhot_comm_unique_id(buf), "dprhot_comm_unique_id")
+        return bytes(buf.raw)
+
+    @staticmethod
+    def _stream():
+        import ctypes
+
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def all_gather_rows(self, send, out):
+        assert send.is_contiguous() and out.is_contiguous() and out.numel() == self.W * send.numel()
+        self._lib.check(self._lib.lib.dprhot_allgather_ctx(self.h, send.data_ptr(), out.data_ptr(),
+                                                           send.numel() * send.element_size(), self._stream()),
+                        "dprhot_allgather_ctx")
+
+    def reduce_scatter_rows(self, inp, out):
+        assert inp.dtype == torch.float32 and out.dtype == torch.float32 and inp.numel() == self.W * out.numel()
+        self._lib.check(self._lib.lib.dprhot_reducescatter_dc(self.h, inp.data_ptr(), out.data_ptr(), out.numel(),
+                                                              self._stream()), "dprhot_reducescatter_dc")
+
+    def all_reduce_sum(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self._lib.check(self._lib.lib.dprhot_allreduce_sum(self.h, t.data_ptr(), t.numel(), self._stream()),
+                        "dprhot_allreduce_sum")
+
+    def close(self):
+        if self.h is not None:
+            self._lib.lib.dprhot_comm_destroy(self.h)
+            self.h = None
+
+
+def try_direct_comm(device, group=None):
+    """COLLECTIVE over `group` (an initialised nccl group): every rank gets a DirectComm, or every rank gets None.
+    Each stage is agreed on through torch.distributed before the next collective stage starts, and the new
+    communicator has to reproduce torch.distributed's all-gather and reduce-scatter on test data before it is used."""
+    W, r = world(group)
+    if not (dist.is_available() and dist.is_initialized()) or not _is_nccl(group):
+        return None
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(t.item())
+
+    try:
+        uid = DirectComm.new_unique_id()  # every rank probes the library; only rank 0's id is used
+    except Exception:
+        uid = None
+    if not all_ok(uid is not None):
+        return None
+    box = [uid]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    comm = None
+    try:
+        comm = DirectComm(W, r, box[0])
+    except Exception:
+        comm = None
+    if not all_ok(comm is not None):
+        if comm is not None:
+            comm.close()
+        return None
+    # self-check against torch.distributed
+    good = True
+    try:
+        g = torch.Generator(device="cpu").manual_seed(77 + r)
+        send = torch.randn(24, 16, generator=g).to(device).to(torch.bfloat16)
+        a, b = torch.empty((W * 24, 16), dtype=torch.bfloat16, device=device), torch.empty((W * 24, 16), dtype=torch.bfloat16, device=device)
+        comm.all_gather_rows(send, a)
+        dist.all_gather_into_tensor(b, send, group=group)
+        part = torch.randn(W * 24, 16, generator=g).to(device)
+        m1, m2 = torch.empty((24, 16), device=device), torch.empty((24, 16), device=device)
+        comm.reduce_scatter_rows(part, m1)
+        dist.reduce_scatter_tensor(m2, part, op=dist.ReduceOp.SUM, group=group)
+        s1 = torch.full((1,), float(r + 1), device=device)
+        comm.all_reduce_sum(s1)
+        torch.cuda.synchronize()
+        good = bool(torch.equal(a, b)) and bool(torch.allclose(m1, m2, rtol=1e-5, atol=1e-6)) and abs(s1.item() - W * (W + 1) / 2) < 1e-3
+    except Exception:
+        good = False
+    if not all_ok(good):
+        comm.close()
+        return None
+    return comm

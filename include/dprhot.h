@@ -199,6 +199,22 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
                   int k, int chunk, float* values, int64_t* indices, int first, void* workspace,
                   size_t workspace_bytes, void* stream);
 
+/* Optional communicator: the collectives of the path (dpr_task.py:166-176 gathers; the autograd split of :192-195)
+ * issued directly on the caller's stream through the RCCL library already present in the process (dlopen; no
+ * link-time dependency) instead of through torch.distributed -- no stream hand-over, ~3x less host time per call.
+ *   dprhot_comm_unique_id   rank 0: 128-byte id to be handed to every rank (any side channel)
+ *   dprhot_comm_init        COLLECTIVE over the W ranks, on the current HIP device; *h is the communicator handle
+ *   dprhot_allgather_ctx    recv[r * bytes_per_rank ...] = rank r's send  (the packed context buffer of dprhot_pack_ctx)
+ *   dprhot_reducescatter_dc recv[0 .. count_per_rank) = sum over ranks of send[rank * count_per_rank ...]  (fp32 dC partials)
+ *   dprhot_allreduce_sum    in place, fp32 (the loss numerator)
+ * One communicator per rank process, used from one thread; every rank issues the same calls in the same order. */
+int dprhot_comm_unique_id(void* id128);
+int dprhot_comm_init(const void* id128, int W, int rank, void** h);
+int dprhot_comm_destroy(void* h);
+int dprhot_allgather_ctx(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int dprhot_reducescatter_dc(void* h, const float* send, float* recv, size_t count_per_rank, void* stream);
+int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,4 +28,16 @@ print("AG + AR(async) + RS     host %.1f us  total %.1f us" % t(three))
 def two():
     dist.all_gather_into_tensor(recv, send); dist.reduce_scatter_tensor(mine, dC)
 print("AG + RS                 host %.1f us  total %.1f us" % t(two))
+import sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpr_scale_amd import dist as D
+comm = D.try_direct_comm(dev)
+print("direct communicator:", "ok" if comm is not None else "unavailable")
+if comm is not None:
+    print("direct all_gather       host %.1f us  total %.1f us" % t(lambda: comm.all_gather_rows(send, recv)))
+    print("direct reduce_scatter   host %.1f us  total %.1f us" % t(lambda: comm.reduce_scatter_rows(dC, mine)))
+    print("direct all_reduce       host %.1f us  total %.1f us" % t(lambda: comm.all_reduce_sum(loss)))
+    def three_d():
+        comm.all_gather_rows(send, recv); comm.reduce_scatter_rows(dC, mine); comm.all_reduce_sum(loss)
+    print("direct AG + RS + AR     host %.1f us  total %.1f us" % t(three_d))
+    comm.close()
 dist.barrier(); dist.destroy_process_group()
