@@ -60,18 +60,19 @@ def P(t):
 class HotPathStep:
     """Pre-allocated buffers + the C-ABI call sequence of one step on one rank."""
 
-    def __init__(self, B, K, d, T, W, r, dev, group=None, comm=None):
+    def __init__(self, B, K, d, T, W, r, dev, group=None, comm=None, dist_mode=None):
         from dpr_scale_amd import _lib
         from dpr_scale_amd import dist as D
         from dpr_scale_amd.datamodule.synthetic import unit_logit_embeddings
 
         self.lib, self._lib, self.D = _lib.lib, _lib, D
         self.B, self.K, self.d, self.T, self.W, self.r, self.group = B, K, d, T, W, r, group
+        self.dist = (W > 1) if dist_mode is None else bool(dist_mode)  # packed layout + collectives (also at W = 1 when forced)
         self.comm = comm  # dist.DirectComm (collectives on this stream through the C ABI) or None (torch.distributed)
         self.n_ctx = B * K
         # W>1: every rank ships ONE buffer (context rows + mask bytes in trailing rows, dprhot_pack_ctx); the
         # trailing rows are extra, always-masked columns of the gathered matrix
-        self.rows_c = self.n_ctx if W == 1 else _lib.packed_rows(self.n_ctx, d)
+        self.rows_c = self.n_ctx if not self.dist else _lib.packed_rows(self.n_ctx, d)
         self.Nc = W * self.rows_c
         self.Nq = W * B
         q, c, y, m = unit_logit_embeddings(1234 + r, B, K, d)
@@ -82,7 +83,7 @@ class HotPathStep:
         self.m8 = torch.from_numpy(m.astype(np.uint8)).to(dev)
         self.Qb = torch.empty((B, d), dtype=bf16, device=dev)
         self.Cb = torch.empty((self.Nc, d), dtype=bf16, device=dev)
-        self.send = self.Cb[:self.n_ctx] if W == 1 else torch.empty((self.rows_c, d), dtype=bf16, device=dev)
+        self.send = self.Cb[:self.n_ctx] if not self.dist else torch.empty((self.rows_c, d), dtype=bf16, device=dev)
         self.mask_all = torch.zeros(self.Nc, dtype=torch.uint8, device=dev)
         self.row_loss = torch.empty(B, dtype=f32, device=dev)
         self.row_lse = torch.empty(B, dtype=f32, device=dev)
@@ -90,13 +91,13 @@ class HotPathStep:
         self.G = torch.empty((B, self.Nc), dtype=bf16, device=dev)
         self.dQ = torch.empty((B, d), dtype=f32, device=dev)
         self.dC = torch.empty((self.Nc, d), dtype=f32, device=dev)
-        self.dc = self.dC if W == 1 else torch.empty((self.rows_c, d), dtype=f32, device=dev)
+        self.dc = self.dC if not self.dist else torch.empty((self.rows_c, d), dtype=f32, device=dev)
         self.go = torch.ones(1, dtype=f32, device=dev)
         self.ws_bytes = _lib.workspace_bytes(B, self.Nc, d)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self.inv_T = 1.0 / T
         self.gscale = self.inv_T / self.Nq
-        if W == 1:
+        if not self.dist:
             self.mask_all.copy_(self.m8)
         self.bind_stream()
 
@@ -108,16 +109,16 @@ class HotPathStep:
         self.a_prep = (P(self.q), self.q.numel(), P(self.Qb), P(self.c), self.c.numel(), P(self.send), st)
         self.a_fwd = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, self.gscale, None,
                       P(self.row_loss), P(self.row_lse), P(self.loss_sum), P(self.G), ws, wsb, st)
-        self.a_fwd32 = (P(self.q), P(self.c) if self.W == 1 else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
+        self.a_fwd32 = (P(self.q), P(self.c) if not self.dist else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
                         P(self.mask_all), self.inv_T, self.gscale, None, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
                         P(self.G), ws, wsb, st)
-        self.a_sim32 = (P(self.q), P(self.c) if self.W == 1 else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
+        self.a_sim32 = (P(self.q), P(self.c) if not self.dist else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
                         P(self.mask_all), self.inv_T, None, ws, wsb, st)
         self.a_pack = (P(self.c), P(self.m8), self.n_ctx, d, P(self.send), st)
         self.a_unpack = (P(self.Cb), self.W, self.n_ctx, d, P(self.mask_all), st)
         self.a_bwd = (P(self.G), P(self.Qb), P(self.Cb), B, Nc, d, 1.0, P(self.go), P(self.dQ), P(self.dC), ws, wsb, st)
         # the whole step in one C call (dprhot_inbatch_step_f32): 2 launches at the small shapes, else fwd_f32 + bwd
-        self.a_step = (P(self.q), P(self.c) if self.W == 1 else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
+        self.a_step = (P(self.q), P(self.c) if not self.dist else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
                        P(self.mask_all), self.inv_T, self.gscale, 1.0, P(self.go), None, P(self.row_loss), P(self.row_lse),
                        P(self.loss_sum), P(self.G), P(self.dQ), P(self.dC), ws, wsb, st)
         self.small = B <= 32 and Nc <= 512 and d % 16 == 0  # mirrors small_step_ok() in csrc/dprhot.hip
@@ -163,7 +164,7 @@ class HotPathStep:
 
     def step(self):
         # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
-        if self.W > 1:
+        if self.dist:
             self.k_pack()
             if self.comm is not None:
                 self.comm.all_gather_rows(self.send, self.Cb)  # the one forward collective
@@ -171,10 +172,10 @@ class HotPathStep:
                 self.D.all_gather_rows(self.send, self.Cb, self.group)
             self.k_unpack()
         self.k_step()  # forward + backward of the local rows: one call into the library
-        if self.W > 1 and self.comm is not None:
+        if self.dist and self.comm is not None:
             self.comm.reduce_scatter_rows(self.dC, self.dc)  # the one backward collective
             self.comm.all_reduce_sum(self.loss_sum)            # the loss numerator (one float)
-        elif self.W > 1:
+        elif self.dist:
             self.D.reduce_scatter_rows(self.dC, self.dc, self.group)
             # the loss numerator (one float).  Plain call: it is enqueued behind the reduce-scatter on RCCL's stream and
             # nothing on the host waits for it -- an async_op handle + wait() costs 3x the host time of the call itself
@@ -293,19 +294,27 @@ def main():
         assert a.gpus == W, f"--gpus {a.gpus} but WORLD_SIZE={W}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if W > 1:
+    # debugging aid for one-GPU boxes: DPRHOT_FORCE_DIST=1 runs the N>1 code path (packed layout, collectives, the C ABI
+    # communicator) with a world of ONE rank over real RCCL
+    DM = W > 1 or bool(os.environ.get("DPRHOT_FORCE_DIST"))
+    if DM:
+        if W == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29555")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     B, K, d, T = a.batch, 1 + a.negatives, a.dim, a.temperature
     comm = None
-    if W > 1 and backend == "nccl" and os.environ.get("DPRHOT_DIRECT_RCCL", "1") != "0":
+    if DM and backend == "nccl" and os.environ.get("DPRHOT_DIRECT_RCCL", "1") != "0":
         from dpr_scale_amd import dist as D
         comm = D.try_direct_comm(dev)  # collective: all ranks get one, or all fall back to torch.distributed
-    hp = HotPathStep(B, K, d, T, W, rank, dev, comm=comm)
+    hp = HotPathStep(B, K, d, T, W, rank, dev, comm=comm, dist_mode=DM)
     driver = a.driver
-    if W > 1:
+    if DM:
         driver = "eager"  # the collectives stay outside graphs
     runs = {"eager": hp.step}
-    if W == 1 and driver in ("auto", "graph"):
+    if not DM and driver in ("auto", "graph"):
         runs["graph"] = capture(hp, hp.step)
     if driver == "auto":  # launch-rate-bound regime: pick the faster issue mechanism on this box (untimed probe)
         probe = {}
@@ -327,7 +336,7 @@ def main():
     out = None
     if rank == 0:
         bn, bd, nd = float(B) * hp.Nc, float(B) * d, float(hp.Nc) * d
-        sim_bytes = (4 + 2) * bd + (6 * nd if W == 1 else 2 * nd) + 4 * bn
+        sim_bytes = (4 + 2) * bd + (6 * nd if not DM else 2 * nd) + 4 * bn
         if hp.small:
             # two launches: sim (partial-logit slabs), then softmax-CE + dScores + dQ + dC in one kernel.  The second
             # has no entry point of its own: its duration is (both, back to back) - (sim alone)
@@ -341,7 +350,7 @@ def main():
             }
         ktimes = {}
         for name, (fn, by, fl) in kern.items():
-            us = time_kernel(hp, fn, use_graph=(W == 1))
+            us = time_kernel(hp, fn, use_graph=not DM)
             if name == "softmax_bwd_fused":
                 us = max(us - ktimes["sim_stats_f32"]["us"], 1e-3)
             ktimes[name] = {"us": round(us, 3), "GBps": round(by / us * 1e-3, 1), "TFLOPs": round(fl / us * 1e-6, 2)}
@@ -350,7 +359,7 @@ def main():
         us = ktimes[dom]["us"]
         traffic, tsrc = None, None
         tfile = os.path.join(ROOT, "profiles", "bench_cfg2_traffic.json")
-        if W == 1 and (B, K, d) == (32, 8, 768) and os.path.isfile(tfile):  # PMC bytes of this very workload (profiles/)
+        if not DM and (B, K, d) == (32, 8, 768) and os.path.isfile(tfile):  # PMC bytes of this very workload (profiles/)
             tj = json.load(open(tfile))
             if dom in tj.get("kernels", {}):
                 traffic, tsrc = tj["kernels"][dom]["hbm_bytes_per_launch"], f"profiles/bench_cfg2_traffic.json ({tj['source']})"
@@ -359,7 +368,7 @@ def main():
                 "avg_launch_us": us, "algorithmic_bytes": by}
         other = "eager" if driver == "graph" else "graph"
         alt = None
-        if W == 1:
+        if not DM:
             run2 = runs.get(other) or capture(hp, hp.step)
             for _ in range(50):
                 run2()
@@ -373,13 +382,13 @@ def main():
             "config": {"workload": f"cfg2-shaped per GPU: B={B} queries x (1+{a.negatives}) contexts, d={d}, T={T}; "
                                    f"global Nq={W * B}, Nc={hp.Nc}; embeddings resident in HBM, step driven through the C ABI",
                        "global_batch": W * B, "global_negatives_per_query": W * hp.n_ctx - 1, "parallelism": f"dp{W}",
-                       "driver": driver, "collectives": ("none" if W == 1 else ("rccl via the C ABI communicator" if comm is not None
+                       "driver": driver, "collectives": ("none" if not DM else ("rccl via the C ABI communicator" if comm is not None
                                                                               else "torch.distributed"))},
             "roofline": roof, "kernels": ktimes, "other_driver": alt,
         }
-        if W == 1 and not a.no_scale_roofline:
+        if not DM and not a.no_scale_roofline:
             out["roofline_at_scale"] = roofline_at_scale(dev, d)
-        if not a.no_cpu_baseline and W == 1:
+        if not a.no_cpu_baseline and not DM:
             out["cpu_baseline"] = cpu_baseline(B, K, d, T)
     if a.e2e and W == 1:
         try:
@@ -389,7 +398,7 @@ def main():
             out["end_to_end"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if W > 1:
+    if DM:
         torch.cuda.synchronize()
         if comm is not None:
             comm.close()
