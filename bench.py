@@ -122,6 +122,12 @@ class HotPathStep:
                        P(self.mask_all), self.inv_T, self.gscale, 1.0, P(self.go), None, P(self.row_loss), P(self.row_lse),
                        P(self.loss_sum), P(self.G), P(self.dQ), P(self.dC), ws, wsb, st)
         self.small = B <= 32 and Nc <= 512 and d % 16 == 0  # mirrors small_step_ok() in csrc/dprhot.hip
+        # N > 1: everything between the all-gather and the reduce-scatter in one call (mask read from the packed buffer,
+        # loss numerator riding in dC_part); DPRHOT_UNPACKED=1 keeps the separate unpack launch and the loss all-reduce
+        self.packed_step = self.dist and not os.environ.get("DPRHOT_UNPACKED")
+        self.a_pstep = (P(self.q), P(self.Cb), P(self.Qb), B, self.W, self.r, self.n_ctx, d, P(self.y), self.inv_T,
+                        self.gscale, 1.0, P(self.go), P(self.row_loss), P(self.row_lse), P(self.loss_sum), P(self.G), P(self.dQ),
+                        P(self.dC), ws, wsb, st)
         self.a_sim = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, None, ws, wsb, st)
         self.a_fin = (None, B, Nc, d, P(self.y), off, self.gscale, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
                       P(self.G), ws, wsb, st)
@@ -160,7 +166,10 @@ class HotPathStep:
         self._call(self.lib.dprhot_softmax_finish, self.a_fin)
 
     def k_step(self):
-        self._call(self.lib.dprhot_inbatch_step_f32, self.a_step)
+        if self.packed_step:
+            self._call(self.lib.dprhot_inbatch_step_packed_f32, self.a_pstep)
+        else:
+            self._call(self.lib.dprhot_inbatch_step_f32, self.a_step)
 
     def step(self):
         # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
@@ -170,13 +179,17 @@ class HotPathStep:
                 self.comm.all_gather_rows(self.send, self.Cb)  # the one forward collective
             else:
                 self.D.all_gather_rows(self.send, self.Cb, self.group)
-            self.k_unpack()
+            if not self.packed_step:
+                self.k_unpack()
         self.k_step()  # forward + backward of the local rows: one call into the library
         if self.dist and self.comm is not None:
-            self.comm.reduce_scatter_rows(self.dC, self.dc)  # the one backward collective
-            self.comm.all_reduce_sum(self.loss_sum)            # the loss numerator (one float)
+            self.comm.reduce_scatter_rows(self.dC, self.dc)  # the one backward collective; dc[n_ctx][0] = global loss numerator
+            if not self.packed_step:
+                self.comm.all_reduce_sum(self.loss_sum)
         elif self.dist:
             self.D.reduce_scatter_rows(self.dC, self.dc, self.group)
+            if self.packed_step:
+                return
             # the loss numerator (one float).  Plain call: it is enqueued behind the reduce-scatter on RCCL's stream and
             # nothing on the host waits for it -- an async_op handle + wait() costs 3x the host time of the call itself
             # (36 vs 11 us, scratch/dist_overhead.py)
@@ -396,14 +409,21 @@ def main():
             out["end_to_end"] = end_to_end(B, K, d, T, dev)
         except Exception as e:  # extra info only
             out["end_to_end"] = {"error": repr(e)}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    # RCCL prints its version banner through C stdio (fully buffered on a pipe: it would surface at process exit, AFTER a
+    # line printed from Python).  Every rank pushes its buffers out before the last barrier; rank 0 prints after it, so
+    # the JSON line is the last line on the shared stdout.
     if DM:
         torch.cuda.synchronize()
         if comm is not None:
             comm.close()
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if DM:
         dist.barrier()
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

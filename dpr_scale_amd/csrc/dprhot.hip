@@ -37,6 +37,38 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Multi-rank packed layout (dprhot_inbatch_step_packed_f32): while set, every sim epilogue built on this thread reads the
+// column mask from the gathered buffer and the dC epilogues stamp the loss numerator (see EpiSim / EpiScaleF32).
+struct PackedSpec {
+  const uint8_t* base = nullptr;
+  int rows_c = 1, n_ctx = 0, row_bytes = 0;
+  const float* stamp_src = nullptr;
+};
+thread_local PackedSpec g_packed;
+struct PackedScope {
+  explicit PackedScope(const PackedSpec& p) { g_packed = p; }
+  ~PackedScope() { g_packed = PackedSpec{}; }
+};
+template <class E>
+E with_packed_mask(E e) {
+  if (g_packed.base != nullptr) {
+    e.packed = g_packed.base;
+    e.p_rows_c = g_packed.rows_c;
+    e.p_n_ctx = g_packed.n_ctx;
+    e.p_row_bytes = g_packed.row_bytes;
+  }
+  return e;
+}
+template <class E>
+E with_loss_stamp(E e) {
+  if (g_packed.stamp_src != nullptr) {
+    e.stamp_src = g_packed.stamp_src;
+    e.stamp_period = g_packed.rows_c;
+    e.stamp_row = g_packed.n_ctx;
+  }
+  return e;
+}
+
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
@@ -444,6 +476,7 @@ int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, in
   const int tile = (force_tile() < 0 && big_ok(B, Nc, d)) ? kBigTile : pick_tile(B, Nc, d, 1, 2 * kNumCU);
   GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
   EpiSim epi{S, colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};
+  epi = with_packed_mask(epi);
   return launch_gemm<true, true>(tile, a, epi, 1, (hipStream_t)stream);
 }
 
@@ -492,7 +525,7 @@ int dprhot_dc(const dprhot_bf16* G, const dprhot_bf16* Q, int B, int Nc, int d, 
   REQUIRE(aligned16(G) && aligned16(Q) && aligned16(dC_part), "pointers must be 16-byte aligned");
   // A(m = ctx column, k = query row) = G[k][m]  (mn-major, lda = Nc);  B(k, n) = Q[k][n]  (mn-major, ldb = d)
   GemmArgs a{G, Q, Nc, d, B, Nc, d, cdiv(B, 64) * 64};
-  EpiScaleF32 epi{dC_part, Nc, d, h_scale, d_scale};
+  const EpiScaleF32 epi = with_loss_stamp(EpiScaleF32{dC_part, Nc, d, h_scale, d_scale});
   const int tile = force_tile() >= 0 && force_tile() <= 3 ? force_tile() : dc_tile(B, Nc, d);
   return launch_gemm<false, false>(tile, a, epi, 1, (hipStream_t)stream);
 }
@@ -594,11 +627,13 @@ int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, 
   if (fp.short_rows) {  // partial logits per K split; the softmax launch sums them (and fills S_out if asked)
     EpiSim epi{reinterpret_cast<float*>(ws + wl.logits), colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr,
                reinterpret_cast<unsigned long long*>(ws + wl.header), 2, (size_t)B * Nc};
+    epi = with_packed_mask(epi);
     return launch_gemm<true, true>(fp.tile, a, epi, fp.splits, (hipStream_t)stream);
   }
   float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
   EpiSim epi{S, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m), reinterpret_cast<float*>(ws + wl.part_s),
              y, y_offset, reinterpret_cast<float*>(ws + wl.gold), reinterpret_cast<unsigned long long*>(ws + wl.header), 2};
+  epi = with_packed_mask(epi);
   return launch_gemm<true, true>(fp.tile, a, epi, 1, (hipStream_t)stream);
 }
 
@@ -633,12 +668,14 @@ int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot
   if (fp.short_rows) {
     EpiSim epi{reinterpret_cast<float*>(ws + wl.logits), colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr,
                reinterpret_cast<unsigned long long*>(ws + wl.header), 2, (size_t)B * Nc};
+    epi = with_packed_mask(epi);
     return c ? launch_sim_f32<true, true>(fp.tile, a, epi, fp.splits, (hipStream_t)stream)
              : launch_sim_f32<true, false>(fp.tile, a, epi, fp.splits, (hipStream_t)stream);
   }
   float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
   EpiSim epi{S, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m), reinterpret_cast<float*>(ws + wl.part_s),
              y, y_offset, reinterpret_cast<float*>(ws + wl.gold), reinterpret_cast<unsigned long long*>(ws + wl.header), 2};
+  epi = with_packed_mask(epi);
   return c ? launch_sim_f32<true, true>(fp.tile, a, epi, 1, (hipStream_t)stream)
            : launch_sim_f32<true, false>(fp.tile, a, epi, 1, (hipStream_t)stream);
 }
@@ -717,7 +754,7 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     return fail(DPRHOT_E_WORKSPACE, "inbatch_bwd needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   // one launch: [dC tiles | dQ tiles x splits]
   GemmArgs a1{G, Q, Nc, d, B, Nc, d, cdiv(B, 64) * 64};
-  EpiScaleF32 e1{dC_part, Nc, d, h_scale, d_scale};
+  const EpiScaleF32 e1 = with_loss_stamp(EpiScaleF32{dC_part, Nc, d, h_scale, d_scale});
   GemmArgs a2{G, C, B, d, Nc, Nc, d, p.kchunk};
   EpiScaleF32 e2 = p.splits == 1 ? EpiScaleF32{dQ, B, d, h_scale, d_scale}
                                  : EpiScaleF32{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
@@ -769,7 +806,8 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   const FwdPlan fp = fwd_plan(B, Nc, d);
   char* ws = static_cast<char*>(workspace);
   StepSmallArgs a{reinterpret_cast<const float*>(ws + wl.logits), fp.splits, (size_t)B * Nc, B, Nc, d, y, y_offset, grad_scale,
-                  Qb, Cb, h_scale, d_scale, dQ, dC_part, S_out, row_loss, row_lse, loss_sum, G};
+                  Qb, Cb, h_scale, d_scale, dQ, dC_part, S_out, row_loss, row_lse, loss_sum, G,
+                  g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx};
   // 16 columns of d per workgroup: every workgroup repeats the softmax, the narrow tile only shortens the GEMM / store tail
   constexpr int tw = 16;
   const size_t lds = step_small_lds(Nc, tw);
@@ -791,6 +829,29 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
 #undef DPRHOT_SS_LAUNCH
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
+}
+
+// World size > 1, everything after the all-gather in ONE call: the column mask is read from the packed buffer (no
+// unpack launch) and this rank's loss numerator rides in dC_part (no loss all-reduce): see include/dprhot.h.
+int dprhot_inbatch_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank, int n_ctx,
+                                   int d, const int64_t* y, float inv_T, float grad_scale, float h_scale, const float* d_scale,
+                                   float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G, float* dQ, float* dC_part,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(q && gathered && Qb && y && loss_sum, "NULL pointer");
+  REQUIRE(W > 0 && rank >= 0 && rank < W && n_ctx > 0 && d > 0 && d % 8 == 0, "bad argument W=%d rank=%d n_ctx=%d d=%d", W, rank, n_ctx, d);
+  int rows_c = 0;
+  if (int rc = dprhot_packed_rows(n_ctx, d, &rows_c)) return rc;
+  PackedSpec ps;
+  ps.base = reinterpret_cast<const uint8_t*>(gathered);
+  ps.rows_c = rows_c;
+  ps.n_ctx = n_ctx;
+  ps.row_bytes = d * 2;
+  ps.stamp_src = loss_sum;
+  PackedScope scope(ps);
+  // the gathered buffer IS the context matrix: [W * rows_c, d] bf16, mask rows = always-masked columns
+  return dprhot_inbatch_step_f32(q, nullptr, Qb, const_cast<dprhot_bf16*>(gathered), B, W * rows_c, d, y, (int64_t)rank * rows_c,
+                                 nullptr, inv_T, grad_scale, h_scale, d_scale, nullptr, row_loss, row_lse, loss_sum, G, dQ, dC_part,
+                                 workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -426,6 +426,20 @@ struct EpiSim {
   unsigned long long* zero_words;  // words to clear for the next kernel (tile (0,0) clears them), or nullptr
   int n_zero;
   size_t slab_stride = 0;  // split-K (statistics off): split bz stores its partial logits at S + bz * slab_stride
+  // Packed multi-rank layout (dprhot_pack_ctx): when `packed` is set the column mask is read straight from the gathered
+  // buffer -- column n = (rank r, local j): j >= p_n_ctx (mask/padding rows) is masked, else the byte j of rank r's
+  // mask row block -- and the separate unpack launch disappears.
+  const uint8_t* packed = nullptr;
+  int p_rows_c = 1, p_n_ctx = 0, p_row_bytes = 0;
+
+  __device__ __forceinline__ uint8_t mask_at(int n) const {
+    if (packed != nullptr) {
+      const int r = n / p_rows_c, j = n - r * p_rows_c;
+      const uint8_t b = packed[(size_t)(r * p_rows_c + p_n_ctx) * p_row_bytes + min(j, p_n_ctx - 1)];
+      return j >= p_n_ctx ? (uint8_t)1 : b;
+    }
+    return colmask != nullptr ? colmask[n] : (uint8_t)0;
+  }
 
   // begin(): raw loads only, issued back to back BEFORE the tile loads (nothing is used here, or the compiler
   // parks one s_waitcnt per load at the top of the kernel); settle(): turned into what finish() needs, after the
@@ -461,7 +475,7 @@ struct EpiSim {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int n = min(c.n0 + c.wn * (BN / WN) + b * 16 + i, N - 1);
-      st.mraw[b] = colmask != nullptr ? colmask[n] : (uint8_t)0;
+      st.mraw[b] = mask_at(n);
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -480,7 +494,7 @@ struct EpiSim {
   __device__ __forceinline__ BigRegs big_load(int m0, int n0, int t) const {
     BigRegs r;
     r.y = part_m != nullptr ? y[min(m0 + t, M - 1)] : (int64_t)-1;
-    r.m = colmask != nullptr ? colmask[min(n0 + t, N - 1)] : (uint8_t)0;
+    r.m = mask_at(min(n0 + t, N - 1));
     return r;
   }
   __device__ __forceinline__ void big_store(const BigRegs& r, int n0, int t, int* meta, int BM) const {
@@ -657,6 +671,11 @@ struct EpiScaleF32 {
   int M, N;
   float h_scale;
   const float* d_scale;
+  // Loss piggy-back for the multi-rank step: element [m][0] of every row m with m % stamp_period == stamp_row (the
+  // first mask row of each rank's chunk: its gradient is dead weight) is replaced by *stamp_src, this rank's loss
+  // numerator, so that the reduce-scatter of dC also delivers the sum of the losses and no all-reduce is needed.
+  const float* stamp_src = nullptr;
+  int stamp_period = 1, stamp_row = -1;
   template <int BM, int BN, int WM, int WN, int TM, int TN>
   __device__ __forceinline__ float begin(const TileCtx&) const {
     return d_scale ? *d_scale : 1.0f;  // raw prefetch (see EpiSim::State)
@@ -678,7 +697,11 @@ struct EpiScaleF32 {
         if (n >= N) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (m + r < M) o[(size_t)(m + r) * N + n] = acc[a][b][r] * s;
+          if (m + r < M) {
+            float v = acc[a][b][r] * s;
+            if (n == 0 && stamp_src != nullptr && (m + r) % stamp_period == stamp_row) v = *stamp_src;
+            o[(size_t)(m + r) * N + n] = v;
+          }
       }
   }
 };

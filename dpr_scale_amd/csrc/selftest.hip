@@ -61,7 +61,7 @@ struct Dev {
   T* p = nullptr;
   size_t n = 0;
   explicit Dev(size_t n_) : n(n_) { CK(hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16))); }
-  ~Dev() { hipFree(p); }
+  ~Dev() { (void)hipFree(p); }
   void up(const std::vector<T>& h) { CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
   std::vector<T> down() const {
     std::vector<T> h(n);

@@ -43,6 +43,7 @@ struct StepSmallArgs {
   float* row_lse;      // optional [B]
   float* loss_sum;     // [1]
   uint16_t* G;         // optional [B][Nc]
+  int stamp_period, stamp_row;  // > 0: dC[m][0] = loss numerator for m % stamp_period == stamp_row (EpiScaleF32)
 };
 
 inline size_t step_small_lds(int Nc, int TW) {
@@ -226,6 +227,7 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
     double tot = 0.0;
     for (int r = 0; r < p.B; ++r) tot += (double)s_rl[r];
     p.loss_sum[0] = (float)tot;
+    s_rl[0] = (float)tot;  // (row losses are no longer needed) for the stamp below, read after the next barrier
   }
 
   const float sc = p.h_scale * dsc;
@@ -254,9 +256,11 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(ks * SS_ROWS + wm * 16 + g * 4 + r) * TW + b * 16 + i] = acc[b][r];
   }
+  __syncthreads();
   // ---- dC_part[0:Nc, n0:n0+TW] = G^T[Nc, 32] x Q[32, TW]: one 16-row block of contexts per wave and round ----
   DPRHOT_TM(14);
   {
+    const bool stamp = lead && p.stamp_period > 0;  // column 0 of d belongs to workgroup 0
     bf16x8 bq[NF];
 #pragma unroll
     for (int b = 0; b < NF; ++b) bq[b] = ss_tr_frag(Qs, TS, 0, b * 16, lane);
@@ -275,7 +279,11 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
         for (int r = 0; r < 4; ++r) {
           if (j0 + g * 4 + r < Nc) {
 #pragma unroll
-            for (int b = 0; b < NF; ++b) o[b * 16] = acc[b][r] * sc;
+            for (int b = 0; b < NF; ++b) {
+              float v = acc[b][r] * sc;
+              if (b == 0 && i == 0 && stamp && (j0 + g * 4 + r) % p.stamp_period == p.stamp_row) v = s_rl[0];
+              o[b * 16] = v;
+            }
           }
           o += p.d;
         }
@@ -283,7 +291,6 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
       out += step;
     }
   }
-  __syncthreads();
   // dQ: add the 8 K slices in order
   for (int e = tid; e < SS_ROWS * TW; e += 1024) {
     const int r = e / TW, ccol = e - r * TW;

@@ -166,6 +166,31 @@ class HipKernels:
             _ptr(ws), ws.numel(), self._stream()), "dprhot_inbatch_step_f32")
         return row_loss, row_lse, loss_sum, G, dQ, dC
 
+    def inbatch_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale):
+        """World size > 1: everything between the all-gather and the reduce-scatter in one library call.  `gathered` is
+        the all-gathered packed buffer; the mask is read from it, and dC_part carries this rank's loss numerator at
+        [k * rows_c + n_ctx][0] of every chunk k (see include/dprhot.h).  Returns (row_loss, row_lse, loss_sum, G, dQ,
+        dC_part)."""
+        self._require_gpu(q, gathered, Qb, y)
+        B, d = Qb.shape
+        Nc = gathered.shape[0]
+        dev = Qb.device
+        q = q.detach().contiguous()
+        assert q.dtype == torch.float32 and gathered.dtype == _BF16 and Nc == W * self.packed_rows(n_ctx, d)
+        f32 = torch.float32
+        row_loss = torch.empty(B, dtype=f32, device=dev)
+        row_lse = torch.empty(B, dtype=f32, device=dev)
+        loss_sum = torch.empty(1, dtype=f32, device=dev)
+        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        dQ = torch.empty((B, d), dtype=f32, device=dev)
+        dC = torch.empty((Nc, d), dtype=f32, device=dev)
+        ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_inbatch_step_packed_f32(
+            _ptr(q), _ptr(gathered), _ptr(Qb), B, int(W), int(rank), int(n_ctx), d, _ptr(y), float(inv_T), float(grad_scale),
+            1.0, None, _ptr(row_loss), _ptr(row_lse), _ptr(loss_sum), _ptr(G), _ptr(dQ), _ptr(dC), _ptr(ws), ws.numel(),
+            self._stream()), "dprhot_inbatch_step_packed_f32")
+        return row_loss, row_lse, loss_sum, G, dQ, dC
+
     def inbatch_bwd(self, G, Qb, Cb, h_scale, d_scale, need_dq=True, need_dc=True):
         self._require_gpu(G, Qb, Cb, d_scale)
         B, d = Qb.shape

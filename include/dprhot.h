@@ -173,6 +173,21 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
                             float* loss_sum, dprhot_bf16* G, float* dQ, float* dC_part, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* The same step for world size > 1, everything between the all-gather and the reduce-scatter in ONE call
+ * (dpr_task.py:177-212 and its backward on this rank's rows).  `gathered` is the all-gathered packed buffer
+ * [W * rows_c, d] bf16 (dprhot_pack_ctx on every rank); it is used as the context matrix as it is:
+ *   - the column mask is read from its mask rows inside the sim kernel (no dprhot_unpack_mask launch, no colmask),
+ *   - labels are y + rank * rows_c,
+ *   - dC_part [W * rows_c, d] is what the caller reduce-scatters; in every rank chunk k its element
+ *     [k * rows_c + n_ctx][0] (first mask row, a dead gradient) carries THIS rank's loss numerator, so the rank's
+ *     reduce-scatter output holds the global sum of the loss numerators at [n_ctx][0]: no all-reduce for the loss.
+ * loss_sum still receives the local numerator.  G is required (as in dprhot_inbatch_step_f32). */
+int dprhot_inbatch_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank,
+                                   int n_ctx, int d, const int64_t* y, float inv_T, float grad_scale, float h_scale,
+                                   const float* d_scale, float* row_loss, float* row_lse, float* loss_sum,
+                                   dprhot_bf16* G, float* dQ, float* dC_part, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+
 /* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
  * their column indices, descending, ties by lower column index.  k <= 128, k <= cols. */
 int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream);

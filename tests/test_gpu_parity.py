@@ -175,6 +175,45 @@ def test_packed_single_gather_layout_vs_reference_ddp(name, kn, dev):
         assert rel(dC[r * rows_c:r * rows_c + n_ctx], g["dc_per_rank"][r]) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("name", ["w2_ddp", "w4_ddp", "cfg4_ddp"])
+def test_packed_step_mask_from_buffer_and_loss_in_reduce_scatter(name, kn, dev):
+    """dprhot_inbatch_step_packed_f32 for every rank on one GPU: no unpack launch (the sim kernel reads the mask bytes from
+    the gathered buffer), and the reduce-scatter of dC_part -- emulated by summing the ranks' buffers -- must deliver
+    the reference's c.grad in the first n_ctx rows of every rank chunk AND the global loss numerator at [n_ctx][0]."""
+    meta, g = load_golden(name)
+    W, B, K, d = meta["W"], meta["B"], meta["K"], meta["d"]
+    n_ctx = B * K
+    parts = rank_inputs(meta)
+    rows_c = kn.packed_rows(n_ctx, d)
+    sends = []
+    for r in range(W):
+        send = torch.empty((rows_c, d), dtype=torch.bfloat16, device=dev)
+        kn.pack_ctx(t(parts[r][1], dev), t(parts[r][3].astype(np.uint8), dev), send)
+        sends.append(send)
+    Cb = torch.cat(sends, 0).contiguous()  # == all_gather_into_tensor
+    inv_T = 1.0 / meta["T"]
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
+    local, dqs = [], []
+    for r in range(W):
+        _, _, ls, _, dq, dcp = kn.inbatch_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), inv_T,
+                                                           inv_T / (W * B))
+        dC += dcp.double()  # what the reduce-scatter sums
+        local.append(ls.item())
+        dqs.append(dq.cpu().numpy())
+    dC = dC.cpu().numpy().reshape(W, rows_c, d)
+    for r in range(W):
+        chunk = dC[r]
+        assert rel(dqs[r], g["dq_per_rank"][r]) <= GRAD_RTOL
+        assert rel(chunk[:n_ctx], g["dc_per_rank"][r]) <= GRAD_RTOL
+        loss = chunk[n_ctx, 0] / (W * B)  # the piggy-backed sum of the loss numerators
+        assert abs(chunk[n_ctx, 0] - sum(local)) <= 1e-6 * max(1.0, abs(sum(local)))
+        assert abs(loss - g["loss_per_rank"][r]) <= LOSS_RTOL * max(1.0, abs(g["loss_per_rank"][r]))
+        dead = chunk[n_ctx:].copy()
+        dead[0, 0] = 0.0
+        assert np.all(dead == 0.0)  # the other mask-row gradients are exactly zero (masked columns have G = 0)
+
+
 @pytest.mark.parametrize("name", golden_names("cfg3") + golden_names("cfg5"))
 def test_full_size_configs_against_reference_summaries(name, kn, dev):
     """cfg3 (W8 B128 K8 d768: 1024 x 8192) and cfg5 (W8 B64 K2 d1024) at full size."""
