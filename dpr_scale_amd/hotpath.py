@@ -414,9 +414,13 @@ class InBatchContrastive(torch.autograd.Function):
                 kn.pack_ctx(c, m8, send)
                 Cb = kn.empty((Nc, d), _BF16, c)
                 D.all_gather_rows(send, Cb, group)
-            colmask = kn.empty((Nc,), torch.uint8, c)
-            kn.unpack_mask(Cb, W, n_ctx, colmask)
             c_direct = False
+            # with a backward to follow, the one-call step reads the mask straight from the gathered buffer: no unpack launch
+            packed_step = (q_f32 and hasattr(kn, "inbatch_step_packed_f32")
+                           and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+            if not packed_step:
+                colmask = kn.empty((Nc,), torch.uint8, c)
+                kn.unpack_mask(Cb, W, n_ctx, colmask)
             if not q_f32:
                 kn.cast_bf16(q, Qb)
 
@@ -424,7 +428,12 @@ class InBatchContrastive(torch.autograd.Function):
         grad_scale = inv_T / Nq  # d loss / d S of the global mean, before grad_output
         y_off = r * rows_c       # dpr_task.py:189-190 (label offset of this rank's columns)
         eager = None  # gradients for grad_output = 1, when the whole step ran in the forward call
-        if q_f32 and hasattr(kn, "inbatch_step_f32") and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+        if W > 1 and packed_step:
+            row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T,
+                                                                                     grad_scale)
+            # (dC_part's dead mask rows also carry the loss numerator; only bench.py's stream-ordered step uses that)
+            eager = (dQ, dC_part)
+        elif q_f32 and hasattr(kn, "inbatch_step_f32") and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             # a backward will follow: forward and backward in ONE library call (two launches at the BASELINE shapes
             # instead of three); backward() only applies grad_output and the reduce-scatter
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx,
