@@ -360,6 +360,9 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
   p.tile = B <= 32 ? (d >= 256 ? 5 : 3) : 2;
   const int bk = kTiles[p.tile].bk, ksteps = cdiv(d, bk);
   int splits = ksteps < 4 ? ksteps : 4;
+  // 512 < Nc <= SS_MAXNC (the BASELINE shape gathered over 2..4 ranks): enough column tiles without a K split, and
+  // every workgroup of the fused softmax+backward kernel that follows re-reads the logits -- one slab, not four
+  if (B <= SS_ROWS && Nc > 512 && Nc <= SS_MAXNC) splits = 1;
   p.kchunk = cdiv(ksteps, splits) * bk;
   p.splits = cdiv(d, p.kchunk);
   const int cpr = Nc / 8;
@@ -814,9 +817,9 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   const int ncp = (Nc + 31) / 32 * 32;
   const dim3 grid(d / tw), block(1024);
   hipStream_t st = (hipStream_t)stream;
-#define DPRHOT_SS_LAUNCH(CPT)                                                                                                  \
+#define DPRHOT_SS_LAUNCH(CPT, NS)                                                                                              \
   do {                                                                                                                         \
-    auto kern = step_small_kernel<CPT, tw>;                                                                                    \
+    auto kern = step_small_kernel<CPT, tw, NS>;                                                                                  \
     static size_t attr = 0; /* benign race: idempotent */                                                                      \
     if (lds > 48 * 1024 && attr < lds) {                                                                                       \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -824,8 +827,22 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
     }                                                                                                                          \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                                         \
   } while (0)
-  if (ncp <= 256) DPRHOT_SS_LAUNCH(1);
-  else DPRHOT_SS_LAUNCH(2);
+  if (lds > 160 * 1024 || fp.splits > 4) return fail(DPRHOT_E_UNSUPPORTED, "small step: Nc=%d needs %zu bytes of LDS", Nc, lds);
+  if (ncp <= 256) {
+    if (fp.splits <= 1) DPRHOT_SS_LAUNCH(1, 1);
+    else if (fp.splits == 2) DPRHOT_SS_LAUNCH(1, 2);
+    else if (fp.splits == 3) DPRHOT_SS_LAUNCH(1, 3);
+    else DPRHOT_SS_LAUNCH(1, 4);
+  } else if (ncp <= 512) {
+    if (fp.splits <= 1) DPRHOT_SS_LAUNCH(2, 1);
+    else if (fp.splits == 2) DPRHOT_SS_LAUNCH(2, 2);
+    else if (fp.splits == 3) DPRHOT_SS_LAUNCH(2, 3);
+    else DPRHOT_SS_LAUNCH(2, 4);
+  } else if (ncp <= 768) {
+    DPRHOT_SS_LAUNCH(3, 1);  // above 512 columns the sim launch writes one slab (fwd_plan)
+  } else {
+    DPRHOT_SS_LAUNCH(5, 1);
+  }
 #undef DPRHOT_SS_LAUNCH
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;

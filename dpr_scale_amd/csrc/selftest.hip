@@ -452,6 +452,9 @@ int main(int argc, char** argv) {
   run_case(32, 2112, 768, 66, 1.0f, true, timing);   // cfg2 per rank at W=8 incl. the mask rows (two chunks per thread)
   run_case(16, 4096, 128, 256, 2.0f, true, false);
   if (timing || big) run_case(128, 8192, 768, 8, 1.0f, true, timing);
+  run_case(32, 528, 768, 16, 1.0f, true, timing);   // cfg2 gathered over 2 and 4 ranks: one slab, fused softmax+backward
+  run_case(32, 1056, 768, 33, 1.0f, true, timing);
+  run_case(16, 1152, 64, 72, 0.5f, true, false);
   run_case(5, 40, 64, 8, 1.0f, true, false);       // small-step shapes with ragged Nc (not a multiple of 32 / 16)
   run_case(32, 264, 192, 8, 0.5f, true, false);
   run_case(20, 488, 128, 24, 1.0f, true, false);

@@ -1,5 +1,5 @@
 // step_small.h -- the second (and last) launch of a whole training step at the latency-bound BASELINE shapes
-// (B <= 32 queries per rank, Nc <= 512 gathered contexts, d % 16 == 0: cfg1, cfg2, cfg4 per rank).
+// (B <= 32 queries per rank, Nc <= 1152 gathered contexts, d % 16 == 0: cfg1, cfg2, cfg4 per rank).
 //
 // dpr_task.py:209-212 (softmax cross-entropy) and the autograd backward of :98-105 (dQ = G C, dC = G^T Q) in ONE
 // kernel.  At these sizes every launch costs a kernel boundary plus one dependent trip to memory (~3.7 us), whatever it
@@ -21,7 +21,7 @@
 namespace dprhot {
 
 constexpr int SS_ROWS = 32;     // query rows held (B <= 32; rows beyond B are zero)
-constexpr int SS_MAXNC = 512;
+constexpr int SS_MAXNC = 1152;  // G image + C tile + dQ partials must fit the 160 KiB of LDS
 // TW = columns of d per workgroup (16 in the library); the C / Q tile images have row stride TW + 8 elements
 
 struct StepSmallArgs {
@@ -82,7 +82,8 @@ __device__ __forceinline__ bf16x8 ss_tr_frag(const uint16_t* T, int stride, int 
 }
 
 // CPT: 8-value chunks of a row per thread (32 threads per row): Nc <= 256 * CPT.  TW: columns of d per workgroup.
-template <int CPT, int TW>
+// NS: partial-logit slabs read (>= p.splits; the sim launch writes 1 slab above 512 columns, up to 4 below).
+template <int CPT, int TW, int NS>
 __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t ss_smem[];
   constexpr int TS = TW + 8;          // tile image row stride (elements)
@@ -114,17 +115,17 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
     creg[u] = make_uint4(0u, 0u, 0u, 0u);
     if (j < Nc) creg[u] = *reinterpret_cast<const uint4*>(p.Cb + (size_t)j * p.d + n0 + cc * 8);
   }
-  // partial-logit slabs (at most 4): every load is issued unconditionally on a valid address (absent slabs re-read
+  // partial-logit slabs (at most NS): every load is issued unconditionally on a valid address (absent slabs re-read
   // slab 0 and are dropped by a select at the add) -- a loop over p.splits would wait for one slab before asking for
-  // the next: four dependent trips to L2 instead of one
-  float4 sa[CPT][4], sb[CPT][4];
+  // the next: dependent trips to L2 instead of one
+  float4 sa[CPT][NS], sb[CPT][NS];
 #pragma unroll
   for (int k = 0; k < CPT; ++k) {
     const int chunk = tr + k * 32;
     const bool ok = active && chunk < cpr;
     const float* src = p.slabs + (ok ? (size_t)row * Nc + (size_t)chunk * 8 : (size_t)0);
 #pragma unroll
-    for (int z = 0; z < 4; ++z) {
+    for (int z = 0; z < NS; ++z) {
       const float* sz = src + (z < p.splits ? (size_t)z * p.slab_stride : (size_t)0);
       sa[k][z] = *reinterpret_cast<const float4*>(sz);
       sb[k][z] = *reinterpret_cast<const float4*>(sz + 4);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   for (int k = 0; k < CPT; ++k) {
     float4 a = sa[k][0], b = sb[k][0];
 #pragma unroll
-    for (int z = 1; z < 4; ++z) {
+    for (int z = 1; z < NS; ++z) {
       const bool on = z < p.splits;
       a.x += on ? sa[k][z].x : 0.f; a.y += on ? sa[k][z].y : 0.f; a.z += on ? sa[k][z].z : 0.f; a.w += on ? sa[k][z].w : 0.f;
       b.x += on ? sb[k][z].x : 0.f; b.y += on ? sb[k][z].y : 0.f; b.z += on ? sb[k][z].z : 0.f; b.w += on ? sb[k][z].w : 0.f;
@@ -166,12 +167,6 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   m = dprhot_row16_max(m);
   m = fmaxf(m, __shfl_xor(m, 16));
   float sm = 0.f, gold = 0.f;  // exactly one lane of the row holds the gold column
-  if (m != -INFINITY) {
-#pragma unroll
-    for (int k = 0; k < CPT; ++k)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sm += __expf(v[k][e] - m);
-  }
 #pragma unroll
   for (int k = 0; k < CPT; ++k) {
     const int c0 = (tr + k * 32) * 8;
@@ -179,11 +174,23 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
     for (int e = 0; e < 8; ++e)
       if (yi == c0 + e) gold = v[k][e];
   }
+  // every workgroup repeats this softmax, so its ALU time is on the critical path of the whole launch: ONE exponential
+  // per score -- e = exp(v - max) feeds the row sum and, scaled by 1 / sum, the probabilities
+  float ex[CPT][8];
+  const bool dead = m == -INFINITY;  // a row with every column masked (the reference yields NaN there as well)
+#pragma unroll
+  for (int k = 0; k < CPT; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ex[k][e] = dead ? 0.f : __expf(v[k][e] - m);
+      sm += ex[k][e];
+    }
   sm = dprhot_row16_sum(sm);
   gold = dprhot_row16_sum(gold);
   sm += __shfl_xor(sm, 16);
   gold += __shfl_xor(gold, 16);
   const float lse = m + logf(sm);
+  const float inv_sm = 1.0f / sm;  // sm = 0 (dead row): inf * 0 = NaN, like exp(v - lse) with lse = NaN
   const bool lead = blockIdx.x == 0;
   if (tr == 0) {
     const float l = active ? lse - gold : 0.f;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
         float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float pr = __expf(v[k][e] - lse);
+          float pr = ex[k][e] * inv_sm;
           if (c0 + e == yi) pr -= 1.0f;
           g[e] = pr * p.grad_scale;
         }

@@ -164,7 +164,7 @@ int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprh
  * backward will follow (autograd: any input requires grad).  Arguments as dprhot_inbatch_fwd_f32 followed by those
  * of dprhot_inbatch_bwd; loss_sum, G, dQ and dC_part are required.  dQ / dC_part are scaled by
  * h_scale * (d_scale ? *d_scale : 1): pass the autograd grad_output there if it is known at forward time, or 1 and
- * multiply later.  At the latency-bound shapes (B <= 32, Nc <= 512, d % 16 == 0) this is TWO launches -- the sim GEMM,
+ * multiply later.  At the latency-bound shapes (B <= 32, Nc <= 1152, d % 16 == 0) this is TWO launches -- the sim GEMM,
  * then one kernel doing softmax-CE, dScores and both backward GEMMs from an LDS-resident G; otherwise it equals
  * dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd (three launches). */
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,

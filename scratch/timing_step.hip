@@ -5,8 +5,8 @@ __device__ unsigned long long g_dprhot_tm[64];
 #include "../dpr_scale_amd/csrc/dprhot.hip"
 #include <vector>
 #include <stdio.h>
-int main() {
-  const int B = 32, Nc = 256, d = 768;
+int main(int argc, char** argv) {
+  const int B = 32, Nc = argc > 1 ? atoi(argv[1]) : 256, d = 768;
   float *q, *c, *dq, *dc; uint16_t *Qb, *Cb, *G; int64_t* y; uint8_t* m; float *loss, *lse, *sum, *go; void* ws; size_t wsb;
   dprhot_workspace_bytes(B, Nc, d, &wsb);
   hipMalloc(&q, B * d * 4); hipMalloc(&c, Nc * d * 4); hipMalloc(&Qb, B * d * 2); hipMalloc(&Cb, Nc * d * 2); hipMalloc(&G, B * Nc * 2);
