@@ -378,7 +378,10 @@ def main():
                 traffic, tsrc = tj["kernels"][dom]["hbm_bytes_per_launch"], f"profiles/bench_cfg2_traffic.json ({tj['source']})"
         roof = {"kernel": dom, "bound": "hbm", "achieved": round(by / us * 1e-3, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": tsrc,
-                "avg_launch_us": us, "algorithmic_bytes": by}
+                "avg_launch_us": us, "algorithmic_bytes": by,
+                "regime": "latency-bound: a whole step moves ~3 MB and 38 MFLOP (0.4 us of HBM time); its cost is the number of "
+                          "dependent launches x (kernel boundary + one trip to memory + the dependent work) -- see roofline_at_scale "
+                          "for the same kernel families where a roofline applies"}
         other = "eager" if driver == "graph" else "graph"
         alt = None
         if not DM:
