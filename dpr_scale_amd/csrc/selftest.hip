@@ -465,6 +465,7 @@ int main(int argc, char** argv) {
   search_case(16, 5000 / 8 * 8, 64, 10, 1024, true, false);
   search_case(40, 30000, 128, 100, 8192, false, false);
   search_case(3, 20000, 768, 128, 4096, true, false);
+  search_case(300, 24576, 128, 50, 8192, true, false);  // ragged row tile; with DPRHOT_BIG_MIN=1 the persistent 256x256 filter GEMM
   if (timing || big) search_case(1024, 1 << 20, 768, 100, 65536, false, timing);
   printf(g_fail ? "SELFTEST FAILED (%d)\n" : "SELFTEST PASSED\n", g_fail);
   return g_fail ? 1 : 0;
