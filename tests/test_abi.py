@@ -47,6 +47,22 @@ def test_argument_validation_is_host_side():
     assert lib.dprhot_sim_fwd(None, 4, None, 8, 128, None, 1.0, None, None) == -1  # NULL pointers
     assert lib.dprhot_cast_bf16(None, None, 8, None) == -1
     assert lib.dprhot_topk(None, 1, 1, 1, None, None, None) == -1
+    # the newer entry points validate on the host as well (nothing below touches a device)
+    assert lib.dprhot_topk_update(None, 1, 8, 8, 0, 1, None, None, 1, None) == -1
+    assert lib.dprhot_search(None, 1, None, 8, 64, 0, 1, 8, None, None, 1, None, 0, None) == -1
+    assert lib.dprhot_search_workspace_bytes(4, 12, ctypes.byref(out)) == -1  # chunk % 8
+    assert lib.dprhot_search_workspace_bytes(4, 16, ctypes.byref(out)) == 0 and out.value >= 4 * 16 * 8
+    null = None
+    assert lib.dprhot_inbatch_step_f32(null, null, null, null, 4, 8, 64, null, 0, null, 1.0, 1.0, 1.0, null, null, null, null,
+                                       null, null, null, null, null, 0, null) == -1
+    assert b"required" in lib.dprhot_last_error()
+    assert lib.dprhot_inbatch_step_packed_f32(null, null, null, 4, 2, 5, 8, 64, null, 1.0, 1.0, 1.0, null, null, null, null, null,
+                                              null, null, null, 0, null) == -1  # rank >= W, NULL pointers
+    assert lib.dprhot_comm_init(null, 2, 0, null) == -1
+    assert lib.dprhot_allgather_ctx(null, null, null, 0, null) == -1
+    assert lib.dprhot_comm_destroy(null) == 0  # destroying nothing is fine
+    rows = ctypes.c_int(0)
+    assert lib.dprhot_packed_rows(256, 768, ctypes.byref(rows)) == 0 and rows.value == 264  # 256 rows + 1 mask row -> 8-row multiple
     with pytest.raises(_lib.DprhotError):
         _lib.check(-1, "x")
 
