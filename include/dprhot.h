@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 100 /* 0.1.0 */
+#define DPRHOT_VERSION 130 /* 0.1.30: + topk_update/search, inbatch_step(_packed)_f32, optional communicator */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
