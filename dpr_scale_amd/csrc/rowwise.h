@@ -733,26 +733,32 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
         __syncthreads();
       }
     } else {
-      // too many qualifiers for the buffer: fold step by step (<= 1024 appended per step), flushing as needed
+      // too many qualifiers for the buffer (in practice the first window of an empty state, where everything qualifies):
+      // fold 512 values at a time and sort as soon as 384 candidates are waiting.  The bitonic sort costs P log^2 P LDS
+      // operations (28 us at P = 2048 with four workgroups sharing a CU's LDS, a third of that at P = 1024), and after the
+      // very first one the threshold already rejects most of what follows.
 #pragma unroll
       for (int w = 0; w < TK_WIN; ++w) {
-        if (s_cnt > TK_CAP - 1024) {  // uniform (read after a barrier)
-          tk_flush(sv, si, k, s_cnt, tid);
-          if (tid == 0) s_cnt = 0;
-          tv = sv[k - 1];
-          ti = si[k - 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (s_cnt > 384) {  // uniform (read after a barrier)
+            tk_flush(sv, si, k, s_cnt, tid);
+            if (tid == 0) s_cnt = 0;
+            tv = sv[k - 1];
+            ti = si[k - 1];
+            __syncthreads();
+          }
+#pragma unroll
+          for (int e = 2 * h; e < 2 * h + 2; ++e) {
+            const long long gj = p.col_offset + cj[w][e];
+            if (tk_before(v[w][e], gj, tv, ti)) {
+              const int pos = atomicAdd(&s_cnt, 1);
+              sv[k + pos] = v[w][e];
+              si[k + pos] = gj;
+            }
+          }
           __syncthreads();
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const long long gj = p.col_offset + cj[w][e];
-          if (tk_before(v[w][e], gj, tv, ti)) {
-            const int pos = atomicAdd(&s_cnt, 1);
-            sv[k + pos] = v[w][e];
-            si[k + pos] = gj;
-          }
-        }
-        __syncthreads();
       }
     }
   }
