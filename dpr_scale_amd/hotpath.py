@@ -465,8 +465,8 @@ class InBatchContrastive(torch.autograd.Function):
         need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         go = grad_out.detach().reshape(1).float().contiguous()  # device scalar: AMP loss scale, no host sync
         if ctx.eager is not None:
-            dQ, dC_part = ctx.eager  # computed in forward for grad_output = 1; the scale is applied below
-            ctx.eager = None
+            dQ, dC_part = ctx.eager  # computed in forward for grad_output = 1; the scale is applied below (kept: a
+            #                          second backward with retain_graph=True must find them again)
         else:
             Qb, Cb, G = ctx.saved_tensors
             dQ, dC_part = kn.inbatch_bwd(G, Qb, Cb, 1.0, go, need_dq, need_dc)

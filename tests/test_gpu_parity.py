@@ -382,6 +382,20 @@ def test_hidden_size_not_a_multiple_of_8_is_zero_padded(B, K, d, dev):
     assert np.abs(S[:, ~m] - r["S"][:, ~m]).max() <= 1e-3 * np.abs(r["S"][fin]).max()
 
 
+def test_backward_twice_with_retain_graph(dev):
+    """The step runs in forward when a backward will follow; a second backward (retain_graph=True) must give the same
+    gradients again (accumulated), not fail on missing state."""
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    q, c, y, m = O.synth_embeddings(21, 8, 4, 64, "U", False)
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), 1.0, False)
+    loss.backward(retain_graph=True)
+    g1q, g1c = tq.grad.clone(), tc.grad.clone()
+    loss.backward()
+    assert torch.allclose(tq.grad, 2 * g1q) and torch.allclose(tc.grad, 2 * g1c)
+
+
 def test_non_inbatch_window_branch(kn, dev):
     """in_batch_negatives=False (dpr_task.py:198-207): row i sees only its own K columns."""
     meta, g = load_golden("nib")
