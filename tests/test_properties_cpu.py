@@ -107,3 +107,45 @@ def test_host_side_plans_are_consistent():
     out = ctypes.c_int(0)
     assert _lib.lib.dprhot_packed_rows(0, 768, ctypes.byref(out)) == -1
     assert _lib.lib.dprhot_pack_ctx(None, None, 8, 8, None, None) == -1
+
+
+def test_search_over_pickled_shards_follows_the_reference_flow(tmp_path):
+    """dpr_scale_amd.retrieval.search_shards (reps_* pickles, sorted glob, build_index sizing rule, shard id offsets)
+    against a direct restatement of run_retrieval_pytorch.py:177-243 + :272-277 in numpy."""
+    import pickle
+
+    import torch
+    from _oracle_kernels import OracleKernels
+    from dpr_scale_amd.retrieval import search_shards
+
+    rng = np.random.default_rng(3)
+    d, sizes = 16, [40, 40, 40, 25]  # the short last file leaves zero rows in its shard, as in the reference
+    files = []
+    for i, n in enumerate(sizes):
+        v = rng.integers(-3, 4, (n, d)).astype(np.float32)
+        files.append(v)
+        with open(tmp_path / f"reps_{i:04}.pkl", "wb") as f:
+            pickle.dump(v, f)
+    q = rng.integers(-3, 4, (6, d)).astype(np.float32)
+    with open(tmp_path / "q.pkl", "wb") as f:
+        pickle.dump(q, f)
+    for shard in (1, 2):
+        v, i = search_shards(str(tmp_path / "q.pkl"), str(tmp_path), 7, shard=shard, device="cpu", chunk=16, kernels=OracleKernels())
+        # the reference: per shard an index of rows(first file) * files rows, per-shard top-k, ids offset by len(index), re-merge
+        per = len(files) // shard
+        cand_s, cand_i, offset = [], [], 0
+        for s in range(shard):
+            fs = files[s * per:(s + 1) * per]
+            index = np.zeros((fs[0].shape[0] * len(fs), d), np.float32)
+            n = 0
+            for f in fs:
+                index[n:n + f.shape[0]] = f
+                n += f.shape[0]
+            sv, si = O.topk_stable(q @ index.T, 7)
+            cand_s.append(sv)
+            cand_i.append(si + offset)
+            offset += index.shape[0]
+        cs, ci = np.concatenate(cand_s, 1), np.concatenate(cand_i, 1)
+        order = np.lexsort((ci, -cs), axis=1)[:, :7]
+        assert np.array_equal(i.numpy(), np.take_along_axis(ci, order, 1))
+        assert np.array_equal(v.numpy(), np.take_along_axis(cs, order, 1))
