@@ -91,7 +91,12 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   constexpr int CU = (256 * CPT * TC + 1023) / 1024;  // C-tile chunks per thread
   constexpr int NF = TW / 16;         // 16-column fragments of the tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * TW;
+  // workgroup -> column tile: linear ids are dealt round-robin to the 8 XCDs; give each XCD a CONTIGUOUS run of tiles, so
+  // that the 4 neighbouring 16-column tiles that share every 128-byte line of C / Q rows meet in one L2 (PMC: 3.5 MB of
+  // HBM traffic per launch at cfg2 with the identity mapping against 1.5 MB algorithmic)
+  const int nwg = gridDim.x;
+  const int tile = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int n0 = tile * TW;
   const int Nc = p.Nc, cpr = Nc >> 3;
   const int ncp = (Nc + 31) / 32 * 32, gs = ncp + 8;
   uint16_t* const Gs = ss_smem;                       // [32][gs]   G, row-major
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   gold += __shfl_xor(gold, 16);
   const float lse = m + logf(sm);
   const float inv_sm = 1.0f / sm;  // sm = 0 (dead row): inf * 0 = NaN, like exp(v - lse) with lse = NaN
-  const bool lead = blockIdx.x == 0;
+  const bool lead = tile == 0;
   if (tr == 0) {
     const float l = active ? lse - gold : 0.f;
     s_rl[row] = l;
