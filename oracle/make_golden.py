@@ -67,7 +67,16 @@ def run_global(Q, C, y, m, T):
                 rank_metrics=np.array([rank_sum, mrr_sum, float(score)], dtype=np.float64))
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]  # optional: fixture-name prefixes to (re)generate
+
+
+def wanted(name):
+    return not ONLY or any(name.startswith(o) for o in ONLY)
+
+
 def save(name, meta, **arrays):
+    if not wanted(name):
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
@@ -126,8 +135,12 @@ def main():
         ("cfg3", (8, 128, 8, 768), ("U", True, 1.0), 3),
         ("cfg3", (8, 128, 8, 768), ("P", False, 1.0), 5),
         ("cfg5", (8, 64, 2, 1024), ("U", False, 1.0), 6),
+        ("cfg3", (8, 128, 8, 768), ("U", True, 0.05), 1),   # round 2: small temperature through the long-row plan
+        ("cfg5", (8, 64, 2, 1024), ("U", True, 1.0), 2),    # round 2: ragged (dummy contexts) at d = 1024
     ]:
         seed = SEED0 + 7
+        if not wanted(f"{name}_{distn}{'r' if ragged else ''}_T{T:g}"):
+            continue
         Q, C, y, m = global_inputs(seed, W, B, K, d, distn, ragged)
         r = run_global(Q, C, y, m, T)
         rng = np.random.default_rng(99)
@@ -150,6 +163,8 @@ def main():
         ("cfg4", (8, 8, 8, 768), ("U", False, 1.0), 29613),
     ]:
         seed = SEED0 + 31
+        if not wanted(f"{name}_ddp"):
+            continue
         loss, dq, dc = run_ddp(W, seed, B, K, d, distn, ragged, T, port)
         meta = dict(case=name, W=W, B=B, K=K, d=d, dist=distn, ragged=ragged, T=T, seed=seed,
                     source=f"reference dpr_task.py DDP branch on {W} gloo ranks (PL 1.6.4 all_gather shim)")

@@ -238,6 +238,96 @@ def test_full_size_configs_against_reference_summaries(name, kn, dev):
     assert rel(dC[own * B * K:own * B * K + 64], g["dc_own_head"]) <= GRAD_RTOL
 
 
+def _packed_world(meta, kn, dev):
+    """Every rank's all-gather send buffer built by dprhot_pack_ctx, concatenated as the all-gather would."""
+    W, B, K, d = meta["W"], meta["B"], meta["K"], meta["d"]
+    n_ctx = B * K
+    parts = rank_inputs(meta)
+    rows_c = kn.packed_rows(n_ctx, d)
+    sends = []
+    for r in range(W):
+        send = torch.empty((rows_c, d), dtype=torch.bfloat16, device=dev)
+        kn.pack_ctx(t(parts[r][1], dev), t(parts[r][3].astype(np.uint8), dev), send)
+        sends.append(send)
+    return parts, rows_c, torch.cat(sends, 0).contiguous()
+
+
+@pytest.mark.parametrize("name", golden_names("cfg3") + golden_names("cfg5"))
+def test_production_packed_step_every_rank_full_size(name, kn, dev):
+    """The entry point DDP training actually runs -- dprhot_inbatch_step_packed_f32: fp32 q straight into the sim kernel
+    (dprhot_sim_stats_f32<AF, !BF>, long-row statistics plan at B = 128 / packed Nc = 8 * 1032 = 8256 for cfg3; the
+    short-row plan with d = 1024 for cfg5), mask bytes read from the gathered buffer, loss numerator riding in dC_part --
+    for EVERY rank of cfg3 (W8 B128 K8 d768) and cfg5 (W8 B64 K2 d1024), against the reference's own global step
+    (dpr_task.py:163-212 run through oracle/ref_shim.py): loss, row logsumexp of all 1024 / 512 rows, q.grad of the
+    fixture's rank, c.grad head / row sums / column sums of its chunk after the (emulated) reduce-scatter."""
+    meta, g = load_golden(name)
+    W, B, K, d, T = meta["W"], meta["B"], meta["K"], meta["d"], meta["T"]
+    own, n_ctx = meta["own_rank"], B * K
+    parts, rows_c, Cb = _packed_world(meta, kn, dev)
+    inv_T = 1.0 / T
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
+    local, lses, dq_own, rl_all = [], [], None, []
+    for r in range(W):
+        rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev),
+                                                              inv_T, inv_T / (W * B))
+        assert np.array_equal(Qb.float().cpu().numpy(), parts[r][0])  # bf16 copy-out of the fp32-operand sim kernel
+        dC += dcp.double()  # what the reduce-scatter sums
+        local.append(ls.item())
+        lses.append(lse.cpu().numpy())
+        rl_all.append(rl.cpu().numpy())
+        assert abs(ls.item() - rl.double().sum().item()) <= 1e-5 * max(1.0, abs(ls.item()))
+        Gf = G.float()
+        assert Gf.sum(dim=1).abs().max().item() <= 2e-2 * inv_T / (W * B)  # softmax - onehot: rows sum to zero
+        if r == own:
+            dq_own = dq.cpu().numpy()
+    loss = sum(local) / (W * B)
+    assert abs(loss - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+    assert rel(np.concatenate(lses), g["lse"]) <= LOGIT_RTOL
+    assert rel(dq_own, g["dq_own"]) <= GRAD_RTOL
+    chunk = dC.cpu().numpy().reshape(W, rows_c, d)[own]
+    assert rel(chunk[:64], g["dc_own_head"]) <= GRAD_RTOL
+    assert rel(chunk[:n_ctx].sum(1), g["dc_own_rowsum"]) <= GRAD_RTOL
+    assert rel(chunk[:n_ctx].sum(0), g["dc_own_colsum"]) <= GRAD_RTOL
+    # the global column sum is ~0 (rows of softmax - onehot sum to zero): absolute bar at the scale of one rank's chunk
+    tot = dC.cpu().numpy().reshape(W, rows_c, d)[:, :n_ctx].sum((0, 1))
+    assert np.abs(tot - g["dC_colsum"]).max() <= GRAD_RTOL * W * np.abs(g["dc_own_colsum"]).max()
+    assert abs(chunk[n_ctx, 0] - sum(local)) <= 1e-6 * max(1.0, abs(sum(local)))  # piggy-backed loss numerator
+    dead = chunk[n_ctx:].copy()
+    dead[0, 0] = 0.0
+    assert np.all(dead == 0.0)
+    # logits and ranks of the fixture's rank from the same fp32-operand sim instance (mask through dprhot_unpack_mask)
+    colmask = torch.empty(W * rows_c, dtype=torch.uint8, device=dev)
+    kn.unpack_mask(Cb, W, n_ctx, colmask)
+    _, lse2, _, _, S = kn.inbatch_fwd_f32(t(parts[own][0], dev), None, Qb, Cb, t(parts[own][2], dev), own * rows_c, colmask,
+                                         inv_T, inv_T / (W * B), want_logits=True)
+    assert rel(lse2.cpu().numpy(), lses[own]) <= 1e-6
+    S = S.cpu().numpy().reshape(B, W, rows_c)[:, :, :n_ctx].reshape(B, W * n_ctx) * T  # drop the mask rows' columns
+    si, sj = g["sample_i"], g["sample_j"]
+    sel = (si >= own * B) & (si < (own + 1) * B)
+    mine, ref = S[si[sel] - own * B, sj[sel]], g["sample_S"][sel]
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(mine)) and rel(mine[fin], ref[fin]) <= LOGIT_RTOL
+    from dpr_scale_amd.hotpath import rank_of_gold
+
+    ranks = rank_of_gold(t(np.ascontiguousarray(S), dev), t(parts[own][2] + own * n_ctx, dev)).cpu().numpy()
+    assert np.array_equal(ranks, g["ranks"][own * B:(own + 1) * B])
+
+
+def test_selftest_big_passes():
+    """The stand-alone C ABI self-test (csrc/selftest.hip) including its cfg3-per-rank (128 x 8192 x 768) and 1M-passage
+    search cases, executed as the binary a C caller would link."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "dpr_scale_amd", "selftest")
+    assert os.path.isfile(exe), "dpr_scale_amd/selftest missing: run __graft_entry__.build()"
+    out = subprocess.run([exe, "big"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "SELFTEST PASSED" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_tie_rule_bit_exact(dev):
     from dpr_scale_amd.hotpath import rank_of_gold, topk
 
