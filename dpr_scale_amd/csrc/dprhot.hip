@@ -6,6 +6,7 @@
 //                             for softmax-CE, dScores, dQ and dC (step_small.h); elsewhere = the two calls below
 //   dprhot_inbatch_fwd(_f32)  2 launches: sim GEMM (+mask, 1/T, softmax statistics or K-split slabs) -> G + loss
 //   dprhot_inbatch_bwd        1 launch: dC_part = G^T Q and dQ = G C side by side (+1 when dQ is split over Nc)
+//   few rows x many contexts (B <= 128, Nc >= 1024: cfg3 / cfg5 per rank): the four launches of skinny.h (sk_plan)
 // Plans (tile, split-K, kernel family) are pure functions of the shape: pick_tile / fwd_plan / dq_plan / big_ok /
 // big_bwd_ok / small_step_ok below.
 #include "../../include/dprhot.h"
@@ -22,6 +23,7 @@
 #include "gemm256.h"
 #include "rowwise.h"
 #include "step_small.h"
+#include "skinny.h"
 
 using namespace dprhot;
 
@@ -320,6 +322,26 @@ DqPlan dq_plan(int B, int Nc, int d) {
 
 int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
 
+// Few query rows against many contexts (skinny.h): B <= 128, d a multiple of 128 up to 1024, 1024 <= Nc <= 16384
+// (beyond that the per-unit recomputation of the row logsumexp from Nc / 128 tile values stops being cheap).
+struct SkPlan { bool ok; int nt, nrb, ksteps, nslices; };
+SkPlan sk_plan(int B, int Nc, int d) {
+  static const bool off = getenv("DPRHOT_NO_SKINNY") != nullptr;
+  static const int min_nc = []() { const char* e = getenv("DPRHOT_SKINNY_MIN_NC"); return e ? atoi(e) : 1024; }();
+  SkPlan p{};
+  p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
+         Nc <= 16384 && !(B <= SS_ROWS && Nc <= SS_MAXNC);
+  p.nt = cdiv(Nc, SK_COLS);
+  p.nrb = cdiv(B, SK_ROWS);
+  const int nk = cdiv(Nc, 64), ndt = d / SK_QN;
+  int ns = kNumCU / ndt;  // dQ units: (slice of contexts) x (64 columns of d), at most one per CU
+  if (ns < 1) ns = 1;
+  if (ns > 64) ns = 64;   // bounds the fp32 partial traffic
+  p.ksteps = cdiv(nk, ns);
+  p.nslices = cdiv(nk, p.ksteps);
+  return p;
+}
+
 // workspace carve-up (all offsets 256-byte aligned)
 struct WsLayout {
   size_t header, gold, part_m, part_s, logits, dq_part, total;
@@ -334,7 +356,9 @@ WsLayout ws_layout(int B, int Nc, int d) {
   w.part_s = off; off += align256((size_t)B * ntmax * 4);
   w.logits = off; off += align256((size_t)B * Nc * 4 * ((Nc <= 4096 && B <= 64) ? 4 : 1));  // short rows: up to 4 split-K slabs
   const DqPlan p = dq_plan(B, Nc, d);
-  w.dq_part = off; off += align256((size_t)p.splits * B * d * 4);
+  const SkPlan sk = sk_plan(B, Nc, d);
+  const int slabs = sk.ok && sk.nslices > p.splits ? sk.nslices : p.splits;
+  w.dq_part = off; off += align256((size_t)slabs * B * d * 4);
   w.total = off;
   return w;
 }
@@ -396,6 +420,81 @@ int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
     const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
                        p.splits, n4, h_scale, d_scale, dQ);
+    HIP_TRY(hipGetLastError());
+  }
+  return DPRHOT_OK;
+}
+
+// ---- few rows x many contexts: the four launches of skinny.h -------------------------------------------------------
+template <int NCH>
+int launch_sk_sim(const SkSimArgs& a, int grid, hipStream_t st) {
+  const size_t lds = sk_sim_lds();
+  static bool attr_done[2] = {false, false};  // benign race: idempotent
+  if (a.q != nullptr) {
+    auto kern = sk_sim_kernel<NCH, true>;
+    if (!attr_done[0]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done[0] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_THREADS), lds, st, a);
+  } else {
+    auto kern = sk_sim_kernel<NCH, false>;
+    if (!attr_done[1]) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done[1] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_THREADS), lds, st, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int Nc, int d, const int64_t* y, int64_t y_offset,
+            const uint8_t* colmask, float inv_T, float grad_scale, float h_scale, const float* d_scale, float* S_out, float* row_loss,
+            float* row_lse, float* loss_sum, dprhot_bf16* G, float* dQ, float* dC_part, char* ws, const WsLayout& wl, const SkPlan& sk,
+            hipStream_t st) {
+  float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
+  float* tile_lse = reinterpret_cast<float*>(ws + wl.part_m);
+  float* gold = reinterpret_cast<float*>(ws + wl.gold);
+  SkSimArgs a{q, nullptr, Cb, Qb, B, Nc, d, y, y_offset, colmask, inv_T, S, tile_lse, gold, g_packed.base, g_packed.rows_c,
+              g_packed.n_ctx, g_packed.row_bytes};
+  const int grid1 = sk.nrb * sk.nt;
+  int rc = DPRHOT_OK;
+  switch (d / 128) {  // NCH = d / 64
+    case 1: rc = launch_sk_sim<2>(a, grid1, st); break;
+    case 2: rc = launch_sk_sim<4>(a, grid1, st); break;
+    case 3: rc = launch_sk_sim<6>(a, grid1, st); break;
+    case 4: rc = launch_sk_sim<8>(a, grid1, st); break;
+    case 5: rc = launch_sk_sim<10>(a, grid1, st); break;
+    case 6: rc = launch_sk_sim<12>(a, grid1, st); break;
+    case 7: rc = launch_sk_sim<14>(a, grid1, st); break;
+    case 8: rc = launch_sk_sim<16>(a, grid1, st); break;
+    default: return fail(DPRHOT_E_UNSUPPORTED, "skinny step: d=%d", d);
+  }
+  if (rc) return rc;
+  {
+    const int parts = B >= 128 ? 2 : (B >= 64 ? 4 : 8);  // >= 256 workgroups; a part is at most 4 x 256 chunks of 8 columns
+    int pp = parts;
+    while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
+    SkGArgs g{S, tile_lse, gold, sk.nt, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
+    hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp)), dim3(SK_THREADS), 0, st, g);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    float* part = reinterpret_cast<float*>(ws + wl.dq_part);
+    const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = sk.nt * (d / SK_DN);
+    SkBwdArgs b{G, Qb, Cb, B, Nc, d, h_scale, d_scale, dC_part, loss_sum, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0,
+                g_packed.n_ctx, sk.ksteps, sk.nslices, part, ndq_pad};
+    const size_t lds = sk_bwd_lds();
+    static bool attr_done = false;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(sk_bwd_kernel, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
+    HIP_TRY(hipGetLastError());
+    const size_t n4 = (size_t)B * d / 4;
+    hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
     HIP_TRY(hipGetLastError());
   }
   return DPRHOT_OK;
@@ -797,6 +896,22 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   REQUIRE(loss_sum && G && dQ && dC_part, "NULL pointer (loss_sum, G, dQ and dC_part are required)");
   REQUIRE(aligned16(G) && aligned16(dQ) && aligned16(dC_part), "pointers must be 16-byte aligned");
   if (int rc = check_shape(B, Nc, d)) return rc;
+  {
+    const SkPlan sk = sk_plan(B, Nc, d);
+    if (sk.ok) {
+      REQUIRE(q && Qb && Cb && y, "NULL pointer");
+      REQUIRE(aligned16(q) && aligned16(Qb) && aligned16(Cb) && (c == nullptr || aligned16(c)) && (S_out == nullptr || aligned16(S_out)),
+              "pointers must be 16-byte aligned");
+      const WsLayout wl = ws_layout(B, Nc, d);
+      if (workspace == nullptr || workspace_bytes < wl.total)
+        return fail(DPRHOT_E_WORKSPACE, "inbatch_step needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+      REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+      if (c != nullptr)  // single rank: the contexts arrive as fp32 -- one cast, then they are the bf16 matrix of every launch
+        if (int rc = dprhot_cast_bf16(c, Cb, (size_t)Nc * d, stream)) return rc;
+      return sk_step(q, Cb, Qb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, h_scale, d_scale, S_out, row_loss, row_lse, loss_sum, G,
+                     dQ, dC_part, static_cast<char*>(workspace), wl, sk, (hipStream_t)stream);
+    }
+  }
   if (!small_step_ok(B, Nc, d)) {
     if (int rc = dprhot_inbatch_fwd_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, S_out, row_loss, row_lse,
                                         loss_sum, G, workspace, workspace_bytes, stream))

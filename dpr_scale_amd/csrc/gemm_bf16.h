@@ -23,8 +23,15 @@ extern __device__ unsigned long long g_dprhot_tm[64];
   do {                                                                                     \
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_dprhot_tm[i] = wall_clock64(); \
   } while (0)
+// per-workgroup stamps (scratch/sk_timing.hip): slot i of workgroup blockIdx.x
+extern __device__ unsigned long long g_dprhot_tmb[4 * 4096 * 8];
+#define DPRHOT_TMB(k, i)                                                                                      \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_dprhot_tmb[((k) * 4096 + blockIdx.x) * 8 + (i)] = wall_clock64(); \
+  } while (0)
 #else
 #define DPRHOT_TM(i) do {} while (0)
+#define DPRHOT_TMB(k, i) do {} while (0)
 #endif
 
 namespace dprhot {

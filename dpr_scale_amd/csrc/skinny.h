@@ -1,0 +1,682 @@
+// skinny.h -- the training step when a rank holds FEW query rows against MANY gathered contexts (B <= 128, Nc in the
+// thousands: BASELINE cfg3 per rank = 128 x 8256 x 768).  dpr_task.py:197-212 and its autograd backward, four launches:
+//
+//   sk_sim_kernel   S = (q x C^T) / T with the column mask (dpr_task.py:98-105,:211), fp32 logits + one logsumexp per
+//                   (row, 128-column tile) + the gold logit                                     [reads C once]
+//   sk_g_kernel     row logsumexp from the tile values, loss, G = (exp(S - lse) - onehot) * scale in bf16
+//   sk_bwd_kernel   dC_part = G^T x Q (128 x 128 units) and split-K partial sums of dQ = G x C (128 x 64 units over a
+//                   slice of contexts) side by side in one launch                               [writes dC, reads C once]
+//   sk_dq_reduce_kernel adds the dQ partials.
+// (A variant that recomputed G inside the dC units -- no sk_g launch, no G round trip -- measured slower: six d tiles per
+//  context tile repeat 16 K exponentials and 33 KB of statistics reads each, 12 us per workgroup against 6.)
+//
+// Why not the gemm_bf16.h engine: at M = 128 every unit of work is a short K loop whose cost is the latency of its
+// dependent loads; a CU needs >= 128 KB of loads in flight to keep its 64 B/clk L2 port busy (Little's law at ~1 us),
+// which register staging cannot hold.  Here every unit puts its WHOLE operand footprint in flight at once: LDS-DMA
+// (global_load_lds_dwordx4) into a ring that covers the unit's K range, fp32 operands (q, the logits) through registers
+// issued before the DMAs.  Waits are counted vmcnt(N) + raw s_barrier, so the tail of the ring stays in flight.
+// Epilogues go through LDS so that every global store is 16 bytes per lane, whole 128-byte lines per row.
+#pragma once
+#include "gemm_bf16.h"
+#include "gemm256.h"
+#include "rowwise.h"
+#include "step_small.h"
+
+namespace dprhot {
+
+constexpr int SK_THREADS = 256;
+constexpr int SK_ROWS = 32;    // query rows of a sim unit
+constexpr int SK_COLS = 128;   // context columns of a sim / dC unit = the statistics tile
+constexpr int SK_KC = 64;      // k per ring slot of the sim kernel
+constexpr int SK_SLOTS = 4;
+constexpr int SK_MAXB = 128;
+constexpr int SK_DN = 128;     // d columns of a dC unit
+constexpr int SK_QN = 64;      // d columns of a dQ unit
+constexpr int SK_QSLOTS = 3;   // ring slots (64 contexts each) of a dQ unit (72 KiB: two workgroups per CU)
+constexpr int SK_MAXG = 16;    // groups of 4 statistics tiles per half row: Nc <= 16384
+
+// bijective XCD-contiguous renumbering: consecutive results run on ONE XCD (workgroup w runs on XCD w % 8)
+__device__ __forceinline__ int sk_xcd_order(int wg, int nwg) {
+  const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+}
+
+template <int N>
+__device__ __forceinline__ void sk_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most n * PER vector-memory operations of this wave are outstanding (n in 0..5)
+template <int PER>
+__device__ __forceinline__ void sk_wait_younger(int n) {
+  switch (n) {
+    case 0: sk_wait_vm<0>(); break;
+    case 1: sk_wait_vm<PER>(); break;
+    case 2: sk_wait_vm<2 * PER>(); break;
+    case 3: sk_wait_vm<3 * PER>(); break;
+    case 4: sk_wait_vm<4 * PER>(); break;
+    default: sk_wait_vm<5 * PER>(); break;
+  }
+}
+__device__ __forceinline__ void sk_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sim + statistics
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkSimArgs {
+  const float* q;        // [B][d] fp32, or nullptr when Qin holds the bf16 rows already
+  const uint16_t* Qin;   // [B][d] bf16 (q == nullptr)
+  const uint16_t* C;     // [Nc][d] bf16
+  uint16_t* Qb;          // bf16 image of q for the backward (q != nullptr), or nullptr
+  int B, Nc, d;
+  const int64_t* y;      // [B]
+  int64_t y_offset;
+  const uint8_t* colmask;  // [Nc] or nullptr
+  float inv_T;
+  float* S;              // [B][Nc]
+  float* tile_lse;       // [ceil(nt/4)][B][4]: logsumexp of row i over the 128 columns of tile t at [t >> 2][i][t & 3]
+  float* gold;           // [B]
+  const uint8_t* packed;   // packed multi-rank layout (EpiSim::mask_at), or nullptr
+  int p_rows_c, p_n_ctx, p_row_bytes;
+};
+
+constexpr int SK_ASTAGE = 2 * SK_ROWS * SK_KC;  // elements: two [32 rows][64 k] images of the q rows
+inline size_t sk_sim_lds() { return (size_t)SK_ASTAGE * 2 + (size_t)SK_SLOTS * SK_COLS * SK_KC * 2; }
+
+// A_F32: q is fp32 (rounded to bf16 right after the loads land; the ct == 0 units also write the bf16 rows to Qb).
+// NCH = d / 64 (compile-time: the q rows of the unit live in registers, one 16-byte bf16 chunk per thread and k chunk).
+// LDS = 72 KiB -> two workgroups per CU: all units of cfg3 per rank (4 x 65 = 260) are resident at once, and one
+// workgroup's MFMA / epilogue overlaps the other's loads.
+template <int NCH, bool A_F32>
+__global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
+  constexpr int D = NCH * SK_KC;
+  constexpr int IPC = SK_COLS * SK_KC * 2 / 1024 / 4;  // DMA instructions per wave and ring slot (4)
+  uint16_t* const Ast = sk_smem;                      // 2 x [32][64]: 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
+  uint16_t* const ring = sk_smem + SK_ASTAGE;         // SK_SLOTS x [128 n][64 k], same swizzle
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nrb = (p.B + SK_ROWS - 1) / SK_ROWS;
+  const int unit = sk_xcd_order(blockIdx.x, gridDim.x);
+  const int rb = unit % nrb, ct = unit / nrb;
+  const int m0 = rb * SK_ROWS, n0 = ct * SK_COLS;
+  DPRHOT_TMB(0, 0);
+
+  // ---- every global read of the unit's first phase, back to back: the q rows (registers: thread t holds the 8 values
+  //      k = kc * 64 + (t & 7) * 8 .. of row t >> 3 for every k chunk kc), the first ring slots, mask bytes, labels
+  const int arow = tid >> 3, ac8 = tid & 7;
+  uint4 areg[NCH][A_F32 ? 2 : 1];
+  {
+    const int gr = min(m0 + arow, p.B - 1);
+#pragma unroll
+    for (int kc = 0; kc < NCH; ++kc) {
+      if constexpr (A_F32) {
+        const float* src = p.q + (size_t)gr * D + kc * SK_KC + ac8 * 8;
+        areg[kc][0] = *reinterpret_cast<const uint4*>(src);
+        areg[kc][1] = *reinterpret_cast<const uint4*>(src + 4);
+      } else {
+        areg[kc][0] = *reinterpret_cast<const uint4*>(p.Qin + (size_t)gr * D + kc * SK_KC + ac8 * 8);
+      }
+    }
+  }
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int srow = tid >> 3, sseg = tid & 7;  // statistics / store phase: 8 threads per row
+
+  unsigned cof[IPC];  // element offset of this lane's source chunk inside a k chunk, per DMA instruction (8 rows of 128 bytes)
+#pragma unroll
+  for (int j = 0; j < IPC; ++j) {
+    const int row = (wave * IPC + j) * 8 + (lane >> 3);
+    cof[j] = (unsigned)min(n0 + row, p.Nc - 1) * (unsigned)D + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+  auto issue = [&](int kc, int slot) {
+    uint16_t* dst = ring + slot * (SK_COLS * SK_KC);
+#pragma unroll
+    for (int j = 0; j < IPC; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + cof[j] + kc * SK_KC), (g2_lds_ptr*)(dst + (wave * IPC + j) * 512), 16, 0, 0);
+  };
+#pragma unroll
+  for (int c = 0; c < SK_SLOTS; ++c)
+    if (c < NCH) issue(c, c);
+  // mask bytes and labels: raw loads only (a select on a loaded value here would park an s_waitcnt in front of everything
+  // that follows); they are turned into what the epilogue needs there
+  // (branch-free: one unconditional byte load per column from a valid address)
+  const bool have_mask = p.packed != nullptr || p.colmask != nullptr;
+  const uint8_t* const mbase = p.packed != nullptr ? p.packed : (p.colmask != nullptr ? p.colmask : reinterpret_cast<const uint8_t*>(p.y));
+  uint8_t mraw[2];
+  bool mover[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = min(n0 + wave * 32 + nb * 16 + i16, p.Nc - 1);
+    const int rc = p.packed != nullptr ? p.p_rows_c : 1;
+    const int r = n / rc, j = n - r * rc;
+    mover[nb] = p.packed != nullptr && j >= p.p_n_ctx;  // mask / padding rows of the packed buffer: always masked
+    const size_t off = p.packed != nullptr ? (size_t)(r * rc + p.p_n_ctx) * p.p_row_bytes + min(j, p.p_n_ctx - 1)
+                                           : (p.colmask != nullptr ? (size_t)n : (size_t)0);
+    mraw[nb] = mbase[off];
+  }
+  // labels are column indices (< 2^31): the low word of the int64 is all that is needed
+  const int yraw = reinterpret_cast<const int*>(p.y)[2 * min(m0 + srow, p.B - 1)];
+
+  DPRHOT_TMB(0, 1);
+  // ---- q rows -> bf16, kept in registers (and written to Qb); one k chunk at a time goes to LDS inside the K loop
+  uint4 abf[NCH];
+#pragma unroll
+  for (int kc = 0; kc < NCH; ++kc) {
+    if constexpr (A_F32) {
+      const uint4 a = areg[kc][0], b = areg[kc][1];
+      abf[kc] = make_uint4(pack_bf16_rne(a.x, a.y), pack_bf16_rne(a.z, a.w), pack_bf16_rne(b.x, b.y), pack_bf16_rne(b.z, b.w));
+      if (p.Qb != nullptr && ct == 0 && m0 + arow < p.B)
+        *reinterpret_cast<uint4*>(p.Qb + (size_t)(m0 + arow) * D + kc * SK_KC + ac8 * 8) = abf[kc];
+    } else {
+      abf[kc] = areg[kc][0];
+    }
+  }
+  DPRHOT_TMB(0, 2);
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    uint16_t* const Ac = Ast + (c & 1) * (SK_ROWS * SK_KC);
+    {
+      // asm store: hipcc orders a plain LDS store behind every LDS-DMA in flight with s_waitcnt vmcnt(0) (it cannot tell the
+      // q image from the ring slots), which would drain the ring at every chunk; sk_barrier() below waits lgkmcnt(0)
+      typedef __attribute__((address_space(3))) uint16_t lds_u16;
+      const unsigned addr = (unsigned)(uintptr_t)(lds_u16*)(Ac + arow * SK_KC + ((ac8 ^ ((arow >> 1) & 7)) << 3));
+      typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
+      const sk_u32x4 val = {abf[c].x, abf[c].y, abf[c].z, abf[c].w};
+      asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(val) : "memory");
+    }
+    sk_wait_younger<IPC>(min(c + SK_SLOTS - 1, NCH - 1) - c);  // this wave's share of chunk c has landed
+    sk_barrier();                                                // ... everybody's has; the q chunk is in place
+    const uint16_t* Bs = ring + (c % SK_SLOTS) * (SK_COLS * SK_KC);
+#pragma unroll
+    for (int kk = 0; kk < SK_KC / 32; ++kk) {
+      bf16x8 af[2], bf[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = a * 16 + i16;
+        af[a] = *reinterpret_cast<const bf16x8*>(Ac + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int row = wave * 32 + b * 16 + i16;
+        bf[b] = *reinterpret_cast<const bf16x8*>(Bs + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (c + SK_SLOTS < NCH) {
+      sk_barrier();  // every wave is done reading this slot
+      issue(c + SK_SLOTS, c % SK_SLOTS);
+    }
+  }
+  sk_barrier();  // the ring is free: slot 0 becomes the fp32 logit tile [32][132]
+  DPRHOT_TMB(0, 3);
+
+  // ---- epilogue: mask, 1/T -> LDS tile -> per-row tile logsumexp, gold logit, coalesced fp32 store
+  constexpr int TS = SK_COLS + 4;
+  float* const T = reinterpret_cast<float*>(ring);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int col = wave * 32 + b * 16 + i16;
+    const bool masked = (n0 + col >= p.Nc) || mover[b] || (have_mask && mraw[b] != 0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(a * 16 + g4 * 4 + r) * TS + col] = masked ? -INFINITY : acc[a][b][r] * p.inv_T;
+  }
+  sk_barrier();
+  {
+    const int row = m0 + srow;
+    const int yi = yraw + (int)p.y_offset - n0;  // gold column relative to the tile
+    float4 v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      v[qd] = *reinterpret_cast<const float4*>(T + srow * TS + (qd * 8 + sseg) * 4);
+      mx = fmaxf(mx, fmaxf(fmaxf(v[qd].x, v[qd].y), fmaxf(v[qd].z, v[qd].w)));
+    }
+    mx = ss_max8(mx);
+    float sm = 0.f;
+    if (mx != -INFINITY) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) sm += __expf(v[qd].x - mx) + __expf(v[qd].y - mx) + __expf(v[qd].z - mx) + __expf(v[qd].w - mx);
+    }
+    sm = ss_sum8(sm);
+    if (row < p.B) {
+      if (sseg == 0) p.tile_lse[((size_t)(ct >> 2) * p.B + row) * 4 + (ct & 3)] = mx == -INFINITY ? -INFINITY : mx + logf(sm);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int col = (qd * 8 + sseg) * 4;
+        if (n0 + col < p.Nc) *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col) = v[qd];
+        if (yi >= col && yi < col + 4) p.gold[row] = yi == col ? v[qd].x : (yi == col + 1 ? v[qd].y : (yi == col + 2 ? v[qd].z : v[qd].w));
+      }
+    }
+  }
+  DPRHOT_TMB(0, 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// row logsumexp, loss, G = (softmax - onehot) * scale   (dpr_task.py:212 and its backward into the scores)
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkGArgs {
+  const float* S;         // [B][Nc]
+  const float* tile_lse;  // [ceil(nt/4)][B][4]
+  const float* gold;      // [B]
+  int nt;
+  int B, Nc;
+  const int64_t* y;
+  int64_t y_offset;
+  float grad_scale;
+  uint16_t* G;            // [B][Nc] bf16
+  float* row_loss;        // optional
+  float* row_lse;         // optional
+  float* loss_sum;        // [1]
+  int parts;              // workgroups per row
+};
+
+// logsumexp of one row from its tile values: 64 lanes of a wave, lane l takes groups l, l + 64 (nt <= 512)
+__device__ __forceinline__ float sk_row_lse(const float* tile_lse, int nt, int B, int row, int lane) {
+  const int ng = (nt + 3) >> 2;
+  float4 tv[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int gq = lane + 64 * u;
+    tv[u] = *reinterpret_cast<const float4*>(tile_lse + ((size_t)(gq < ng ? gq : 0) * B + row) * 4);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = (lane + 64 * u) * 4;
+    tv[u].x = t + 0 < nt ? tv[u].x : -INFINITY;
+    tv[u].y = t + 1 < nt ? tv[u].y : -INFINITY;
+    tv[u].z = t + 2 < nt ? tv[u].z : -INFINITY;
+    tv[u].w = t + 3 < nt ? tv[u].w : -INFINITY;
+    mx = fmaxf(mx, fmaxf(fmaxf(tv[u].x, tv[u].y), fmaxf(tv[u].z, tv[u].w)));
+  }
+  mx = wave_max(mx);
+  float sm = 0.f;
+  if (mx != -INFINITY) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sm += __expf(tv[u].x - mx) + __expf(tv[u].y - mx) + __expf(tv[u].z - mx) + __expf(tv[u].w - mx);
+  }
+  sm = wave_sum(sm);
+  return mx + logf(sm);  // every lane holds the same bits (butterfly reductions)
+}
+
+// grid = B * parts workgroups: workgroup (row, part) turns its share of the row's logits into G.  Every wave derives the
+// row logsumexp itself (<= 2 KB of tile values); workgroup 0 additionally writes row_lse / row_loss / loss_sum for all rows.
+__global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x / p.parts, part = blockIdx.x - row * p.parts;
+  const int cpr = p.Nc >> 3;                       // 8-column chunks per row
+  const int per = (cpr + p.parts - 1) / p.parts;   // chunks of this part
+  const int c_lo = part * per, c_hi = min(cpr, c_lo + per);
+  constexpr int CPT = 4;                           // chunks per thread kept in flight (per <= 1024)
+  float4 va[CPT], vb[CPT];
+  const float* Srow = p.S + (size_t)row * p.Nc;
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int ch = c_lo + tid + k * SK_THREADS;
+    const float* src = Srow + (size_t)(ch < c_hi ? ch : c_lo) * 8;
+    va[k] = *reinterpret_cast<const float4*>(src);
+    vb[k] = *reinterpret_cast<const float4*>(src + 4);
+  }
+  const int yi = reinterpret_cast<const int*>(p.y)[2 * row] + (int)p.y_offset;
+  const float lse = sk_row_lse(p.tile_lse, p.nt, p.B, row, lane);
+#pragma unroll
+  for (int k = 0; k < CPT; ++k) {
+    const int ch = c_lo + tid + k * SK_THREADS;
+    if (ch < c_hi) {
+      const int j = ch * 8;
+      const float v[8] = {va[k].x, va[k].y, va[k].z, va[k].w, vb[k].x, vb[k].y, vb[k].z, vb[k].w};
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float pr = __expf(v[e] - lse);  // exp(-inf) == 0 at masked columns
+        if (j + e == yi) pr -= 1.0f;
+        g[e] = pr * p.grad_scale;
+      }
+      *reinterpret_cast<uint4*>(p.G + (size_t)row * p.Nc + j) = make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
+    }
+  }
+  if (blockIdx.x == 0) {
+    // the loss of ALL rows: thread (row = tid & 127, half = tid >> 7) folds the tile groups half, half + 2, ... of its row
+    // (lanes = rows: coalesced 16-byte loads, all of them in flight at once); the halves meet in LDS; fixed-order sum
+    __shared__ float s_m[SK_MAXB], s_s[SK_MAXB], s_l[SK_MAXB];
+    const int lrow = tid & (SK_MAXB - 1), half = tid >> 7;
+    const bool row_ok = lrow < p.B;
+    const int ng = (p.nt + 3) >> 2;
+    float4 tv[SK_MAXG];
+#pragma unroll
+    for (int u = 0; u < SK_MAXG; ++u) {  // groups beyond ng re-read group 0 (dropped below by the t < nt tests): no branches
+      const int gq = half + 2 * u;
+      tv[u] = *reinterpret_cast<const float4*>(p.tile_lse + ((size_t)(gq < ng ? gq : 0) * p.B + (row_ok ? lrow : 0)) * 4);
+    }
+    const float gold = p.gold[row_ok ? lrow : 0];
+    float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+    for (int u = 0; u < SK_MAXG; ++u) {
+      const int t = (half + 2 * u) * 4;
+      const float a = t + 0 < p.nt ? tv[u].x : -INFINITY, b = t + 1 < p.nt ? tv[u].y : -INFINITY;
+      const float c = t + 2 < p.nt ? tv[u].z : -INFINITY, e = t + 3 < p.nt ? tv[u].w : -INFINITY;
+      tv[u] = make_float4(a, b, c, e);
+      mx = fmaxf(mx, fmaxf(fmaxf(a, b), fmaxf(c, e)));
+    }
+    if (mx != -INFINITY) {
+#pragma unroll
+      for (int u = 0; u < SK_MAXG; ++u) sm += __expf(tv[u].x - mx) + __expf(tv[u].y - mx) + __expf(tv[u].z - mx) + __expf(tv[u].w - mx);
+    }
+    if (half == 1) { s_m[lrow] = mx; s_s[lrow] = sm; }
+    __syncthreads();
+    if (half == 0) {
+      const float m2 = s_m[lrow], s2 = s_s[lrow];
+      const float M = fmaxf(mx, m2);
+      float tot = 0.f;
+      if (M != -INFINITY) tot = sm * __expf(mx - M) + s2 * __expf(m2 - M);
+      const float ls = M + logf(tot);
+      s_l[lrow] = row_ok ? ls - gold : 0.f;
+      if (row_ok) {
+        if (p.row_lse) p.row_lse[lrow] = ls;
+        if (p.row_loss) p.row_loss[lrow] = ls - gold;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float a = s_l[lane] + s_l[lane + 64];
+      a = wave_sum(a);
+      if (lane == 0) p.loss_sum[0] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward GEMMs, one launch: [dQ partial-sum units | dC units]
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkBwdArgs {
+  const uint16_t* G;      // [B][Nc] bf16
+  const uint16_t* Qb;     // [B][d]
+  const uint16_t* C;      // [Nc][d]
+  int B, Nc, d;
+  float h_scale;
+  const float* d_scale;
+  float* dC;              // [Nc][d]
+  const float* loss_sum;  // [1] (sk_g_kernel), read for the stamp
+  int stamp_period, stamp_row;  // > 0: dC[m][0] = loss numerator where m % stamp_period == stamp_row (EpiScaleF32)
+  int ksteps;             // 64-context steps per dQ slice
+  int nslices;
+  float* part;            // [nslices][B][d] dQ partial sums
+  int ndq_pad;            // dQ units rounded up to a multiple of 8 (keeps workgroup % 8 == XCD for the dC units)
+};
+
+constexpr int SK_DC_TS = SK_DN + 4;  // fp32 output tile row stride in LDS
+constexpr int SK_QA = SK_MAXB * 64;  // elements of the G part of a dQ slot  [128 rows][64 k]
+constexpr int SK_QB = 64 * SK_QN;    // elements of the C part of a dQ slot  [64 k][64 n]
+inline size_t sk_bwd_lds() {
+  const size_t dc = (size_t)SK_COLS * SK_DC_TS * sizeof(float);  // dC: epilogue tile (>= G image + Q image)
+  const size_t dq = (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2;
+  return dc > dq ? dc : dq;
+}
+
+// dC unit = 128 contexts x 128 columns of d: dC[ct*128.., dt*128..] = G^T x Q over the B rows (B % 32 == 0).
+// Both operands are "mn-major" (contraction index = row of the matrix in HBM): DMA with the source-side swizzle of
+// gemm_bf16.h (32-byte group cg of row k at cg ^ mswz(k)), fragments through ds_read_b64_tr_b16.
+__device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_t* sk_smem) {
+  constexpr size_t kImg = (size_t)SK_MAXB * SK_COLS;  // elements of one image
+  uint16_t* const Gs = sk_smem;                 // [128 k = query row][128 m = context]
+  uint16_t* const Qs = sk_smem + kImg;          // [128 k = query row][128 n = d column]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ndt = p.d / SK_DN;
+  const int dt = unit % ndt, ct = unit / ndt;
+  const int n0 = ct * SK_COLS, c0 = dt * SK_DN;
+  const int kmax = p.B;  // contraction length
+  DPRHOT_TMB(1, 0);
+  {
+    // one DMA instruction = 4 rows of 256 bytes; lane l: row + (l >> 4), position l & 15
+    const int nins = kmax / 4 / 4;  // per wave and image
+    for (int j = 0; j < nins; ++j) {
+      const int krow = (wave * nins + j) * 4 + (lane >> 4), pos = lane & 15;
+      const int col = ((((pos >> 1) ^ mswz(krow))) << 4) + (pos & 1) * 8;
+      // contexts beyond Nc (ragged last tile) only feed output rows that are never stored: any valid address will do
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.G + (size_t)krow * p.Nc + min(n0 + col, p.Nc - 8)),
+                                       (g2_lds_ptr*)(Gs + (wave * nins + j) * 4 * SK_COLS), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.Qb + (size_t)krow * p.d + c0 + col),
+                                       (g2_lds_ptr*)(Qs + (wave * nins + j) * 4 * SK_DN), 16, 0, 0);
+    }
+  }
+  const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
+  const bool stamp = dt == 0 && p.stamp_period > 0;
+  const float lsum = stamp ? p.loss_sum[0] : 0.f;
+  DPRHOT_TMB(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  DPRHOT_TMB(1, 2);
+
+  // 4 waves as 2 x 2, 64 contexts x 64 d columns each
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kk = 0; kk < kmax / 32; ++kk) {
+    bf16x8 af[4], bf[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) af[a] = load_frag<128, 64, false, true>(Gs, wm * 64 + a * 16, kk, lane);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bf[b] = load_frag<128, 64, false, true>(Qs, wn * 64 + b * 16, kk, lane);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+  __syncthreads();  // the images are dead: the fp32 tile takes their place
+  DPRHOT_TMB(1, 3);
+  float* const T = reinterpret_cast<float*>(sk_smem);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(wm * 64 + a * 16 + g4 * 4 + r) * SK_DC_TS + wn * 64 + b * 16 + i16] = acc[a][b][r] * sc;
+  __syncthreads();
+  DPRHOT_TMB(1, 4);
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int e = tid + it * SK_THREADS, row = e >> 5, cq = e & 31;
+    const int m = n0 + row;
+    if (m < p.Nc) {
+      float4 v = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + cq * 4);
+      if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+      *reinterpret_cast<float4*>(p.dC + (size_t)m * p.d + c0 + cq * 4) = v;
+    }
+  }
+  DPRHOT_TMB(1, 5);
+}
+
+// 64-wide mn-major image [k][64]: two k rows share a 256-byte bank row; the 32 lanes of a transpose read served together
+// touch rows k0..k0+3 and k0+8..k0+11 of one 32-byte column group, so group cg of row k sits at slot cg ^ sk_swz64(k)
+__device__ __forceinline__ int sk_swz64(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }
+
+// dQ unit = (slice of contexts, 64 columns of d), all B rows: partial sum of dQ = G x C over the slice
+__device__ __forceinline__ void sk_dq_unit(const SkBwdArgs& p, int unit, uint16_t* sk_smem) {
+  constexpr int IA = SK_QA * 2 / 1024 / 4;  // DMA instructions per wave and slot: G part (4)
+  constexpr int IB = SK_QB * 2 / 1024 / 4;  //                                      C part (2)
+  constexpr int SLOT = SK_QA + SK_QB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ndt = p.d / SK_QN;
+  const int dt = unit % ndt, ks = unit / ndt;
+  const int c0 = dt * SK_QN;
+  const int nk = (p.Nc + 63) / 64;
+  const int s0 = ks * p.ksteps;
+  const int ns = min(p.ksteps, nk - s0);  // steps of this unit (>= 1 by construction of the grid)
+
+  DPRHOT_TMB(2, 0);
+  // per-lane source coordinates of this wave's DMA instructions (one instruction = 1 KiB = 8 rows of 128 bytes)
+  unsigned arow[IA], bcol[IB];
+  int akin[IA], bk[IB];
+#pragma unroll
+  for (int j = 0; j < IA; ++j) {  // G part: k-major rows, 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
+    const int row = (wave * IA + j) * 8 + (lane >> 3);
+    arow[j] = (unsigned)min(row, p.B - 1) * (unsigned)p.Nc;
+    akin[j] = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
+  }
+#pragma unroll
+  for (int j = 0; j < IB; ++j) {  // C part: k rows of 64 d columns, 32-byte group cg of row k at cg ^ sk_swz64(k)
+    const int krow = (wave * IB + j) * 8 + (lane >> 3), pos = lane & 7;
+    bk[j] = krow;
+    bcol[j] = (unsigned)(c0 + ((((pos >> 1) ^ sk_swz64(krow)) << 4) + (pos & 1) * 8));
+  }
+  auto issue = [&](int s, int slot) {
+    uint16_t* As = sk_smem + slot * SLOT;
+    uint16_t* Bs = As + SK_QA;
+    const int k0 = (s0 + s) * 64;
+#pragma unroll
+    for (int j = 0; j < IA; ++j)  // k beyond Nc (ragged last step): the address stays inside the row; zeroed in LDS below
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.G + arow[j] + min(k0 + akin[j], p.Nc - 8)), (g2_lds_ptr*)(As + (wave * IA + j) * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(k0 + bk[j], p.Nc - 1) * (unsigned)p.d + bcol[j]),
+                                       (g2_lds_ptr*)(Bs + (wave * IB + j) * 512), 16, 0, 0);
+  };
+#pragma unroll
+  for (int s = 0; s < SK_QSLOTS; ++s)
+    if (s < ns) issue(s, s);
+
+  DPRHOT_TMB(2, 1);
+  // 4 waves: 32 rows x 64 columns each
+  const int i16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  for (int s = 0; s < ns; ++s) {
+    sk_wait_younger<IA + IB>(min(s + SK_QSLOTS - 1, ns - 1) - s);
+    const int slot = s % SK_QSLOTS;
+    uint16_t* As = sk_smem + slot * SLOT;
+    const uint16_t* Bs = As + SK_QA;
+    const int kvalid = p.Nc - (s0 + s) * 64;  // < 64 only in the ragged last step of the last slice
+    if (kvalid < 64) {
+      sk_barrier();  // everybody's DMA of this slot has landed before anyone overwrites part of it
+      // zero the k columns beyond Nc of the G part: 128 rows x 8 chunks
+      for (int e = tid; e < SK_MAXB * 8; e += SK_THREADS) {
+        const int row = e >> 3, ch = e & 7;
+        if (ch * 8 >= kvalid) *reinterpret_cast<uint4*>(As + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    sk_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[2], bf[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = wave * 32 + a * 16 + i16;
+        af[a] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
+      }
+      // The transpose reads go through inline asm: hipcc parks an s_waitcnt vmcnt(0) in front of the builtin form whenever an
+      // LDS-DMA is in flight (it cannot tell the slots apart), which would drain the whole ring at every step.  An asm read is
+      // invisible to its counters, hence the explicit lgkmcnt(0) + sched_barrier behind the block (guide section 5.7, form iii).
+      bf16x4 lo[4], hi[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = kk * 32 + g4 * 8 + (i16 >> 2);
+        const unsigned addr = (unsigned)(uintptr_t)(lds_bf16x4*)(Bs + k * SK_QN + ((b ^ sk_swz64(k)) << 4) + (i16 & 3) * 4);
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(lo[b]), "=&v"(hi[b]) : "v"(addr));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        bf16x8 r;
+        r[0] = lo[b][0]; r[1] = lo[b][1]; r[2] = lo[b][2]; r[3] = lo[b][3];
+        r[4] = hi[b][0]; r[5] = hi[b][1]; r[6] = hi[b][2]; r[7] = hi[b][3];
+        bf[b] = r;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (s + SK_QSLOTS < ns) {
+      sk_barrier();
+      issue(s + SK_QSLOTS, slot);
+    }
+  }
+  sk_barrier();
+  DPRHOT_TMB(2, 2);
+  // ---- partial tile [128][64] fp32 through LDS -> 16-byte stores, 256 bytes per row
+  constexpr int TS = SK_QN + 4;
+  float* const T = reinterpret_cast<float*>(sk_smem);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(wave * 32 + a * 16 + g4 * 4 + r) * TS + b * 16 + i16] = acc[a][b][r];
+  sk_barrier();
+  float* out = p.part + (size_t)ks * p.B * p.d;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int e = tid + it * SK_THREADS, row = e >> 4, cq = e & 15;
+    if (row < p.B) *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + cq * 4) = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
+  }
+  DPRHOT_TMB(2, 3);
+}
+
+// Workgroups [0, ndq_pad) are the dQ units (longer: they start first), the rest the dC units; inside each family consecutive
+// unit numbers run on one XCD (units that share a G slice / a G tile meet in one L2).
+__global__ __launch_bounds__(SK_THREADS, 2) void sk_bwd_kernel(SkBwdArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
+  const int b = blockIdx.x;
+  const int ndq = p.nslices * (p.d / SK_QN);
+  if (b < p.ndq_pad) {
+    if (b >= ndq) return;  // padding
+    sk_dq_unit(p, sk_xcd_order(b, ndq), sk_smem);
+  } else {
+    sk_dc_unit(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
+  }
+}
+
+// dQ = scale * sum of the partial slabs.  64 outputs (float4) per workgroup, the slabs dealt to 4 thread groups whose loads are
+// all in flight at once; fixed summation order (bit-reproducible).  nslices <= 64.
+__global__ __launch_bounds__(256) void sk_dq_reduce_kernel(const float* __restrict__ part, int nslices, size_t n4, float h_scale,
+                                                           const float* d_scale, float* __restrict__ out) {
+  __shared__ float4 s_acc[4][64];
+  const int tid = threadIdx.x, o = tid & 63, zg = tid >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + o;
+  const bool ok = idx < n4;
+  float4 v[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int z = zg + 4 * u;
+    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && z < nslices) v[u] = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + idx];
+  }
+  float4 a = v[0];
+#pragma unroll
+  for (int u = 1; u < 16; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+  s_acc[zg][o] = a;
+  __syncthreads();
+  if (zg == 0 && ok) {
+    const float sc = h_scale * (d_scale ? *d_scale : 1.0f);
+    const float4 b = s_acc[1][o], c = s_acc[2][o], e = s_acc[3][o];
+    a.x = ((a.x + b.x) + (c.x + e.x)) * sc;
+    a.y = ((a.y + b.y) + (c.y + e.y)) * sc;
+    a.z = ((a.z + b.z) + (c.z + e.z)) * sc;
+    a.w = ((a.w + b.w) + (c.w + e.w)) * sc;
+    reinterpret_cast<float4*>(out)[idx] = a;
+  }
+}
+
+}  // namespace dprhot

@@ -1,0 +1,60 @@
+// experiment: per-workgroup wall-clock stamps of the skinny.h kernels at the cfg3-per-rank shape (build with hipcc -O3; not shipped)
+#define DPRHOT_TIMING 1
+#include <hip/hip_runtime.h>
+__device__ unsigned long long g_dprhot_tm[64];
+__device__ unsigned long long g_dprhot_tmb[4 * 4096 * 8];
+#include "../dpr_scale_amd/csrc/dprhot.hip"
+#include <algorithm>
+#include <stdio.h>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 128, K = argc > 2 ? atoi(argv[2]) : 8, d = argc > 3 ? atoi(argv[3]) : 768, W = 8;
+  const int n_ctx = B * K;
+  int rows_c; dprhot_packed_rows(n_ctx, d, &rows_c);
+  const int Nc = W * rows_c;
+  float *q, *c, *dq, *dc; uint16_t *Qb, *Cb, *G, *send; int64_t* y; uint8_t* m; float *loss, *lse, *sum, *go; void* ws; size_t wsb;
+  dprhot_workspace_bytes(B, Nc, d, &wsb);
+  CK(hipMalloc(&q, (size_t)B * d * 4)); CK(hipMalloc(&c, (size_t)n_ctx * d * 4)); CK(hipMalloc(&Qb, (size_t)B * d * 2));
+  CK(hipMalloc(&Cb, (size_t)Nc * d * 2)); CK(hipMalloc(&send, (size_t)rows_c * d * 2)); CK(hipMalloc(&G, (size_t)B * Nc * 2));
+  CK(hipMalloc(&dq, (size_t)B * d * 4)); CK(hipMalloc(&dc, (size_t)Nc * d * 4)); CK(hipMalloc(&go, 4));
+  CK(hipMalloc(&y, B * 8)); CK(hipMalloc(&m, n_ctx)); CK(hipMalloc(&loss, B * 4)); CK(hipMalloc(&lse, B * 4)); CK(hipMalloc(&sum, 4)); CK(hipMalloc(&ws, wsb));
+  std::vector<float> h((size_t)n_ctx * d);
+  unsigned s = 12345;
+  for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+  CK(hipMemcpy(q, h.data(), (size_t)B * d * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(c, h.data(), (size_t)n_ctx * d * 4, hipMemcpyHostToDevice));
+  float one = 1.f; CK(hipMemcpy(go, &one, 4, hipMemcpyHostToDevice));
+  std::vector<int64_t> hy(B); for (int i = 0; i < B; ++i) hy[i] = i * K; CK(hipMemcpy(y, hy.data(), B * 8, hipMemcpyHostToDevice)); CK(hipMemset(m, 0, n_ctx));
+  dprhot_pack_ctx(c, m, n_ctx, d, send, nullptr);
+  for (int r = 0; r < W; ++r) CK(hipMemcpy(Cb + (size_t)r * rows_c * d, send, (size_t)rows_c * d * 2, hipMemcpyDeviceToDevice));
+  const char* names[3] = {"sim", "dc ", "dq "};
+  const int nst[3] = {5, 6, 4};
+  std::vector<unsigned long long> t(4 * 4096 * 8);
+  for (int it = 0; it < 4; ++it) {
+    CK(hipMemset(ws, 0, 64));
+    hipMemsetAsync(nullptr, 0, 0, nullptr);
+    unsigned long long* dptr; CK(hipGetSymbolAddress((void**)&dptr, HIP_SYMBOL(g_dprhot_tmb)));
+    CK(hipMemset(dptr, 0, t.size() * 8));
+    int rc = dprhot_inbatch_step_packed_f32(q, Cb, Qb, B, W, 3, n_ctx, d, y, 1.f, 1.f / (W * B), 1.f, go, loss, lse, sum, G, dq, dc, ws, wsb, nullptr);
+    if (rc) { printf("rc=%d %s\n", rc, dprhot_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(t.data(), dptr, t.size() * 8, hipMemcpyDeviceToHost));
+    if (it < 2) continue;
+    for (int k = 0; k < 3; ++k) {
+      unsigned long long t0 = ~0ull, t1 = 0; int nb = 0;
+      for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (r[0]) { ++nb; t0 = std::min(t0, r[0]); t1 = std::max(t1, r[nst[k] - 1]); } }
+      printf("it%d %s: %d workgroups, kernel span %.2f us | ", it, names[k], nb, (t1 - t0) * 0.01);
+      // start offsets and per-phase averages (10 ns ticks)
+      double startavg = 0, startmax = 0; std::vector<double> ph(nst[k], 0.0);
+      for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (!r[0]) continue;
+        const double so = (r[0] - t0) * 0.01; startavg += so; startmax = std::max(startmax, so);
+        for (int i = 1; i < nst[k]; ++i) ph[i] += (r[i] - r[i - 1]) * 0.01; }
+      printf("start avg %.2f max %.2f | phases(avg us):", startavg / nb, startmax);
+      for (int i = 1; i < nst[k]; ++i) printf(" %.2f", ph[i] / nb);
+      double dur = 0; for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (r[0]) dur += (r[nst[k] - 1] - r[0]) * 0.01; }
+      printf(" | wg duration avg %.2f\n", dur / nb);
+    }
+  }
+  float hs; CK(hipMemcpy(&hs, sum, 4, hipMemcpyDeviceToHost)); printf("loss_sum %.4f\n", hs);
+  return 0;
+}
