@@ -12,11 +12,15 @@ launches at N=1.
 N=1 workload = BASELINE.json configs[1]: bert-base shapes, batch 32, 1 positive + 7 negatives, d=768, no
 all-gather.  N>1: the same per-GPU batch on every rank (weak scaling; the global negatives grow with N).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--negatives 7] [--dim 768]
-                  [--driver graph|eager] [--no-cpu-baseline] [--e2e]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--batch B] [--negatives 7] [--dim 768]
+                  [--driver graph|eager] [--no-cpu-baseline] [--no-e2e] [--no-rank-roofline]
 --driver eager: one C-ABI call per stage per step; graph: the step's launches captured once into a HIP graph and
 replayed; auto (default): an untimed probe picks the faster of the two on this box (both rates are reported).
-Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+The K-step timed region (barrier + synchronize on both sides) is repeated R times (default 31) and the MEDIAN is
+reported (min / max next to it): K = 20 steps of ~10 us are a 0.2 ms region, one measurement of it is noise.
+Multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one rank per GPU over RCCL) when it
+is not already running under a launcher; it refuses to run when fewer than N devices are visible.  Under a launcher
+(WORLD_SIZE set) it is one of the ranks:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -40,8 +44,8 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=32, help="queries per GPU")
     ap.add_argument("--negatives", type=int, default=7)
     ap.add_argument("--dim", type=int, default=768)
@@ -49,7 +53,10 @@ def parse():
     ap.add_argument("--driver", choices=["auto", "graph", "eager"], default="auto")
     ap.add_argument("--no-scale-roofline", action="store_true", help="skip the extra 8192x8192 per-kernel roofline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e", action="store_true")
+    ap.add_argument("--repeats", type=int, default=31, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--e2e", action="store_true", help="(default on; kept for compatibility)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the short end-to-end (bert-base towers) block")
+    ap.add_argument("--no-rank-roofline", action="store_true", help="skip the cfg3-per-rank (128 x 8256 x 768) block")
     return ap.parse_args()
 
 
@@ -236,7 +243,7 @@ def time_kernel(hp, fn, reps=50, iters=20, use_graph=True):
     return e0.elapsed_time(e1) * 1e3 / (iters * reps)  # us
 
 
-def cpu_baseline(B, K, d, T, budget_s=12.0):
+def cpu_baseline(B, K, d, T, budget_s=10.0):
     """The plain-C port of the same step (oracle/inbatch_oracle.c) on this box's host cores."""
     from oracle import c_oracle
     from oracle.inbatch_oracle import synth_embeddings
@@ -251,6 +258,54 @@ def cpu_baseline(B, K, d, T, budget_s=12.0):
     el = time.perf_counter() - t0
     return {"value": B * n / el, "unit": "query-passage pairs/s", "cores": int(lib.oracle_num_threads()), "kind": "port",
             "sample": f"{n} steps of the same B={B} K={K} d={d} workload in {el:.1f} s (oracle/inbatch_oracle.c, OpenMP)"}
+
+
+def cpu_baseline_reference(B, K, d, T, budget_s=6.0):
+    """The reference's own formulation (dpr_task.py:197-212: mask.repeat -> matmul -> masked fill -> /T -> CrossEntropyLoss ->
+    backward) in the reference's own library, torch CPU ops, on this box's host cores (oracle/torch_steps.py; /root/reference
+    does not exist on the GPU box, tests/test_oracle_golden.py pins the restatement to the reference's fixtures bit for bit)."""
+    from oracle.inbatch_oracle import synth_embeddings
+    from oracle.torch_steps import time_reference_step
+
+    q, c, y, m = synth_embeddings(1234, B, K, d, "U", False)
+    best = None
+    for nth in sorted({min(8, torch.get_num_threads()), torch.get_num_threads()}):  # SURVEY 8(d): 8 threads; and the box default
+        torch.set_num_threads(nth)
+        med, n = time_reference_step(q, c, y, m, T, budget_s=budget_s / 2)
+        if best is None or med < best[0]:
+            best = (med, n, nth)
+    med, n, nth = best
+    return {"value": B / med, "unit": "query-passage pairs/s", "cores": nth, "kind": "port",
+            "formulation": "reference ops in torch (CPU, fp32): matmul, masked fill, /T, CrossEntropyLoss, autograd backward",
+            "sample": f"median of {n} steps of the same B={B} K={K} d={d} workload ({med * 1e3:.3f} ms/step, torch {torch.__version__}, "
+                      f"{nth} threads)"}
+
+
+def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
+    """Extra information (never `value`): ONE rank's share of BASELINE configs[2] (8 x MI355X, batch 128 per GPU, 8192 global
+    negatives) timed on this GPU -- the gathered packed buffer [W * rows_c, d] is filled locally, then
+    dprhot_inbatch_step_packed_f32 (everything between the all-gather and the reduce-scatter) is replayed.  Algorithmic bytes:
+    SURVEY.md section 8(d), unfused 3-kernel figure with q read as fp32."""
+    hp = HotPathStep(B, K, d, 1.0, W, 0, dev, dist_mode=True)
+    hp.k_pack()
+    for r in range(W):
+        hp.Cb[r * hp.rows_c:(r + 1) * hp.rows_c].copy_(hp.send)
+    torch.cuda.synchronize()
+    us = time_kernel(hp, hp.k_step, reps=20, iters=10)
+    bn, bd, nd = float(B) * hp.Nc, float(B) * d, float(hp.Nc) * d
+    algo = (4 * bd + 2 * nd + 4 * bn) + 6 * bn + (2 * bn + 2 * nd + 4 * bd) + (2 * bn + 2 * bd + 4 * nd)
+    out = {"workload": f"cfg3 per rank: B={B} rows x Nc={hp.Nc} gathered columns (W={W} x {hp.rows_c} packed rows) x d={d}, "
+                       "bf16 contexts resident, fp32 q in, fp32 dQ / dC_part out",
+           "step_us": round(us, 2), "pairs_per_s_per_gpu": round(B / us * 1e6, 1), "bound": "hbm",
+           "algorithmic_bytes": algo, "achieved": round(algo / us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(algo / us * 1e-3 / HBM_PEAK_GBS, 4), "flops": 6 * bn * d,
+           "mfma_frac": round(6 * bn * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+    kfile = os.path.join(ROOT, "profiles", "r02_cfg3rank_kernel_stats.csv")
+    if os.path.isfile(kfile):
+        out["kernel_stats"] = "profiles/r02_cfg3rank_kernel_stats.csv (rocprofv3 --kernel-trace of this very call sequence)"
+    del hp
+    torch.cuda.empty_cache()
+    return out
 
 
 def roofline_at_scale(dev, d, B=8192, Nc=8192):
@@ -292,8 +347,31 @@ def timed_loop(run, steps, W):
     return time.perf_counter() - t0
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` outside a launcher: start N ranks, one per GPU, and relay their output."""
+    import socket
+    import subprocess
+
+    n = torch.cuda.device_count()
+    same_dev = bool(os.environ.get("DPRHOT_SAME_DEVICE"))  # debugging aid: every rank on device 0 over gloo
+    if n < a.gpus and not same_dev:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} requested but only {n} HIP device(s) are visible; refusing to run fewer ranks "
+                         "than asked (a line with a different n_gpus would be a mis-measurement)\n")
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     W = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -303,8 +381,12 @@ def main():
     if os.environ.get("DPRHOT_SAME_DEVICE"):
         local = 0
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    if W > 1:
-        assert a.gpus == W, f"--gpus {a.gpus} but WORLD_SIZE={W}"
+    if a.gpus != W:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={W}: the line would report a different n_gpus than was asked for\n")
+        sys.exit(2)
+    if local >= torch.cuda.device_count():
+        sys.stderr.write(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible\n")
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # debugging aid for one-GPU boxes: DPRHOT_FORCE_DIST=1 runs the N>1 code path (packed layout, collectives, the C ABI
@@ -340,11 +422,14 @@ def main():
 
     for _ in range(a.warmup):
         run()
-    el = timed_loop(run, a.steps, W)
+    # R timed regions of exactly K steps each (barrier + synchronize on both sides), MAX over ranks per region, then the median
+    els = [timed_loop(run, a.steps, W) for _ in range(max(1, a.repeats))]
     if W > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        tt = torch.tensor(els, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = tt.item()
+        els = tt.tolist()
+    els_sorted = sorted(els)
+    el = els_sorted[len(els_sorted) // 2]
 
     out = None
     if rank == 0:
@@ -401,17 +486,45 @@ def main():
                        "driver": driver, "collectives": ("none" if not DM else ("rccl via the C ABI communicator" if comm is not None
                                                                               else "torch.distributed"))},
             "roofline": roof, "kernels": ktimes, "other_driver": alt,
+            "timing": {"repeats": len(els), "steps_per_repeat": a.steps, "statistic": "median",
+                       "ms_per_step_min": round(els_sorted[0] / a.steps * 1e3, 5), "ms_per_step_max": round(els_sorted[-1] / a.steps * 1e3, 5)},
+            "rccl_ranks": W if (DM and backend == "nccl") else 0,
+            "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
         }
         if not DM and not a.no_scale_roofline:
             out["roofline_at_scale"] = roofline_at_scale(dev, d)
+        if not DM and not a.no_rank_roofline and d % 128 == 0:
+            try:
+                out["roofline_cfg3_rank"] = roofline_cfg3_rank(dev, d)
+            except Exception as e:  # extra info only
+                out["roofline_cfg3_rank"] = {"error": repr(e)}
         if not a.no_cpu_baseline and not DM:
             out["cpu_baseline"] = cpu_baseline(B, K, d, T)
-    if a.e2e and W == 1:
+            out["cpu_baseline_reference"] = cpu_baseline_reference(B, K, d, T)
+    if not a.no_e2e and d == 768:
+        # the END-TO-END number of the north star (bert-base towers, seq_len 256): short, extra information, never `value`.
+        # A watchdog prints the line without it if the leg does not come back (a rank lost in a collective must not cost
+        # the measured line).
+        import threading
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out["end_to_end"] = {"error": "timed out"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(240.0, give_up)
+        wd.daemon = True
+        wd.start()
         try:
             from bench_e2e import end_to_end
-            out["end_to_end"] = end_to_end(B, K, d, T, dev)
+            e2e = end_to_end(B, K, d, T, dev, steps=5, warmup=3, world=W, rank=rank)
+            if out is not None:
+                out["end_to_end"] = e2e
         except Exception as e:  # extra info only
-            out["end_to_end"] = {"error": repr(e)}
+            if out is not None:
+                out["end_to_end"] = {"error": repr(e)}
+        wd.cancel()
     # RCCL prints its version banner through C stdio (fully buffered on a pipe: it would surface at process exit, AFTER a
     # line printed from Python).  Every rank pushes its buffers out before the last barrier; rank 0 prints after it, so
     # the JSON line is the last line on the shared stdout.

@@ -6,7 +6,7 @@
 //                             for softmax-CE, dScores, dQ and dC (step_small.h); elsewhere = the two calls below
 //   dprhot_inbatch_fwd(_f32)  2 launches: sim GEMM (+mask, 1/T, softmax statistics or K-split slabs) -> G + loss
 //   dprhot_inbatch_bwd        1 launch: dC_part = G^T Q and dQ = G C side by side (+1 when dQ is split over Nc)
-//   few rows x many contexts (B <= 128, Nc >= 1024: cfg3 / cfg5 per rank): the four launches of skinny.h (sk_plan)
+//   few rows x many contexts (B <= 128, Nc >= 2048: cfg3 per rank): the four launches of skinny.h (sk_plan)
 // Plans (tile, split-K, kernel family) are pure functions of the shape: pick_tile / fwd_plan / dq_plan / big_ok /
 // big_bwd_ok / small_step_ok below.
 #include "../../include/dprhot.h"
@@ -322,22 +322,27 @@ DqPlan dq_plan(int B, int Nc, int d) {
 
 int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
 
-// Few query rows against many contexts (skinny.h): B <= 128, d a multiple of 128 up to 1024, 1024 <= Nc <= 16384
+// Few query rows against many contexts (skinny.h): B <= 128 (a multiple of 32), d a multiple of 128 up to 1024, 2048 <= Nc <= 16384
+// (measured: at Nc ~ 1000 the short-row plan below is as fast or faster)
 // (beyond that the per-unit recomputation of the row logsumexp from Nc / 128 tile values stops being cheap).
 struct SkPlan { bool ok; int nt, nrb, ksteps, nslices; };
 SkPlan sk_plan(int B, int Nc, int d) {
   static const bool off = getenv("DPRHOT_NO_SKINNY") != nullptr;
-  static const int min_nc = []() { const char* e = getenv("DPRHOT_SKINNY_MIN_NC"); return e ? atoi(e) : 1024; }();
+  static const int min_nc = []() { const char* e = getenv("DPRHOT_SKINNY_MIN_NC"); return e ? atoi(e) : 2048; }();
   SkPlan p{};
   p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
          Nc <= 16384 && !(B <= SS_ROWS && Nc <= SS_MAXNC);
   p.nt = cdiv(Nc, SK_COLS);
   p.nrb = cdiv(B, SK_ROWS);
   const int nk = cdiv(Nc, 64), ndt = d / SK_QN;
-  int ns = kNumCU / ndt;  // dQ units: (slice of contexts) x (64 columns of d), at most one per CU
-  if (ns < 1) ns = 1;
+  int ns = kNumCU / 2 / ndt;  // dQ units: (slice of contexts) x (64 columns of d); ~half a unit per CU measured best: the
+  if (ns < 1) ns = 1;         // units run next to the dC units, and fewer slices mean fewer partial sums to write and re-read
   if (ns > 64) ns = 64;   // bounds the fp32 partial traffic
   p.ksteps = cdiv(nk, ns);
+  {
+    static const int forced = []() { const char* e = getenv("DPRHOT_SK_KSTEPS"); return e ? atoi(e) : 0; }();  // tuning aid
+    if (forced > 0 && cdiv(nk, forced) <= 64) p.ksteps = forced;
+  }
   p.nslices = cdiv(nk, p.ksteps);
   return p;
 }
@@ -474,7 +479,8 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   if (rc) return rc;
   {
     const int parts = B >= 128 ? 2 : (B >= 64 ? 4 : 8);  // >= 256 workgroups; a part is at most 4 x 256 chunks of 8 columns
-    int pp = parts;
+    static const int gp = []() { const char* e = getenv("DPRHOT_SK_GPARTS"); return e ? atoi(e) : 0; }();  // tuning aid
+    int pp = gp > 0 ? gp : parts;
     while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
     SkGArgs g{S, tile_lse, gold, sk.nt, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
     hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp)), dim3(SK_THREADS), 0, st, g);

@@ -115,10 +115,15 @@ class DenseRetrieverTask(LightningModule):
         self.setup("fit")  # modules must exist before Lightning restores the state dict
 
     def on_pretrain_routine_start(self):
+        """Reference :90-92: `fp16_grads` registers torch's fp16_compress_hook (one half-precision ring all-reduce per
+        bucket).  Here the same switch registers dpr_scale_amd.comm_hooks.compressed_allreduce_hook: half the bytes on the
+        wire as well, but as an all-pairs exchange with fp32 accumulation (7 xGMI links per GPU instead of a one-link
+        ring); bf16 on the wire by default, DPRHOT_GRAD_WIRE=fp16 for the reference's format, DPRHOT_GRAD_MODE=ring for
+        its decomposition."""
         if self.fp16_grads:
-            from torch.distributed.algorithms.ddp_comm_hooks.default_hooks import fp16_compress_hook
+            from .. import comm_hooks
 
-            self.trainer.strategy._model.register_comm_hook(None, fp16_compress_hook)
+            self.grad_comm_state = comm_hooks.register(self.trainer.strategy._model, comm_hooks.GradCommState.from_env())
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, **kwargs):

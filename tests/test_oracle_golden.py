@@ -116,3 +116,19 @@ def test_bf16_helpers_roundtrip():
     assert np.array_equal(O.from_bf16_bits(O.to_bf16_bits(x)), r)
     assert np.array_equal(O.bf16_round(r), r)
     assert np.abs(r - x).max() <= np.abs(x).max() * 2 ** -8
+
+
+@pytest.mark.parametrize("name", golden_names("cfg1") + golden_names("cfg2"))
+def test_torch_ops_restatement_is_bit_identical_to_the_reference_fixture(name):
+    """oracle/torch_steps.py (bench.py's `cpu_baseline_reference` leg: dpr_task.py:197-212 in torch CPU ops) against the
+    loss / q.grad / c.grad the reference itself produced: same library, same op order -> the same bits."""
+    import torch
+
+    from oracle.torch_steps import reference_step_torch
+
+    meta, g = load_golden(name)
+    _, Q, C, y, m = _global_inputs(meta)
+    torch.set_num_threads(8)
+    loss, dq, dc = reference_step_torch(torch.from_numpy(Q), torch.from_numpy(C), torch.from_numpy(y), torch.from_numpy(m), meta["T"])
+    assert abs(loss.item() - g["loss"]) <= 1e-6 * max(1.0, abs(g["loss"]))
+    assert rel(dq.numpy(), g["dQ"]) <= 1e-6 and rel(dc.numpy(), g["dC"]) <= 1e-6

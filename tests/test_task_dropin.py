@@ -174,3 +174,25 @@ def test_cfg1_plumbing_run_gpu(tmp_path):
 
     _, t2, _, _ = run_fit("cpu", OracleKernels(), tmp_path / "cpu")
     assert abs(trainer.train_losses[0] - t2.train_losses[0]) <= 2e-3 * max(1.0, abs(t2.train_losses[0]))
+
+
+def test_fp16_grads_registers_the_xgmi_gradient_hook():
+    """dpr_task.py:90-92: fp16_grads -> a DDP communication hook on trainer.strategy._model; here the all-pairs-exchange hook
+    of dpr_scale_amd.comm_hooks, configured by DPRHOT_GRAD_* like the reference's is by nothing."""
+    from types import SimpleNamespace
+
+    from dpr_scale_amd import comm_hooks
+    from dpr_scale_amd.task.dpr_task import DenseRetrieverTask
+
+    calls = []
+    model = SimpleNamespace(register_comm_hook=lambda state, hook: calls.append((state, hook)))
+    task = DenseRetrieverTask(None, None, None, None, fp16_grads=True)
+    task.trainer = SimpleNamespace(strategy=SimpleNamespace(_model=model))
+    task.on_pretrain_routine_start()
+    assert len(calls) == 1 and calls[0][1] is comm_hooks.compressed_allreduce_hook
+    st = calls[0][0]
+    assert isinstance(st, comm_hooks.GradCommState) and st.mode == "direct" and str(st.wire_dtype) == "torch.bfloat16"
+    task2 = DenseRetrieverTask(None, None, None, None, fp16_grads=False)
+    task2.trainer = task.trainer
+    task2.on_pretrain_routine_start()
+    assert len(calls) == 1
