@@ -281,6 +281,26 @@ def cpu_baseline_reference(B, K, d, T, budget_s=6.0):
                       f"{nth} threads)"}
 
 
+def roofline_router(dev, B=128, K=8, d=30528):
+    """Extra information (never `value`): the CITADEL router loss (citadel_task.py:249-262) is the same Q x C^T +
+    CrossEntropyLoss on vocabulary-wide vectors (d = 30522, zero-padded to 30528): the one shape of the reference where the
+    step is MFMA-bound.  One in-batch step (forward + backward), per launch and as a whole."""
+    hp = HotPathStep(B, K, d, 1.0, 1, 0, dev)
+    bn = float(B) * hp.Nc
+    out = {"workload": f"router vectors: B={B} x Nc={hp.Nc} x d={d} (30522 padded), fp32 in, one in-batch step"}
+    tot = 0.0
+    for name, fn, fl in (("sim_stats_f32", hp.k_sim32, 2 * bn * d), ("softmax_finish", hp.k_softmax, 0.0), ("bwd_pair", hp.k_bwd, 4 * bn * d)):
+        us = time_kernel(hp, fn, reps=10, iters=5)
+        tot += us
+        out[name] = {"us": round(us, 2), "TFLOPs": round(fl / us * 1e-6, 1), "mfma_frac": round(fl / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+    step = time_kernel(hp, hp.k_step, reps=10, iters=5)
+    out.update({"step_us": round(step, 2), "bound": "mfma", "achieved": round(6 * bn * d / step * 1e-6, 1), "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(6 * bn * d / step * 1e-6 / MFMA_PEAK_TFLOPS, 4)})
+    del hp
+    torch.cuda.empty_cache()
+    return out
+
+
 def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
     """Extra information (never `value`): ONE rank's share of BASELINE configs[2] (8 x MI355X, batch 128 per GPU, 8192 global
     negatives) timed on this GPU -- the gathered packed buffer [W * rows_c, d] is filled locally, then
@@ -498,10 +518,15 @@ def main():
                 out["roofline_cfg3_rank"] = roofline_cfg3_rank(dev, d)
             except Exception as e:  # extra info only
                 out["roofline_cfg3_rank"] = {"error": repr(e)}
+        if not DM and not a.no_rank_roofline:
+            try:
+                out["router"] = roofline_router(dev)
+            except Exception as e:  # extra info only
+                out["router"] = {"error": repr(e)}
         if not a.no_cpu_baseline and not DM:
             out["cpu_baseline"] = cpu_baseline(B, K, d, T)
             out["cpu_baseline_reference"] = cpu_baseline_reference(B, K, d, T)
-    if not a.no_e2e and d == 768:
+    if not a.no_e2e and d == 768 and (W == 1 or backend == "nccl"):
         # the END-TO-END number of the north star (bert-base towers, seq_len 256): short, extra information, never `value`.
         # A watchdog prints the line without it if the leg does not come back (a rank lost in a collective must not cost
         # the measured line).

@@ -93,7 +93,7 @@ def end_to_end(B, K, d, T, dev, seq_len=256, steps=5, warmup=3, world=1, rank=0)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        return (time.perf_counter() - t0) / steps, float(loss)
+        return (time.perf_counter() - t0) / steps, float(loss.detach())
 
     t_ours, l_ours = run(ours)
     out = {"workload": f"2 x bert-base (random init), seq_len={seq_len}, B={B} per GPU, K={K}, bf16 autocast, AdamW, {world} GPU(s)",

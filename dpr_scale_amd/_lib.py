@@ -62,6 +62,8 @@ SIGNATURES = {
     "dprhot_inbatch_step_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float,
                                                c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_pairwise_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dprhot_pairwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dprhot_comm_unique_id": (c_int, [c_void_p]),
     "dprhot_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "dprhot_comm_destroy": (c_int, [c_void_p]),

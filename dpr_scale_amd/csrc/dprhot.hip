@@ -347,6 +347,9 @@ SkPlan sk_plan(int B, int Nc, int d) {
   return p;
 }
 
+struct FwdPlan { bool short_rows; int tile, splits, kchunk, nt, tpr, cpt, threads, blocks; };
+FwdPlan fwd_plan(int B, int Nc, int d);
+
 // workspace carve-up (all offsets 256-byte aligned)
 struct WsLayout {
   size_t header, gold, part_m, part_s, logits, dq_part, total;
@@ -359,7 +362,11 @@ WsLayout ws_layout(int B, int Nc, int d) {
   w.gold = off; off += align256((size_t)B * 4);
   w.part_m = off; off += align256((size_t)B * ntmax * 4);
   w.part_s = off; off += align256((size_t)B * ntmax * 4);
-  w.logits = off; off += align256((size_t)B * Nc * 4 * ((Nc <= 4096 && B <= 64) ? 4 : 1));  // short rows: up to 4 split-K slabs
+  {
+    const FwdPlan fp = fwd_plan(B, Nc, d);  // short rows: split-K slabs of partial logits (4, or up to 32 for wide vectors)
+    const size_t slabs = (Nc <= 4096 && (B <= 64 || fp.short_rows)) ? (size_t)(fp.short_rows && fp.splits > 4 ? fp.splits : 4) : 1;
+    w.logits = off; off += align256((size_t)B * Nc * 4 * slabs);
+  }
   const DqPlan p = dq_plan(B, Nc, d);
   const SkPlan sk = sk_plan(B, Nc, d);
   const int slabs = sk.ok && sk.nslices > p.splits ? sk.nslices : p.splits;
@@ -371,14 +378,16 @@ WsLayout ws_layout(int B, int Nc, int d) {
 // Forward plan, a pure function of the shape (both forward launches derive it independently).
 //  short rows (the BASELINE training shapes): sim split over K into `splits` slabs, softmax with the row in registers
 //  long rows: sim with per-tile statistics, then the streaming gfinal kernel
-struct FwdPlan { bool short_rows; int tile, splits, kchunk, nt, tpr, cpt, threads, blocks; };
 bool no_short() {
   static const bool v = []() { const char* e = getenv("DPRHOT_NO_SHORT"); return e && e[0] == '1'; }();
   return v;
 }
 FwdPlan fwd_plan(int B, int Nc, int d) {
   FwdPlan p{};
-  p.short_rows = Nc <= 4096 && B <= 64 && !no_short() && force_tile() < 0;
+  // wide: vocabulary-wide vectors (CITADEL router, d = 30522): the contraction is long and the logit matrix small -- the
+  // K range is what has to be spread over the chip (B = 128, Nc = 1024 are only 32 tiles of 64 x 64)
+  const bool wide = d >= 4096 && Nc <= 4096 && B <= 256;
+  p.short_rows = Nc <= 4096 && (B <= 64 || wide) && !no_short() && force_tile() < 0;
   if (!p.short_rows) {
     p.tile = (force_tile() < 0 && big_ok(B, Nc, d)) ? kBigTile : pick_tile(B, Nc, d, 1, 2 * kNumCU);
     p.splits = 1;
@@ -389,6 +398,13 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
   p.tile = B <= 32 ? (d >= 256 ? 5 : 3) : 2;
   const int bk = kTiles[p.tile].bk, ksteps = cdiv(d, bk);
   int splits = ksteps < 4 ? ksteps : 4;
+  if (wide) {  // >= 2 workgroups per CU, at least 4 K steps each, at most 32 slabs of partial logits
+    const int per_split = cdiv(B, kTiles[p.tile].bm) * cdiv(Nc, kTiles[p.tile].bn);
+    splits = cdiv(2 * kNumCU, per_split);
+    if (splits > ksteps / 4) splits = ksteps / 4;
+    if (splits > 32) splits = 32;
+    if (splits < 4) splits = 4;
+  }
   // 512 < Nc <= SS_MAXNC (the BASELINE shape gathered over 2..4 ranks): enough column tiles without a K split, and
   // every workgroup of the fused softmax+backward kernel that follows re-reads the logits -- one slab, not four
   if (B <= SS_ROWS && Nc > 512 && Nc <= SS_MAXNC) splits = 1;
@@ -648,6 +664,23 @@ int dprhot_rank_of_gold(const float* S, int rows, int cols, const int64_t* y, in
   return DPRHOT_OK;
 }
 
+int dprhot_pairwise_fwd(const float* q, const float* c, const uint8_t* mask, int B, int M, int d, float* S, void* stream) {
+  REQUIRE(q && c && S, "NULL pointer");
+  REQUIRE(B > 0 && M > 0 && d > 0, "bad shape B=%d M=%d d=%d", B, M, d);
+  REQUIRE((long)B * M <= 0x7fffffffL, "too many pairs");
+  hipLaunchKernelGGL(pairwise_fwd_kernel, dim3((unsigned)(B * M)), dim3(256), 0, (hipStream_t)stream, q, c, mask, B, M, d, S);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_pairwise_bwd(const float* g, const float* q, const float* c, int B, int M, int d, float* dq, float* dc, void* stream) {
+  REQUIRE(g && q && c, "NULL pointer");
+  REQUIRE(B > 0 && M > 0 && d > 0 && B <= 65535, "bad shape B=%d M=%d d=%d", B, M, d);
+  hipLaunchKernelGGL(pairwise_bwd_kernel, dim3((unsigned)cdiv(d, 512), (unsigned)B), dim3(256), 0, (hipStream_t)stream, g, q, c, B, M, d, dq, dc);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values,
                        int64_t* indices, int first, void* stream) {
   REQUIRE(S && values && indices, "NULL pointer");
@@ -892,7 +925,8 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
 // every other shape runs the three launches of dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd.
 static bool small_step_ok(int B, int Nc, int d) {
   static const bool off = getenv("DPRHOT_NO_SMALL_STEP") != nullptr;
-  return !off && B <= SS_ROWS && Nc <= SS_MAXNC && d % 16 == 0 && fwd_plan(B, Nc, d).short_rows && !unfused_bwd();
+  const FwdPlan fp = fwd_plan(B, Nc, d);
+  return !off && B <= SS_ROWS && Nc <= SS_MAXNC && d % 16 == 0 && fp.short_rows && fp.splits <= 4 && !unfused_bwd();
 }
 
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,

@@ -604,6 +604,71 @@ __global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, 
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Pairwise scores (citadel_task.py:137-146, `sim_score(..., pairwise=True)`): query b against its OWN M contexts only,
+//   S[b][j] = sum_k q[b][k] * c[b*M + j][k]        (fp32 in, fp32 accumulate; masked pairs -> -inf)
+// and its backward  dq[b] = sum_j g[b][j] * c[b*M + j],  dc[b*M + j] = g[b][j] * q[b].
+// Router vectors are vocabulary-wide (d = 30522): these are pure HBM streams (8 bytes per multiply-add), no GEMM.
+// Rows are only guaranteed 8-byte aligned (d even) -> float2 accesses; odd d takes the scalar tail path throughout.
+// ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pairwise_fwd_kernel(const float* __restrict__ q, const float* __restrict__ c,
+                                                           const uint8_t* __restrict__ mask, int B, int M, int d, float* __restrict__ S) {
+  const int pair = blockIdx.x, b = pair / M;
+  const float* qr = q + (size_t)b * d;
+  const float* cr = c + (size_t)pair * d;
+  float acc = 0.f;
+  if ((d & 1) == 0) {
+    const int d2 = d >> 1;
+    for (int k = threadIdx.x; k < d2; k += 256) {
+      const float2 a = reinterpret_cast<const float2*>(qr)[k], e = reinterpret_cast<const float2*>(cr)[k];
+      acc = fmaf(a.x, e.x, acc);
+      acc = fmaf(a.y, e.y, acc);
+    }
+  } else {
+    for (int k = threadIdx.x; k < d; k += 256) acc = fmaf(qr[k], cr[k], acc);
+  }
+  __shared__ float sm[4];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) S[pair] = (mask != nullptr && mask[pair] != 0) ? -INFINITY : (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// grid (ceil(d / 512), B): thread t owns columns 2 t, 2 t + 1 of its 512-column slab for all M contexts of query b
+__global__ __launch_bounds__(256) void pairwise_bwd_kernel(const float* __restrict__ g, const float* __restrict__ q,
+                                                           const float* __restrict__ c, int B, int M, int d, float* __restrict__ dq,
+                                                           float* __restrict__ dc) {
+  const int b = blockIdx.y;
+  const int k0 = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (k0 >= d) return;
+  const bool two = k0 + 1 < d, vec = (d & 1) == 0;
+  const float* qr = q + (size_t)b * d;
+  float q0 = qr[k0], q1 = two ? qr[k0 + 1] : 0.f;
+  float a0 = 0.f, a1 = 0.f;
+  for (int j = 0; j < M; ++j) {
+    const float gj = g[(size_t)b * M + j];  // 0 at masked pairs (the caller zeroes them: -inf carries no gradient)
+    const size_t row = ((size_t)b * M + j) * d;
+    float c0, c1 = 0.f;
+    if (vec) {
+      const float2 v = *reinterpret_cast<const float2*>(c + row + k0);
+      c0 = v.x; c1 = v.y;
+    } else {
+      c0 = c[row + k0];
+      if (two) c1 = c[row + k0 + 1];
+    }
+    a0 = fmaf(gj, c0, a0);
+    a1 = fmaf(gj, c1, a1);
+    if (dc != nullptr) {
+      if (vec) *reinterpret_cast<float2*>(dc + row + k0) = make_float2(gj * q0, gj * q1);
+      else { dc[row + k0] = gj * q0; if (two) dc[row + k0 + 1] = gj * q1; }
+    }
+  }
+  if (dq != nullptr) {
+    dq[(size_t)b * d + k0] = a0;
+    if (two) dq[(size_t)b * d + k0 + 1] = a1;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Streaming top-k per row (torch.topk of run_retrieval_pytorch.py:149-150,156-157, and its shard re-merge
 // :272-277), in the total order (score desc, column asc).  State = the k best so far, sorted, in HBM
 // ([rows][k] values + int64 columns); one workgroup per row folds one chunk of columns into it:
@@ -611,14 +676,14 @@ __global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ S, 
 //   append the values that beat the current k-th entry to an LDS buffer, and whenever the buffer fills up
 //   bitonic-sort buffer + state (2048 slots) and keep the k best -- the threshold only ever rises, so after the
 //   first windows almost nothing is appended and the kernel is a pure stream over the scores.
-// Exact and deterministic (the buffer order is arbitrary, the sort is by the total order).  k <= 128.
+// Exact and deterministic (the buffer order is arbitrary, the sort is by the total order).  k <= 1024.
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool tk_before(float v1, long long j1, float v2, long long j2) {  // (v1,j1) ranks ahead of (v2,j2)
   return v1 > v2 || (v1 == v2 && j1 < j2);
 }
 
-constexpr int TK_P = 2048;           // sort size
-constexpr int TK_KMAX = 128;
+constexpr int TK_P = 4096;           // sort size
+constexpr int TK_KMAX = 1024;        // run_retrieval_pytorch.py takes any --topk; dragon/README recipes use 1000
 constexpr int TK_CAP = TK_P - TK_KMAX;  // candidate slots
 constexpr int TK_WIN = 8;            // 1024-column steps per window
 
@@ -661,7 +726,7 @@ __device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cn
 __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
   __shared__ float sv[TK_P];
   __shared__ long long si[TK_P];
-  __shared__ int s_cnt, s_win;
+  __shared__ int s_cnt, s_win2[2];  // window counters alternate: the reset of one never races the adds into the other
   const int row = blockIdx.x, tid = threadIdx.x, k = p.k;
   const float* Srow = p.S + (size_t)row * p.ld;
   const int* Jrow = p.cand_j != nullptr ? p.cand_j + (size_t)row * p.ld : nullptr;
@@ -672,13 +737,14 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
     sv[i] = (p.first || j < 0) ? -INFINITY : p.vals[(size_t)row * k + i];
     si[i] = j < 0 ? 0x7fffffffffffffffLL : j;
   }
-  if (tid == 0) { s_cnt = 0; s_win = 0; }
+  if (tid == 0) { s_cnt = 0; s_win2[0] = 0; s_win2[1] = 0; }
   __syncthreads();
   if (p.cnt != nullptr && tid == 0) p.cnt[row] = 0;
   float tv = sv[k - 1];
   long long ti = si[k - 1];
   const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.S) & 15) == 0);
-  for (int base = 0; base < ncols; base += TK_WIN * 1024) {
+  int wpar = 0;
+  for (int base = 0; base < ncols; base += TK_WIN * 1024, wpar ^= 1) {
     float v[TK_WIN][4];
     int cj[TK_WIN][4];  // column of each value (implicit for a score matrix, loaded for a candidate list)
     int mine = 0;
@@ -706,11 +772,11 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) mine += tk_before(v[w][e], p.col_offset + cj[w][e], tv, ti) ? 1 : 0;
     }
-    if (mine) atomicAdd(&s_win, mine);
+    if (mine) atomicAdd(&s_win2[wpar], mine);
     __syncthreads();
-    const int win = s_win, cnt0 = s_cnt;
+    const int win = s_win2[wpar], cnt0 = s_cnt;
+    if (tid == 0) s_win2[wpar ^ 1] = 0;  // the OTHER counter (next window's): nobody touches it before the next barrier pair
     __syncthreads();
-    if (tid == 0) s_win = 0;
     if (win == 0) continue;  // (uniform) the common case once the threshold has risen
     if (cnt0 + win <= TK_CAP) {
 #pragma unroll

@@ -249,6 +249,24 @@ class HipKernels:
                                            self._stream()), "dprhot_dc")
         return out
 
+    def pairwise_fwd(self, q, c, m8):
+        self._require_gpu(q, c, m8)
+        B, d = q.shape
+        M = c.shape[0] // B
+        S = torch.empty((B, M), dtype=torch.float32, device=q.device)
+        self._lib.check(self.lib.dprhot_pairwise_fwd(_ptr(q), _ptr(c), _ptr(m8), B, M, d, _ptr(S), self._stream()), "dprhot_pairwise_fwd")
+        return S
+
+    def pairwise_bwd(self, g, q, c, need_dq=True, need_dc=True):
+        self._require_gpu(g, q, c)
+        B, d = q.shape
+        M = c.shape[0] // B
+        dq = torch.empty_like(q) if need_dq else None
+        dc = torch.empty_like(c) if need_dc else None
+        self._lib.check(self.lib.dprhot_pairwise_bwd(_ptr(g), _ptr(q), _ptr(c), B, M, d, _ptr(dq), _ptr(dc), self._stream()),
+                        "dprhot_pairwise_bwd")
+        return dq, dc
+
     def rank_of_gold(self, S, y, y_offset=0):
         self._require_gpu(S, y)
         rows, cols = S.shape
@@ -548,12 +566,9 @@ def windowed_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, kernels=
     return WindowedContrastive.apply(q, c, pos_idx, ctx_mask, temperature, kernels)
 
 
-# ---- forward-only helpers used by the task's eval path -------------------------------------------------
-def sim_score(q, c, colmask=None, inv_T=1.0, kernels=None):
-    """dpr_task.py:98-105 on the device: fp32 logits [Nq, Nc] from fp32/bf16 embeddings; colmask is the [Nc]
-    dummy-context mask (the row the reference broadcasts at :197)."""
-    kn = kernels if kernels is not None else default_kernels()
-    q, c = _pad_hidden(q, c)
+# ---- scoring helpers used by the task's eval path and by subclasses that train through sim_score ----------------
+def _sim_fwd(kn, q, c, colmask, inv_T):
+    """(S, Qb, Cb, Nc) -- fp32 logits [Nq, Nc_pad] and the bf16 operand images (the backward of SimScore re-uses them)."""
     Nc = c.shape[0]
     Nc_pad = _pad_cols(Nc)
     Qb = kn.empty(tuple(q.shape), _BF16, q)
@@ -568,8 +583,79 @@ def sim_score(q, c, colmask=None, inv_T=1.0, kernels=None):
         if Nc_pad != Nc:
             Cb[Nc:].zero_()
             m8[Nc:] = 1
-    S = kn.sim(Qb, Cb, m8, inv_T)
-    return S if Nc_pad == Nc else S[:, :Nc]
+    return kn.sim(Qb, Cb, m8, inv_T), Qb, Cb, Nc
+
+
+class SimScore(torch.autograd.Function):
+    """scores = sim_score(q, c, colmask) * inv_T with gradients (dpr_task.py:98-105 is a differentiable torch.matmul):
+    backward dq = inv_T * dS x C, dc = inv_T * dS^T x Q on the HIP backward GEMMs.  The incoming dS is rounded to bf16 for the
+    MFMA operands, exactly like the dScores of the fused training step; masked columns receive no gradient (the reference's
+    index-put leaves them out of the graph as well)."""
+
+    @staticmethod
+    def forward(ctx, q, c, colmask, inv_T, kernels):
+        kn = kernels if kernels is not None else default_kernels()
+        S, Qb, Cb, Nc = _sim_fwd(kn, q.detach(), c.detach(), colmask, inv_T)
+        ctx.kn, ctx.Nc, ctx.inv_T, ctx.in_dtypes = kn, Nc, float(inv_T), (q.dtype, c.dtype)
+        ctx.save_for_backward(Qb, Cb, colmask)
+        return S if S.shape[1] == Nc else S[:, :Nc]
+
+    @staticmethod
+    def backward(ctx, dS):
+        Qb, Cb, colmask = ctx.saved_tensors
+        kn, Nc = ctx.kn, ctx.Nc
+        G = kn.empty((dS.shape[0], Cb.shape[0]), _BF16, dS)
+        if Cb.shape[0] != Nc:
+            G[:, Nc:].zero_()
+        g = dS.detach().float()
+        if colmask is not None:
+            g = g.masked_fill(colmask.bool()[None, :], 0.0)
+        G[:, :Nc].copy_(g)
+        dq = dc = None
+        if ctx.needs_input_grad[0]:
+            dq = kn.dq(G, Cb, ctx.inv_T).to(ctx.in_dtypes[0])
+        if ctx.needs_input_grad[1]:
+            dc = kn.dc(G, Qb, ctx.inv_T)[:Nc].to(ctx.in_dtypes[1])
+        return dq, dc, None, None, None
+
+
+def sim_score(q, c, colmask=None, inv_T=1.0, kernels=None):
+    """dpr_task.py:98-105 on the device: fp32 logits [Nq, Nc] from fp32/bf16 embeddings; colmask is the [Nc]
+    dummy-context mask (the row the reference broadcasts at :197).  Differentiable when an input requires grad."""
+    kn = kernels if kernels is not None else default_kernels()
+    q, c = _pad_hidden(q, c)
+    if torch.is_grad_enabled() and (q.requires_grad or c.requires_grad) and hasattr(kn, "dq"):
+        return SimScore.apply(q, c, colmask, inv_T, kn)
+    S, _, _, Nc = _sim_fwd(kn, q.detach(), c.detach(), colmask, inv_T)
+    return S if S.shape[1] == Nc else S[:, :Nc]
+
+
+class PairwiseScore(torch.autograd.Function):
+    """citadel_task.py:137-146 `sim_score(q, c, mask, pairwise=True)`: scores[b][j] = <q[b], c[b*M + j]>, -inf at masked
+    pairs; differentiable (HBM-streaming HIP kernels, fp32)."""
+
+    @staticmethod
+    def forward(ctx, q, c, mask, kernels):
+        kn = kernels if kernels is not None else default_kernels()
+        qf, cf = q.detach().float().contiguous(), c.detach().float().contiguous()
+        m8 = None if mask is None else (mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)).contiguous().view(-1)
+        ctx.kn, ctx.in_dtypes = kn, (q.dtype, c.dtype)
+        ctx.save_for_backward(qf, cf, m8)
+        return kn.pairwise_fwd(qf, cf, m8)
+
+    @staticmethod
+    def backward(ctx, dS):
+        qf, cf, m8 = ctx.saved_tensors
+        g = dS.detach().float()
+        if m8 is not None:
+            g = g.masked_fill(m8.view_as(g).bool(), 0.0)  # -inf entries were index-put: no gradient flows through them
+        dq, dc = ctx.kn.pairwise_bwd(g.contiguous(), qf, cf, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (dq.to(ctx.in_dtypes[0]) if dq is not None else None, dc.to(ctx.in_dtypes[1]) if dc is not None else None, None, None)
+
+
+def pairwise_score(q, c, mask=None, kernels=None):
+    """[B, M] scores of every query against its own M = c.shape[0] // B contexts (mask: [B*M] or [B, M] bool)."""
+    return PairwiseScore.apply(q, c, mask, kernels)
 
 
 def cross_entropy_mean(S, labels, kernels=None):

@@ -222,12 +222,16 @@ def _plain(x):
 
 def load_from_checkpoint(cls, path, **overrides):
     """DenseRetrieverTask.load_from_checkpoint for the stand-in (drboost_task.py:29, spar_task.py:31-32 use it)."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    # PL's own keyword arguments (drboost_task.py:29 passes map_location) are not hyper-parameters of the task
+    map_location = overrides.pop("map_location", "cpu")
+    strict = overrides.pop("strict", True)
+    overrides.pop("hparams_file", None)
+    ck = torch.load(path, map_location=map_location if map_location is not None else "cpu", weights_only=False)
     hp = dict(ck.get("hyper_parameters", {}))
     hp.update(overrides)
     task = cls(**hp)
     task.on_load_checkpoint(ck)
-    task.load_state_dict(ck["state_dict"])
+    task.load_state_dict(ck["state_dict"], strict=strict)
     return task
 
 

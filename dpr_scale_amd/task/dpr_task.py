@@ -150,7 +150,9 @@ class DenseRetrieverTask(LightningModule):
     # ---- scoring (reference :98-105) -----------------------------------------------------------------------
     def sim_score(self, query_repr, context_repr, mask=None):
         """fp32 logits [Nq, Nc]; masked entries are -inf.  `mask` is the [Nc] dummy-context mask or, as the
-        reference passes it, that row repeated to [Nq, Nc]."""
+        reference passes it, that row repeated to [Nq, Nc].  Differentiable like the reference's torch.matmul
+        (:98-105): subclasses that train through `self.loss(self.sim_score(q, c, mask), y)` (citadel_task.py:249-262)
+        get encoder gradients -- the backward runs the HIP dQ / dC GEMMs (hotpath.SimScore)."""
         col = None
         full = None
         if mask is not None:
@@ -158,7 +160,7 @@ class DenseRetrieverTask(LightningModule):
                 col = mask
             else:
                 full = mask
-        scores = hotpath.sim_score(query_repr.detach(), context_repr.detach(), col, 1.0, self.kernels)
+        scores = hotpath.sim_score(query_repr, context_repr, col, 1.0, self.kernels)
         if full is not None:
             scores = scores.masked_fill(full, float("-inf"))
         return scores
@@ -287,10 +289,14 @@ class DenseRetrieverTask(LightningModule):
         if method != "script":
             raise ValueError(f"The 'method' parameter only supports 'script', but value given was: {method}")
         transform = instantiate(self.transform_conf)
+        mode = self.training
         with torch.no_grad():
-            result = {"ctx_encoder": torch.jit.script(ScriptEncoder(transform, self.context_encoder).eval(), **kwargs)}
+            result = {"ctx_encoder": torch.jit.script(ScriptEncoder(transform, self.context_encoder).eval(), **kwargs),
+                      "ctx_encoder_qt": torch.jit.script(ScriptEncoder(transform, self.context_encoder, quantize=True).eval(), **kwargs)}
             if not self.shared_model:
                 result["q_encoder"] = torch.jit.script(ScriptEncoder(transform, self.query_encoder).eval(), **kwargs)
+                result["q_encoder_qt"] = torch.jit.script(ScriptEncoder(transform, self.query_encoder, quantize=True).eval(), **kwargs)
+        self.train(mode)
         if file_path is not None:
             torch.jit.save(result["ctx_encoder"], file_path)
         return result

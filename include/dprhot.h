@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 130 /* 0.1.30: + topk_update/search, inbatch_step(_packed)_f32, optional communicator */
+#define DPRHOT_VERSION 140 /* 0.1.40: + skinny-M step plan (B <= 128), pairwise scores, top-k up to 1024 */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -189,7 +189,8 @@ int dprhot_inbatch_step_packed_f32(const float* q, const dprhot_bf16* gathered, 
                                    void* stream);
 
 /* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
- * their column indices, descending, ties by lower column index.  k <= 128, k <= cols. */
+ * their column indices, descending, ties by lower column index.  k <= 1024 (the reference's recipes use --topk 100 and 1000),
+ * k <= cols. */
 int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream);
 
 /* The same as a streaming update, for a corpus that is scored in pieces (the shard loop of
@@ -213,6 +214,14 @@ int dprhot_search_workspace_bytes(int nq, int chunk, size_t* h_out);
 int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_ctx, int d, int64_t id_offset,
                   int k, int chunk, float* values, int64_t* indices, int first, void* workspace,
                   size_t workspace_bytes, void* stream);
+
+/* Pairwise scores of the CITADEL router / distillation path (dpr_scale/task/citadel_task.py:137-146, sim_score(...,
+ * pairwise=True)): query b against its own M contexts,  S[b][j] = <q[b], c[b*M + j]>, -inf where mask[b*M + j] != 0
+ * (mask may be NULL).  q [B,d], c [B*M,d] fp32 (router vectors are vocabulary-wide: d = 30522), S [B,M] fp32.  Any d. */
+int dprhot_pairwise_fwd(const float* q, const float* c, const uint8_t* mask, int B, int M, int d, float* S, void* stream);
+/* Its backward: dq[b] = sum_j g[b][j] c[b*M+j] and dc[b*M+j] = g[b][j] q[b]; g [B,M] fp32 with 0 at masked pairs.
+ * dq / dc may each be NULL. */
+int dprhot_pairwise_bwd(const float* g, const float* q, const float* c, int B, int M, int d, float* dq, float* dc, void* stream);
 
 /* Optional communicator: the collectives of the path (dpr_task.py:166-176 gathers; the autograd split of :192-195)
  * issued directly on the caller's stream through the RCCL library already present in the process (dlopen; no

@@ -60,6 +60,26 @@ class OracleKernels:
         return dQ, dC
 
     # fp32-operand forms: the product rounds to bf16 while staging and leaves the bf16 images in Qb / Cb
+    def dq(self, G, Cb, h_scale=1.0, d_scale=None):
+        return self.inbatch_bwd(G, None, Cb, h_scale, d_scale, True, False)[0]
+
+    def dc(self, G, Qb, h_scale=1.0, d_scale=None):
+        return self.inbatch_bwd(G, Qb, None, h_scale, d_scale, False, True)[1]
+
+    def pairwise_fwd(self, q, c, m8):
+        B, d = q.shape
+        S = (q.double()[:, None, :] * c.double().view(B, -1, d)).sum(-1).float()
+        if m8 is not None:
+            S = S.masked_fill(m8.view_as(S).bool(), float("-inf"))
+        return S
+
+    def pairwise_bwd(self, g, q, c, need_dq=True, need_dc=True):
+        B, d = q.shape
+        c3 = c.view(B, -1, d)
+        dq = (g[:, :, None] * c3).sum(1) if need_dq else None
+        dc = (g[:, :, None] * q[:, None, :]).reshape(c.shape) if need_dc else None
+        return dq, dc
+
     def inbatch_fwd_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_logits=False, want_G=True):
         self.cast_bf16(q, Qb)
         if c is not None:

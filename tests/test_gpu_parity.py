@@ -340,7 +340,7 @@ def test_tie_rule_bit_exact(dev):
 
 
 @pytest.mark.parametrize("rows,cols,k,levels", [(5, 1000, 10, 4), (3, 70000, 100, 0), (64, 9000, 128, 50), (2, 3, 3, 2),
-                                               (4, 20000, 1, 0)])
+                                               (4, 20000, 1, 0), (3, 50000, 1000, 0), (2, 1500, 1024, 7), (5, 30000, 300, 20)])
 def test_streaming_topk_equals_stable_sort_prefix(rows, cols, k, levels, kn, dev):
     """torch.topk of run_retrieval_pytorch.py:149-150 under the frozen tie rule, in one piece and folded over pieces
     (the shard re-merge of :272-277); indices bit-exact."""
@@ -380,7 +380,8 @@ def test_topk_state_with_fewer_columns_than_k(kn, dev):
     assert i.tolist() == [[0, 2, 11, 13, 12, 10]]
 
 
-@pytest.mark.parametrize("nq,shards,d,k,chunk", [(9, (4000, 13, 8, 2051), 64, 20, 1024), (130, (50000,), 768, 100, 8192)])
+@pytest.mark.parametrize("nq,shards,d,k,chunk", [(9, (4000, 13, 8, 2051), 64, 20, 1024), (130, (50000,), 768, 100, 8192),
+                                                 (7, (30000, 5000), 128, 1000, 4096)])  # --topk 1000: dragon/README recipes
 def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk, kn, dev):
     """search_index + shard loop (run_retrieval_pytorch.py:141-166, :196-243, :272-277): ids bit-exact against
     the stable top-k of the full score matrix computed by the same similarity kernel; scores against fp32 torch."""

@@ -196,3 +196,35 @@ def test_fp16_grads_registers_the_xgmi_gradient_hook():
     task2.trainer = task.trainer
     task2.on_pretrain_routine_start()
     assert len(calls) == 1
+
+
+def test_sim_score_then_loss_is_differentiable_like_the_reference():
+    """dpr_task.py:98-105 is a differentiable torch.matmul and subclasses train through `self.loss(self.sim_score(...))`
+    (citadel_task.py:249-262): gradients must reach the encoder outputs (they silently did not)."""
+    import numpy as np
+
+    from _oracle_kernels import OracleKernels
+    from dpr_scale_amd.task.dpr_task import DenseRetrieverTask
+    from oracle import inbatch_oracle as O
+
+    q, c, y, m = O.synth_embeddings(5, 6, 3, 64, "U", True)
+    task = DenseRetrieverTask(None, None, None, None)
+    task.kernels = OracleKernels()
+    task.loss.kernels = task.kernels
+    tq, tc = torch.from_numpy(q).requires_grad_(True), torch.from_numpy(c).requires_grad_(True)
+    scores = task.sim_score(tq, tc, torch.from_numpy(m))
+    assert scores.requires_grad
+    loss = task.loss(scores, torch.from_numpy(y))
+    loss.backward()
+    rq, rc = torch.from_numpy(q).requires_grad_(True), torch.from_numpy(c).requires_grad_(True)
+    S = torch.matmul(rq, rc.T)
+    S = S.masked_fill(torch.from_numpy(m)[None, :].expand_as(S), float("-inf"))
+    ref = torch.nn.CrossEntropyLoss()(S, torch.from_numpy(y))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    assert tq.grad is not None and tc.grad is not None
+    assert np.abs(tq.grad.numpy() - rq.grad.numpy()).max() <= 1e-2 * np.abs(rq.grad.numpy()).max()
+    assert np.abs(tc.grad.numpy() - rc.grad.numpy()).max() <= 1e-2 * np.abs(rc.grad.numpy()).max()
+    # the [Nq, Nc] mask form the reference passes (:197) works too
+    s2 = task.sim_score(tq.detach(), tc.detach(), torch.from_numpy(m).repeat(6, 1))
+    assert torch.equal(torch.isinf(s2), torch.from_numpy(m).repeat(6, 1))
