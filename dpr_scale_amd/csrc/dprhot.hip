@@ -837,6 +837,7 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
     // S_in, when given, is where the caller wants the summed logits (the slabs always live in the workspace)
     GShortArgs g{reinterpret_cast<const float*>(ws + wl.logits), fp.splits, (size_t)B * Nc, B, Nc, y, y_offset, grad_scale,
                  const_cast<float*>(S_in), row_loss, row_lse, G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum, fp.tpr};
+    if (fp.blocks > 65535) return fail(DPRHOT_E_UNSUPPORTED, "softmax_finish: B=%d rows need %d workgroups (max 65535)", B, fp.blocks);
     if (fp.cpt == 1) hipLaunchKernelGGL(gfinal_short_kernel<1>, dim3(fp.blocks), dim3(fp.threads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(gfinal_short_kernel<2>, dim3(fp.blocks), dim3(fp.threads), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
@@ -851,6 +852,8 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   const bool thin = (long)B * (Nc / 8) <= 1L << 18;  // latency-bound sizes: one chunk per thread, many small workgroups
   int rpb, xblocks;
   gfinal_geometry(Nc, thin ? 1 : 8, &rpb, &xblocks);
+  if (cdiv(B, rpb) > 65535)  // grid.y limit, and the arrival ticket of the loss accumulation is 16 bits wide
+    return fail(DPRHOT_E_UNSUPPORTED, "softmax_finish: B=%d rows need %d row blocks (max 65535)", B, cdiv(B, rpb));
   dim3 grid(xblocks, cdiv(B, rpb));
   if (thin) hipLaunchKernelGGL(gfinal_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(gfinal_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, g);

@@ -163,7 +163,35 @@ struct GFinalArgs {
   float* loss_sum;          // out: sum_i row_loss[i]
 };
 
-constexpr double kLossFix = 16777216.0;  // 2^24
+constexpr double kLossFix = 1048576.0;   // 2^20: 48 bits of 2^-20 fixed point hold sums up to 2.7e8 at 1e-6 resolution
+constexpr double kLossMaxBlock = 67108864.0;  // 2^26: a single workgroup's sum beyond this is published as +inf
+
+// Loss numerator across workgroups: ONE 64-bit integer atomic carries the arrival ticket (bits 48..63) and the 2^-20
+// fixed-point sum (bits 0..47): order-independent, hence deterministic, and a single round trip.  A NaN / inf / out-of-range
+// workgroup sum cannot travel in fixed point: it sets sticky bits in acc[1] (bit 0 NaN, bit 1 +inf, bit 2 -inf) BEFORE its
+// ticket, and the last arriver publishes NaN / inf exactly as nn.CrossEntropyLoss would (diverged embeddings, a masked gold
+// column) instead of a finite-looking number.  acc[0..1] are zeroed by the sim launch.
+__device__ __forceinline__ void loss_ticket_add(unsigned long long* acc, double tot, unsigned nblocks, float* loss_sum) {
+  long long fx = 0;
+  const bool nan = !(tot == tot), big = fabs(tot) >= kLossMaxBlock;  // inf counts as big
+  if (nan || big) {
+    atomicOr(&acc[1], nan ? 1ull : (tot > 0 ? 2ull : 4ull));
+    __threadfence();  // rare path: the flag must be visible before this workgroup's ticket
+  } else {
+    fx = __double2ll_rn(tot * kLossFix);
+    if (fx < 0) fx = 0;  // row losses are >= 0 up to rounding
+  }
+  const unsigned long long old = atomicAdd(&acc[0], (1ull << 48) | (unsigned long long)fx);
+  if ((old >> 48) == (unsigned long long)nblocks - 1) {
+    const unsigned long long flags = atomicOr(&acc[1], 0ull);
+    float out = (float)((double)((old & ((1ull << 48) - 1)) + (unsigned long long)fx) / kLossFix);
+    if (flags & 1ull) out = NAN;
+    else if ((flags & 6ull) == 6ull) out = NAN;  // +inf and -inf
+    else if (flags & 2ull) out = INFINITY;
+    else if (flags & 4ull) out = -INFINITY;
+    loss_sum[0] = out;
+  }
+}
 constexpr int kGfMaxPairs = 2048;         // (max, sum) pairs one workgroup stages in LDS
 
 // rows per workgroup / x-blocks per row for a given row length and CPT chunks per thread (host and device agree)
@@ -296,12 +324,7 @@ __global__ __launch_bounds__(256) void gfinal_kernel(GFinalArgs p) {
       if (small || gridDim.y == 1) {
         p.loss_sum[0] = (float)tot;
       } else {
-        // ticket (bits 48..63) and 2^-24 fixed-point sum (bits 0..47) in ONE atomic: one round trip
-        long long fx = __double2ll_rn(tot * kLossFix);
-        if (fx < 0) fx = 0;
-        const unsigned long long old = atomicAdd(&p.acc[0], (1ull << 48) | (unsigned long long)fx);
-        if ((old >> 48) == (unsigned long long)gridDim.y - 1)
-          p.loss_sum[0] = (float)((double)((old & ((1ull << 48) - 1)) + (unsigned long long)fx) / kLossFix);
+        loss_ticket_add(p.acc, tot, gridDim.y, p.loss_sum);
       }
     }
   }
@@ -444,11 +467,7 @@ __global__ __launch_bounds__(1024) void gfinal_short_kernel(GShortArgs p) {
     if (gridDim.x == 1) {
       p.loss_sum[0] = (float)tot;
     } else {
-      long long fx = __double2ll_rn(tot * kLossFix);
-      if (fx < 0) fx = 0;
-      const unsigned long long old = atomicAdd(&p.acc[0], kTicketOne | (unsigned long long)fx);
-      if ((old >> 48) == (unsigned long long)gridDim.x - 1)
-        p.loss_sum[0] = (float)((double)((old & kSumMask) + (unsigned long long)fx) / kLossFix);
+      loss_ticket_add(p.acc, tot, gridDim.x, p.loss_sum);
     }
   }
 }

@@ -42,8 +42,9 @@ def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_
     assert inp.shape[0] == W * n
     if _is_nccl(group):
         return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
-    # gloo (CPU tests): no reduce-scatter -- all-reduce then keep the own slice
-    tmp = inp.clone()
+    # gloo (CPU tests): no reduce-scatter -- all-reduce then keep the own slice (bf16: gloo cannot add it; the rounded values
+    # are summed in fp32 and rounded once more, which bounds what RCCL's bf16 additions do)
+    tmp = inp.float() if inp.dtype == torch.bfloat16 else inp.clone()
     dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
     out.copy_(tmp[r * n:(r + 1) * n])
     return None

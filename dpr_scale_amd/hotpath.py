@@ -10,12 +10,27 @@ layout, label offsets, reduce-scatter, loss all-reduce) on gloo with a stand-in;
 thing the product ever passes -- is the HIP library.
 """
 import ctypes
+import os
 
 import torch
 
 from . import dist as D
 
 _BF16 = torch.bfloat16
+
+
+def _fp32_g_mode():
+    """DPRHOT_FP32_G=1: debug mode of SURVEY.md section 8 c5 -- dScores no longer travel as ONE bf16 value (2^-9 relative
+    rounding, the source of the ~2e-3 gradient deviation) but as a bf16 pair hi + lo (G = hi + lo to 2^-17), and each
+    backward GEMM runs twice on the same MFMA kernels; gradients then agree with the fp32 reference to <= 1e-3.  Single
+    rank only; costs a second pass over the logits and two more GEMM launches."""
+    return os.environ.get("DPRHOT_FP32_G") == "1"
+
+
+def _dc_wire_dtype():
+    """DPRHOT_DC_WIRE=bf16: the reduce-scatter of the dC partials ships bf16 (10.5 MiB per rank at cfg3 instead of 21 MiB,
+    SURVEY.md section 8(d)); the partial sums of the W ranks are then added in bf16 by RCCL.  Default: fp32."""
+    return _BF16 if os.environ.get("DPRHOT_DC_WIRE", "fp32") == "bf16" else torch.float32
 
 
 def _ptr(t):
@@ -446,7 +461,14 @@ class InBatchContrastive(torch.autograd.Function):
         grad_scale = inv_T / Nq  # d loss / d S of the global mean, before grad_output
         y_off = r * rows_c       # dpr_task.py:189-190 (label offset of this rank's columns)
         eager = None  # gradients for grad_output = 1, when the whole step ran in the forward call
-        if W > 1 and packed_step:
+        S_dbg = None
+        if W == 1 and _fp32_g_mode() and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            if q_f32:
+                row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
+                                                                           inv_T, grad_scale, want_logits=True)
+            else:
+                row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale, want_logits=True)
+        elif W > 1 and packed_step:
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T,
                                                                                      grad_scale)
             # (dC_part's dead mask rows also carry the loss numerator; only bench.py's stream-ordered step uses that)
@@ -474,6 +496,7 @@ class InBatchContrastive(torch.autograd.Function):
         if eager is None:
             ctx.save_for_backward(Qb, Cb, G)
         ctx.row_lse = row_lse
+        ctx.dbg = None if S_dbg is None else (S_dbg, pos_idx + y_off, grad_scale)
         return loss
 
     @staticmethod
@@ -485,6 +508,20 @@ class InBatchContrastive(torch.autograd.Function):
         if ctx.eager is not None:
             dQ, dC_part = ctx.eager  # computed in forward for grad_output = 1; the scale is applied below (kept: a
             #                          second backward with retain_graph=True must find them again)
+        elif ctx.dbg is not None:
+            # fp32-G debug mode: G = (exp(S - lse) - onehot) * scale recomputed in fp32, split into a bf16 pair, two GEMM passes
+            Qb, Cb, _ = ctx.saved_tensors
+            S, labels, gs = ctx.dbg
+            G32 = torch.exp(S - ctx.row_lse[:, None])
+            G32[torch.arange(S.shape[0], device=S.device), labels] -= 1.0
+            G32 *= gs
+            hi = G32.to(_BF16)
+            lo = (G32 - hi.float()).to(_BF16)
+            dQ1, dC1 = kn.inbatch_bwd(hi, Qb, Cb, 1.0, go, need_dq, need_dc)
+            dQ2, dC2 = kn.inbatch_bwd(lo, Qb, Cb, 1.0, go, need_dq, need_dc)
+            dQ = dQ1 + dQ2 if need_dq else None
+            dC_part = dC1 + dC2 if need_dc else None
+            go = None
         else:
             Qb, Cb, G = ctx.saved_tensors
             dQ, dC_part = kn.inbatch_bwd(G, Qb, Cb, 1.0, go, need_dq, need_dc)
@@ -497,10 +534,13 @@ class InBatchContrastive(torch.autograd.Function):
                 dc = dC_part[:n_ctx]
                 dc = (dc if go is None else dc * go).to(ctx.in_dtypes[1])
             else:
-                mine = kn.empty((rows_c, d), torch.float32, dC_part)
+                wire = _dc_wire_dtype()
+                mine = kn.empty((rows_c, d), wire, dC_part)
                 if go is not None:
                     dC_part = dC_part * go  # scale before the collective: nothing is left to do after it
-                if ctx.pending is not None and ctx.in_dtypes[1] == torch.float32:
+                if wire != torch.float32:
+                    dC_part = dC_part.to(wire)  # half the bytes on the links (and in RCCL's reduction)
+                if ctx.pending is not None and ctx.in_dtypes[1] == torch.float32 and wire == torch.float32:
                     # reduce-scatter on RCCL's stream; whoever consumes dc (defer_context_grad, after the query-tower
                     # backward has been enqueued) waits for it
                     ctx.pending.work = D.reduce_scatter_rows(dC_part, mine, group, async_op=True)

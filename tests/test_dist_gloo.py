@@ -44,8 +44,13 @@ def _worker(rank, W, port, meta, q, overlapped=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,port,overlapped", [("w2_ddp", 29711, False), ("w4_ddp", 29712, False), ("w2_ddp", 29713, True)])
-def test_ddp_branch_matches_reference(name, port, overlapped):
+@pytest.mark.parametrize("name,port,overlapped", [("w2_ddp", 29711, False), ("w4_ddp", 29712, False), ("w2_ddp", 29713, True),
+                                                  ("w4_ddp", 29714, "bf16wire")])
+def test_ddp_branch_matches_reference(name, port, overlapped, monkeypatch):
+    """overlapped == "bf16wire": DPRHOT_DC_WIRE=bf16 -- the reduce-scatter of the dC partials ships bf16."""
+    if overlapped == "bf16wire":
+        monkeypatch.setenv("DPRHOT_DC_WIRE", "bf16")  # inherited by the spawned ranks
+        overlapped = True
     meta, g = load_golden(name)
     W = meta["W"]
     ctx = mp.get_context("spawn")
