@@ -21,6 +21,7 @@
 #include <type_traits>
 #include "gemm_bf16.h"
 #include "gemm256.h"
+#include "gemm8p.h"
 #include "rowwise.h"
 #include "step_small.h"
 #include "skinny.h"
@@ -131,6 +132,13 @@ bool big_ok(int M, int N, int K) {
   return M > 128 && K % 64 == 0 && K >= 128 && big_min_wgs() > 0 && wgs >= big_min_wgs();
 }
 
+// The phase-interleaved persistent 256x256 kernel (gemm8p.h) and the forward built on it that never stores the logits: same gate
+// as the 256x256 tile, plus an even number of K steps and operands addressable with 32-bit byte offsets.
+bool nl_ok(int M, int N, int K) {
+  static const bool off = getenv("DPRHOT_NO_NL") != nullptr;
+  return !off && force_tile() < 0 && big_ok(M, N, K) && K % 128 == 0 && (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
+}
+
 // Tile for D[M,N] with contraction length K: the largest tile (BM capped by M) that still yields `want`
 // workgroups, else the smallest; small-M problems with a long K use the BK=256 variants (latency-bound:
 // fewer, fatter K steps keep a whole K range in flight).
@@ -180,6 +188,29 @@ int launch_big(const GemmArgs& a, const Epi& epi, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g2_lds_total, st, a, epi, nbx, nby);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
+}
+
+template <class Epi>
+int launch_g8(const GemmArgs& a, const Epi& epi, hipStream_t st) {
+  auto kern = gemm8p_kernel<Epi>;
+  static bool attr_done = false;  // benign race: idempotent
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+    attr_done = true;
+  }
+  const int nbx = cdiv(a.N, G2_B), nby = cdiv(a.M, G2_B);
+  const int grid = nbx * nby < kNumCU ? nbx * nby : kNumCU;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g8_lds_total, st, a, epi, nbx, nby);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+// the inputs every gemm8p.h sim epilogue shares
+Epi8Base g8_base(const dprhot_bf16* Q, int B, int Nc, const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float* gold) {
+  EpiSim e{nullptr, colmask, B, Nc, inv_T, nullptr, nullptr, y, y_offset, gold, nullptr, 0};
+  Epi8Base b;
+  b.sim = with_packed_mask(e);
+  b.dummy = Q;
+  return b;
 }
 
 template <bool AK, bool BKM, class Epi>
@@ -352,7 +383,7 @@ FwdPlan fwd_plan(int B, int Nc, int d);
 
 // workspace carve-up (all offsets 256-byte aligned)
 struct WsLayout {
-  size_t header, gold, part_m, part_s, logits, dq_part, total;
+  size_t header, gold, lse, rloss, part_m, part_s, logits, dq_part, total;
 };
 WsLayout ws_layout(int B, int Nc, int d) {
   WsLayout w;
@@ -360,12 +391,15 @@ WsLayout ws_layout(int B, int Nc, int d) {
   size_t off = 0;
   w.header = off; off += 256;
   w.gold = off; off += align256((size_t)B * 4);
+  w.lse = off; off += align256((size_t)B * 4);    // no-logits forward: row logsumexp for the dScores pass / rank: gold logits
+  w.rloss = off; off += align256((size_t)B * 4);  // no-logits forward: row losses / rank: counts
   w.part_m = off; off += align256((size_t)B * ntmax * 4);
   w.part_s = off; off += align256((size_t)B * ntmax * 4);
   {
     const FwdPlan fp = fwd_plan(B, Nc, d);  // short rows: split-K slabs of partial logits (4, or up to 32 for wide vectors)
     const size_t slabs = (Nc <= 4096 && (B <= 64 || fp.short_rows)) ? (size_t)(fp.short_rows && fp.splits > 4 ? fp.splits : 4) : 1;
-    w.logits = off; off += align256((size_t)B * Nc * 4 * slabs);
+    // no-logits shapes: the forward never stores S (a caller who wants the logits passes S_out)
+    w.logits = off; off += nl_ok(B, Nc, d) ? 0 : align256((size_t)B * Nc * 4 * slabs);
   }
   const DqPlan p = dq_plan(B, Nc, d);
   const SkPlan sk = sk_plan(B, Nc, d);
@@ -763,6 +797,17 @@ int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, 
     return fail(DPRHOT_E_WORKSPACE, "sim_stats needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
   char* ws = static_cast<char*>(workspace);
+  if (S_out == nullptr && nl_ok(B, Nc, d)) {
+    // no-logits plan: strip statistics + gold logit only; dprhot_softmax_finish turns them into logsumexp / loss and
+    // dprhot_dscores recomputes the logits into G
+    Epi8Stats epi;
+    static_cast<Epi8Base&>(epi) = g8_base(Q, B, Nc, y, y_offset, colmask, inv_T, reinterpret_cast<float*>(ws + wl.gold));
+    epi.part_m = reinterpret_cast<float*>(ws + wl.part_m);
+    epi.part_s = reinterpret_cast<float*>(ws + wl.part_s);
+    epi.npart = cdiv(Nc, G2_B) * 4;
+    GemmArgs a8{Q, C, B, Nc, d, d, d, d};
+    return launch_g8(a8, epi, (hipStream_t)stream);
+  }
   const FwdPlan fp = fwd_plan(B, Nc, d);
   GemmArgs a{Q, C, B, Nc, d, d, d, fp.kchunk};
   if (fp.short_rows) {  // partial logits per K split; the softmax launch sums them (and fills S_out if asked)
@@ -832,6 +877,18 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   if (workspace == nullptr || workspace_bytes < wl.total)
     return fail(DPRHOT_E_WORKSPACE, "softmax_finish needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
   char* ws = static_cast<char*>(workspace);
+  if (S_in == nullptr && nl_ok(B, Nc, d)) {
+    // no-logits plan (same test as dprhot_sim_stats): logsumexp and loss from the strip statistics; there are no logits to turn
+    // into G here -- dprhot_dscores recomputes them
+    if (G != nullptr) return fail(DPRHOT_E_UNSUPPORTED, "softmax_finish: no logits at B=%d Nc=%d d=%d (no-logits forward): G comes from dprhot_dscores", B, Nc, d);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(g8_lse_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.part_m),
+                       reinterpret_cast<const float*>(ws + wl.part_s), cdiv(Nc, G2_B) * 4, reinterpret_cast<const float*>(ws + wl.gold), B,
+                       reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss, reinterpret_cast<float*>(ws + wl.rloss));
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, 1.0f, loss_sum);
+    HIP_TRY(hipGetLastError());
+    return DPRHOT_OK;
+  }
   const FwdPlan fp = fwd_plan(B, Nc, d);  // same plan as dprhot_sim_stats -> same intermediate layout
   if (fp.short_rows) {
     // S_in, when given, is where the caller wants the summed logits (the slabs always live in the workspace)
@@ -861,9 +918,77 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   return DPRHOT_OK;
 }
 
+// dScores of the no-logits forward: G = (softmax(S) - onehot) * grad_scale with S recomputed tile by tile (the same GEMM as
+// dprhot_sim_stats, bit-identical accumulators).  row_lse: the rows' logsumexp, or NULL to use the values dprhot_softmax_finish
+// left in the workspace.
+int dprhot_dscores(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                   const uint8_t* colmask, float inv_T, float grad_scale, const float* row_lse, dprhot_bf16* G, void* workspace,
+                   size_t workspace_bytes, void* stream) {
+  REQUIRE(Q && C && y && G, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  REQUIRE(aligned16(Q) && aligned16(C) && aligned16(G), "pointers must be 16-byte aligned");
+  if (!nl_ok(B, Nc, d)) return fail(DPRHOT_E_UNSUPPORTED, "dscores: B=%d Nc=%d d=%d is not a no-logits shape (use dprhot_softmax_finish)", B, Nc, d);
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (row_lse == nullptr) {
+    if (workspace == nullptr || workspace_bytes < wl.total)
+      return fail(DPRHOT_E_WORKSPACE, "dscores needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+    row_lse = reinterpret_cast<const float*>(static_cast<char*>(workspace) + wl.lse);
+  }
+  Epi8G epi;
+  static_cast<Epi8Base&>(epi) = g8_base(Q, B, Nc, y, y_offset, colmask, inv_T, nullptr);
+  epi.row_lse = row_lse;
+  epi.G = G;
+  epi.grad_scale = grad_scale;
+  GemmArgs a8{Q, C, B, Nc, d, d, d, d};
+  return launch_g8(a8, epi, (hipStream_t)stream);
+}
+
+// Rank of every row's gold column in the stable descending order of its scores (dpr_task.py:235-246) straight from the
+// embeddings: at no-logits shapes the score matrix is never written (gold logits from a gathered mini GEMM, then a count-greater
+// epilogue inside the similarity GEMM); smaller problems materialise S in the workspace and count there.
+int dprhot_sim_rank(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                    const uint8_t* colmask, float inv_T, int64_t* rank, void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(Q && C && y && rank, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  REQUIRE(aligned16(Q) && aligned16(C), "pointers must be 16-byte aligned");
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (workspace == nullptr || workspace_bytes < wl.total)
+    return fail(DPRHOT_E_WORKSPACE, "sim_rank needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  if (!nl_ok(B, Nc, d)) {
+    float* S = reinterpret_cast<float*>(ws + wl.logits);
+    if (int rc = dprhot_sim_fwd(Q, B, C, Nc, d, colmask, inv_T, S, stream)) return rc;
+    return dprhot_rank_of_gold(S, B, Nc, y, y_offset, rank, stream);
+  }
+  float* gold = reinterpret_cast<float*>(ws + wl.lse);
+  int* count = reinterpret_cast<int*>(ws + wl.rloss);
+  Epi8Count epi;
+  static_cast<Epi8Base&>(epi) = g8_base(Q, B, Nc, y, y_offset, colmask, inv_T, nullptr);
+  epi.gold_val = gold;
+  epi.count = count;
+  hipLaunchKernelGGL(g8_gold_kernel, dim3(cdiv(B, 32)), dim3(64), 0, st, Q, C, B, Nc, d, y, y_offset, epi.sim, inv_T, gold);
+  HIP_TRY(hipMemsetAsync(count, 0, (size_t)B * sizeof(int), st));
+  GemmArgs a8{Q, C, B, Nc, d, d, d, d};
+  if (int rc = launch_g8(a8, epi, st)) return rc;
+  hipLaunchKernelGGL(g8_rank_finish_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, count, B, rank);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
                        const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss, float* row_lse,
                        float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
+  if (S_out == nullptr && nl_ok(B, Nc, d)) {
+    // no-logits forward: statistics pass -> logsumexp / loss -> dScores pass (logits recomputed); S is never in memory
+    if (int rc = dprhot_sim_stats(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, nullptr, workspace, workspace_bytes, stream)) return rc;
+    if (int rc = dprhot_softmax_finish(nullptr, B, Nc, d, y, y_offset, grad_scale, row_loss, row_lse, loss_sum, nullptr, workspace,
+                                       workspace_bytes, stream))
+      return rc;
+    if (G == nullptr) return DPRHOT_OK;
+    return dprhot_dscores(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, grad_scale, nullptr, G, workspace, workspace_bytes, stream);
+  }
   if (int rc = dprhot_sim_stats(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream)) return rc;
   return dprhot_softmax_finish(S_out, B, Nc, d, y, y_offset, grad_scale, row_loss, row_lse, loss_sum, G, workspace, workspace_bytes,
                                stream);
@@ -872,6 +997,16 @@ int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc
 int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
                            int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss,
                            float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
+  if (S_out == nullptr && B > 128 && nl_ok(B, Nc, d)) {  // cast once, then the no-logits forward on the bf16 copies
+    REQUIRE(q && Qb && Cb && y, "NULL pointer");
+    if (c != nullptr) {
+      if (int rc = dprhot_prep(q, (size_t)B * d, Qb, c, (size_t)Nc * d, Cb, stream)) return rc;
+    } else {
+      if (int rc = dprhot_cast_bf16(q, Qb, (size_t)B * d, stream)) return rc;
+    }
+    return dprhot_inbatch_fwd(Qb, B, Cb, Nc, d, y, y_offset, colmask, inv_T, grad_scale, nullptr, row_loss, row_lse, loss_sum, G, workspace,
+                              workspace_bytes, stream);
+  }
   if (int rc = dprhot_sim_stats_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, S_out, workspace, workspace_bytes, stream))
     return rc;
   return dprhot_softmax_finish(S_out, B, Nc, d, y, y_offset, grad_scale, row_loss, row_lse, loss_sum, G, workspace, workspace_bytes,

@@ -1,0 +1,631 @@
+// gemm8p.h -- the 256x256 similarity GEMM with a phase-interleaved K loop (dpr_task.py:98-105 at evaluation / retrieval /
+// large-batch sizes): D[M,N] = A[M,K] * B[N,K]^T, both operands k-major bf16, persistent workgroups.
+//
+// gemm256.h runs one barrier per K step: DMA the next step, wait for everything (vmcnt(0)), barrier, 24 fragment reads, 64
+// MFMAs -- all eight waves read LDS at the same time and then all queue on the matrix pipe (45 % of the dense peak in the K
+// loop alone).  Here a K step (64 deep) is four phases, one per 64 x 32 quadrant of the wave's 128 x 64 output, and a phase is
+//     [ fragment reads of ONE half-tile | LDS-DMA of ONE future half-tile | counted vmcnt ]  barrier
+//     [ 16 MFMAs ]                                                                            barrier
+// The wave groups wm = 0 and wm = 1 (one wave of each on every SIMD) run one barrier apart, so one group's LDS / DMA section
+// sits under the other group's MFMA section.  The DMA runs six phases (1.5 K steps) ahead of its first read and is never
+// drained inside the loop: vmcnt(10) leaves the five youngest half-tiles in flight across the barriers.
+//
+// Half-tiles.  A K step of an operand is two 16 KiB images [128 rows][64 k]: A-half h holds the rows
+// {wm * 128 + h * 64 + j}, B-half h the columns {wn * 64 + h * 32 + j}: exactly what ALL waves need for their quadrant row /
+// column h.  Quadrant order (0,0) (0,1) (1,1) (1,0): one operand half changes per phase.  Per K step t (LDS buffer t & 1):
+//     phase  reads (-> registers)   MFMA quadrant        DMA issued (K step, half)
+//     p0     A0(t)                  (0,0) A0 x B0(t)     A1(t+1)
+//     p1     B1(t)                  (0,1) A0 x B1        B0(t+2)
+//     p2     A1(t)                  (1,1) A1 x B1        A0(t+2)
+//     p3     B0(t+1)                (1,0) A1 x B0(t)     B1(t+2)
+// Every half-tile is read exactly six phases after its DMA was issued, every DMA overwrites an image two phases after its
+// last read (one phase would race with the lagging wave group), and every wait sits one phase before the read it covers (a
+// wave's vmcnt only covers its own share of the image; the barrier after it covers everybody's).
+// K steps beyond the tile's last belong to the workgroup's NEXT tile (persistent: the pipeline never drains).
+//
+// MFMA shape: v_mfma_f32_32x32x16_bf16 (the matrix pipe's better-fed shape: 2382 vs 2075 TFLOP/s in the instruction
+// microbenchmark; measured here 148.7 k vs 163.1 k cycles per XCD at 8192^2 x 768), operands swapped so that a lane holds runs of
+// 4 consecutive columns of one row (G8Acc): row statistics reduce inside a lane plus ONE cross-lane step, stores are 8 / 16
+// bytes per lane.  Every output element is the same chain of k slices in increasing order as in gemm256.h, and the logits are
+// bit-identical to that kernel's (scratch/g8probe.hip checks it).
+//
+// What did not work (profiles/r02_g8_ablation.txt): the wave groups in step (-33 %), one barrier per phase (-21 %), a 4-wave
+// workgroup with one wave per SIMD and no hand-over at all (scratch/negative/gemm1w.h: the barrier then idles the pipe, -33 %).
+// The loop is at 66 % MFMA-busy cycles with a null epilogue; its barrier / MFMA skeleton alone (no DMA, no reads) reaches 69-72 %.
+#pragma once
+#include "gemm256.h"
+#include "rowwise.h"
+
+namespace dprhot {
+
+constexpr int G8_HALF = 128 * 64;                                   // elements of a half-tile image
+constexpr size_t g8_tiles_bytes = (size_t)2 * 4 * G8_HALF * 2;      // 2 buffers x {A0, A1, B0, B1} = 128 KiB
+constexpr size_t g8_scratch_bytes = 8 * 1024;                       // epilogue scratch
+constexpr size_t g8_meta_bytes = (size_t)2 * 1024 * sizeof(int);    // 2 x 1024 words of per-tile epilogue inputs
+constexpr size_t g8_lds_total = g8_tiles_bytes + g8_scratch_bytes + g8_meta_bytes;  // 144 KiB
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void g8_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void g8_wait_lgkm0() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // register-only MFMAs may not be hoisted above the wait (guide 5.4 rule 18)
+}
+__device__ __forceinline__ void g8_bar() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// LDS accesses of the epilogues go through inline asm: hipcc orders a plain LDS access behind every LDS-DMA in flight with
+// s_waitcnt vmcnt(0) (it cannot tell the epilogue words from the tile images), which would drain the next tile's prefetch.
+typedef __attribute__((address_space(3))) int g8_lds_int;
+__device__ __forceinline__ unsigned g8_lds_addr(const void* p) { return (unsigned)(uintptr_t)(g8_lds_int*)p; }
+__device__ __forceinline__ void g8_lds_write(void* p, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(g8_lds_addr(p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ int g8_lds_read(const void* p) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(g8_lds_addr(p)) : "memory");
+  return v;
+}
+typedef int g8_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ g8_i32x4 g8_lds_read4(const void* p) {
+  g8_i32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(g8_lds_addr(p)) : "memory");
+  return v;
+}
+
+// What an epilogue sees of one tile.
+struct Tile8 {
+  int m0, n0;       // tile origin
+  int wm, wn;       // wave position (2 x 4): rows wm * 128.., columns wn * 64..
+  int lane, tid;
+  int bx, by, nbx;  // tile indices, column-tile count
+  float* scratch;   // LDS, g8_scratch_bytes
+  int* meta;        // LDS: the tile's 1024 input words, fetched by LDS-DMA from Epi::meta_src while the previous tile was computed
+};
+
+// The wave's 128 x 64 accumulators: v[a][b] (a < 4, b < 2) of 16 registers; lane (i = lane & 31, h = lane >> 5), register r:
+//   row wm*128 + a*32 + i,   column wn*64 + b*32 + (r >> 2)*8 + h*4 + (r & 3)
+// i.e. a lane holds, of each of its 4 rows, eight runs of 4 consecutive columns; lanes i and i + 32 share a row.
+struct G8Acc {
+  f32x16 v[4][2];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[a][b][r] = 0.f;
+  }
+};
+
+// Epilogue interface (all members __device__):
+//   const void* meta_src(int m0, int n0, int e) const   e < 1024: 4-byte aligned, always valid source address of input word e of the
+//                                                       tile at (m0, n0); by convention e < 256: one word per column n0 + e,
+//                                                       256 <= e < 512 and 512 <= e < 768: two words per row m0 + (e & 255)
+//   void finish(G8Acc& acc, const Tile8&) const         every wave executes the same number of barriers in it; it runs with the next
+//                                                       tile's first K steps in flight: LDS only through g8_lds_* (asm), tile images
+//                                                       untouched; global stores allowed (vmcnt retires in order, loads and stores
+//                                                       alike: scratch/g8probe.hip's order probe), plain global loads are not
+//                                                       (hipcc would wait vmcnt(0) for them: the whole DMA pipeline)
+
+// LDS fragment: lane reads 16 bytes of image row r0 + (lane & 31), 16-byte chunk kk*2 + (lane >> 5) of the 64-deep K step
+// (v_mfma_f32_32x32x16_bf16 operand: 32 rows x 16 k); conflict-free under the c ^ ((r >> 1) & 7) swizzle (the 16 lanes served
+// together cover both row parities x all 8 swizzle values).
+__device__ __forceinline__ bf16x8 g8_frag32(const uint16_t* T, int r0, int kk, int lane) {
+  const int row = r0 + (lane & 31);
+  return *reinterpret_cast<const bf16x8*>(T + row * 64 + (((kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7)) << 3));
+}
+
+#define G8_RD_A(IMG)                                                                                                      \
+  if constexpr (!(VAR & 16)) {                                                                                            \
+    _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_) _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                     \
+        af[a_ * 4 + k_] = g8_frag32((IMG), wm * 64 + a_ * 32, k_, lane);                                                  \
+  }
+#define G8_RD_B(DST, IMG)                                                                                                 \
+  if constexpr (!(VAR & 16)) {                                                                                            \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) DST[k_] = g8_frag32((IMG), wn * 32, k_, lane);                       \
+  }
+#define G8_MM(AH, BH, BQ)                                                                                                 \
+  if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);                                                                \
+  _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                       \
+      acc.v[(AH) * 2 + a_][(BH)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BQ[k_], af[a_ * 4 + k_], acc.v[(AH) * 2 + a_][(BH)], 0, 0, 0); \
+  if constexpr (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);
+
+// VAR: ablation switches of scratch/g8probe.hip (timing only, results are garbage): 1 no s_setprio, 2 wave groups in step,
+// 4 one barrier per phase, 8 no DMA after the prologue, 16 no fragment reads; the library always builds VAR = 0.
+template <class Epi, int VAR = 0>
+__global__ __launch_bounds__(G2_THREADS, 2) void gemm8p_kernel(GemmArgs p, Epi epi, int nbx, int nby) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nt = p.K / G2_BK;  // the launcher guarantees K % 128 == 0: an even number of K steps
+  const int ntiles = nbx * nby;
+  float* const scratch = reinterpret_cast<float*>(smem + 8 * G8_HALF);
+  int* const meta0 = reinterpret_cast<int*>(reinterpret_cast<char*>(scratch) + g8_scratch_bytes);
+
+  // Per-lane source offsets (bytes; the launcher guarantees operands below 4 GiB) of this wave's two DMA instructions per
+  // half-tile, for the tile the DMA front is in: instruction j covers the image rows (wave * 2 + j) * 8 + (lane >> 3); the 16-byte
+  // chunk c of image row r lives at position c ^ ((r >> 1) & 7) and the DMA writes lane-linearly, so the lane at position
+  // (lane & 7) fetches chunk (lane & 7) ^ ((r >> 1) & 7)  (source swizzle).  Plain scalars: an array selected at run time would
+  // live in scratch memory, and a scratch load in the K loop is a vmcnt(0).
+  unsigned oa00, oa01, oa10, oa11, ob00, ob01, ob10, ob11;
+  auto aim = [&](int bx, int by) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));  // opaque: nothing derived here is kept live (or spilled) across the K loop
+    const int ln = t_ & 63;
+    const int lr0 = (wave * 2 + 0) * 8 + (ln >> 3), lr1 = lr0 + 8;
+    const int c0 = ((ln & 7) ^ ((lr0 >> 1) & 7)) * 16, c1 = ((ln & 7) ^ ((lr1 >> 1) & 7)) * 16;
+    const int ar0 = by * G2_B + (lr0 >> 6) * 128 + (lr0 & 63), ar1 = by * G2_B + (lr1 >> 6) * 128 + (lr1 & 63);
+    const int br0 = bx * G2_B + (lr0 >> 5) * 64 + (lr0 & 31), br1 = bx * G2_B + (lr1 >> 5) * 64 + (lr1 & 31);
+    const unsigned la = (unsigned)p.lda * 2u, lb = (unsigned)p.ldb * 2u;
+    oa00 = (unsigned)min(ar0, p.M - 1) * la + c0;
+    oa01 = (unsigned)min(ar1, p.M - 1) * la + c1;
+    oa10 = (unsigned)min(ar0 + 64, p.M - 1) * la + c0;
+    oa11 = (unsigned)min(ar1 + 64, p.M - 1) * la + c1;
+    ob00 = (unsigned)min(br0, p.N - 1) * lb + c0;
+    ob01 = (unsigned)min(br1, p.N - 1) * lb + c1;
+    ob10 = (unsigned)min(br0 + 32, p.N - 1) * lb + c0;
+    ob11 = (unsigned)min(br1 + 32, p.N - 1) * lb + c1;
+  };
+  // the 1024 input words of the epilogue of the tile at (bx, by) -> meta buffer mb: two 4-byte LDS-DMAs per lane
+  auto fetch_meta = [&](int bx, int by, int* mb) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)epi.meta_src(by * G2_B, bx * G2_B, t_), (g2_lds_ptr*)(mb + wave * 64), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)epi.meta_src(by * G2_B, bx * G2_B, t_ + 512), (g2_lds_ptr*)(mb + 512 + wave * 64), 4, 0, 0);
+  };
+  // image addresses: buffer par, {A0, A1, B0, B1}
+  auto img = [&](int par, int which) { return smem + (par * 4 + which) * G8_HALF; };
+  bool dma_off = false;  // VAR & 8
+  // Stage one half-tile of K step TT (relative to the tile being computed; TT >= nt: the DMA front is in the next tile, whose
+  // offsets are in place by then) and wait until at most the five youngest half-tiles are in flight.  Never a branch: past the
+  // workgroup's last tile the front keeps fetching the same tile again into images nobody reads (a scalar branch in every load
+  // section costs more than the loads it would skip); the kernel drains vmcnt before it ends.
+#define G8_STAGE(P, O0, O1, TT, IMG)                                                                                              \
+  if ((VAR & 8) && dma_off) {                                                                                                     \
+  } else {                                                                                                                        \
+    const char* base_ = reinterpret_cast<const char*>(P) + (size_t)(((TT) >= nt ? (TT) - nt : (TT)) * (G2_BK * 2));               \
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(base_ + (size_t)(O0)), (g2_lds_ptr*)((IMG) + (wave * 2 + 0) * 512), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(base_ + (size_t)(O1)), (g2_lds_ptr*)((IMG) + (wave * 2 + 1) * 512), 16, 0, 0); \
+    g8_wait_vm<10>();                                                                                                             \
+  }
+
+  int tile = blockIdx.x, bx, by;
+  g2_tile_of(tile, nbx, nby, bx, by);
+  aim(bx, by);
+  int next = tile, nbx_ = bx, nby_ = by;
+  bool has_next = false;
+
+  bf16x8 af[8], bq[2][4];  // B0(t) lives in bq[t & 1], B1(t) in the other set; B0(t+1) replaces B1(t) in p3
+  G8Acc acc;
+  acc.zero();
+
+  // ---- prologue: the first tile's epilogue inputs, the DMAs of phases -7 .. -1 in schedule order, the B0 read of phase -1
+  fetch_meta(bx, by, meta0);
+  G8_STAGE(p.B, ob00, ob01, 0, img(0, 2));
+  G8_STAGE(p.A, oa00, oa01, 0, img(0, 0));
+  G8_STAGE(p.B, ob10, ob11, 0, img(0, 3));
+  G8_STAGE(p.A, oa10, oa11, 0, img(0, 1));
+  G8_STAGE(p.B, ob00, ob01, 1, img(1, 2));
+  G8_STAGE(p.A, oa00, oa01, 1, img(1, 0));  // ... vmcnt(10): B0(0) has landed
+  g8_bar();
+  g8_bar();
+  G8_RD_B(bq[0], img(0, 2));
+  G8_STAGE(p.B, ob10, ob11, 1, img(1, 3));  // ... A0(0) has landed
+  g8_wait_lgkm0();
+  g8_bar();
+  g8_bar();
+
+  int par = 0;  // meta buffer of the current tile
+  dma_off = true;
+  while (true) {
+    if (!(VAR & 2) && wm == 1) g8_bar();  // this wave group runs one barrier behind from here on
+    for (int t = 0; t < nt; t += 2) {
+#define G8_KSTEP(PAR, T, SWITCH)                                                                                 \
+  {                                                                                                              \
+    /* p0 */                                                                                                     \
+    G8_RD_A(img(PAR, 0));                                                                                        \
+    G8_STAGE(p.A, oa10, oa11, (T) + 1, img((PAR) ^ 1, 1));                                                       \
+    if (SWITCH) {                                                                                                \
+      /* from here on the DMA front is in the workgroup's next tile */                                          \
+      next = tile + (int)gridDim.x;                                                                              \
+      has_next = next < ntiles;                                                                                  \
+      if (has_next) {                                                                                            \
+        g2_tile_of(next, nbx, nby, nbx_, nby_);                                                                  \
+        aim(nbx_, nby_);                                                                                         \
+        fetch_meta(nbx_, nby_, meta0 + (par ^ 1) * 1024);                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+    g8_bar();                                                                                                    \
+    g8_wait_lgkm0();                                                                                             \
+    G8_MM(0, 0, bq[PAR]);                                                                                        \
+    if constexpr (!(VAR & 4)) g8_bar();                                                                          \
+    /* p1 */                                                                                                     \
+    G8_RD_B(bq[(PAR) ^ 1], img(PAR, 3));                                                                         \
+    G8_STAGE(p.B, ob00, ob01, (T) + 2, img(PAR, 2));                                                             \
+    g8_bar();                                                                                                    \
+    g8_wait_lgkm0();                                                                                             \
+    G8_MM(0, 1, bq[(PAR) ^ 1]);                                                                                  \
+    if constexpr (!(VAR & 4)) g8_bar();                                                                          \
+    /* p2 */                                                                                                     \
+    G8_RD_A(img(PAR, 1));                                                                                        \
+    G8_STAGE(p.A, oa00, oa01, (T) + 2, img(PAR, 0));                                                             \
+    g8_bar();                                                                                                    \
+    g8_wait_lgkm0();                                                                                             \
+    G8_MM(1, 1, bq[(PAR) ^ 1]);                                                                                  \
+    if constexpr (!(VAR & 4)) g8_bar();                                                                          \
+    /* p3 */                                                                                                     \
+    G8_RD_B(bq[(PAR) ^ 1], img((PAR) ^ 1, 2));                                                                   \
+    G8_STAGE(p.B, ob10, ob11, (T) + 2, img(PAR, 3));                                                             \
+    g8_bar();                                                                                                    \
+    g8_wait_lgkm0();                                                                                             \
+    G8_MM(1, 0, bq[PAR]);                                                                                        \
+    if constexpr (!(VAR & 4)) g8_bar();                                                                          \
+  }
+      G8_KSTEP(0, t, t == nt - 2);
+      G8_KSTEP(1, t + 1, false);
+    }
+    if (!(VAR & 2) && wm == 0) g8_bar();  // both wave groups in step again
+
+    // ---- epilogue of (bx, by)
+    int te = tid;
+    asm volatile("" : "+v"(te));  // opaque: the epilogue's lane arithmetic starts here, not above the K loop
+    const Tile8 tc{by * G2_B, bx * G2_B, wm, wn, te & 63, te, bx, by, nbx, scratch, meta0 + par * 1024};
+    // last tile: nothing of this workgroup may still be writing LDS when its place on the CU is handed on -- drained HERE, ahead of
+    // the epilogue's stores, which may outlive the workgroup (a launch with one workgroup per tile relies on that: the stores
+    // of a finished workgroup drain under the prologue of its successor)
+    if (!has_next) g8_wait_vm<0>();
+    epi.finish(acc, tc);
+    acc.zero();
+    if (!has_next) break;
+    par ^= 1;
+    tile = next;
+    bx = nbx_;
+    by = nby_;
+  }
+}
+
+// ---- cross-lane step of the accumulator layout: lanes i and i + 32 hold the same row ------------------------------------------
+// v_permlane32_swap D, S trades D's upper 32 lanes with S's lower 32; with D = S = x the pair becomes ([lo lo], [hi hi]): every
+// lane holds x[l] and x[l ^ 32].
+__device__ __forceinline__ float g8_max_x32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float g8_sum_x32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ int g8_isum_x32(int v) {
+  const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int)(r[0] + r[1]);
+}
+
+// Inputs shared by the sim epilogues.  Raw words arrive by LDS-DMA (meta_src); meta_fix() turns them, one entry per thread, into
+//   meta[e]          (e < 256)  1 where tile column e is masked or outside the matrix, else 0
+//   meta[256 + e]    gold column of tile row e (global column index), -1: none / row outside the matrix
+//   meta[512 + e]    second row word, untouched here (Epi8G: row logsumexp, Epi8Count: gold logit)
+//   meta[768 + w]    (w < 4) != 0 when a gold column of the rows fixed by wave 4 + w falls inside this tile
+struct Epi8Base {
+  EpiSim sim;         // mask source (colmask / packed layout), M, N, inv_T, y, y_offset, gold
+  const void* dummy;  // any valid device address: source of the words that have no input (no mask, no labels)
+
+  __device__ __forceinline__ const uint8_t* mask_byte(int n) const {
+    if (sim.packed != nullptr) {
+      const int r = n / sim.p_rows_c, j = n - r * sim.p_rows_c;
+      return sim.packed + (size_t)(r * sim.p_rows_c + sim.p_n_ctx) * sim.p_row_bytes + min(j, sim.p_n_ctx - 1);
+    }
+    return sim.colmask != nullptr ? sim.colmask + n : nullptr;
+  }
+  __device__ __forceinline__ const void* base_src(int m0, int n0, int e) const {
+    if (e < 256) {
+      const uint8_t* b = mask_byte(min(n0 + e, sim.N - 1));
+      return b != nullptr ? reinterpret_cast<const void*>(reinterpret_cast<uintptr_t>(b) & ~(uintptr_t)3) : dummy;
+    }
+    if (e < 512 && sim.y != nullptr) return reinterpret_cast<const int*>(sim.y) + 2 * min(m0 + e - 256, sim.M - 1);
+    return dummy;
+  }
+  __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const { return base_src(m0, n0, e); }
+  __device__ __forceinline__ void meta_fix(const Tile8& t) const {
+    if (t.tid < 256) {
+      const int e = t.tid, n = t.n0 + e;
+      const int raw = g8_lds_read(t.meta + e);
+      const uint8_t* b = mask_byte(min(n, sim.N - 1));
+      int flag = n >= sim.N ? 1 : 0;
+      if (b != nullptr) flag |= ((raw >> ((reinterpret_cast<uintptr_t>(b) & 3) * 8)) & 0xff) != 0 ? 1 : 0;
+      if (sim.packed != nullptr) flag |= (min(n, sim.N - 1) % sim.p_rows_c) >= sim.p_n_ctx ? 1 : 0;
+      g8_lds_write(t.meta + e, flag);
+    } else {
+      const int e = t.tid - 256;
+      const int rawy = g8_lds_read(t.meta + 256 + e);
+      const int yi = (sim.y != nullptr && t.m0 + e < sim.M) ? rawy + (int)sim.y_offset : -1;
+      g8_lds_write(t.meta + 256 + e, yi);
+      const bool hit = yi >= t.n0 && yi < t.n0 + G2_B;
+      const unsigned long long any = __ballot(hit);
+      if (t.lane == 0) g8_lds_write(t.meta + 768 + ((t.tid >> 6) - 4), any != 0ull ? 1 : 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    g8_bar();
+  }
+  __device__ __forceinline__ bool tile_has_gold(const Tile8& t) const {
+    const g8_i32x4 f = g8_lds_read4(t.meta + 768);
+    return (f[0] | f[1] | f[2] | f[3]) != 0;
+  }
+  // tile column of the lane's run q (0..3) of fragment column block b: 4 consecutive columns start here
+  __device__ __forceinline__ static int run_col(const Tile8& t, int b, int q) { return t.wn * 64 + b * 32 + q * 8 + (t.lane >> 5) * 4; }
+  // madd[b*4 + q][j]: 0, or -inf where that column is masked
+  __device__ __forceinline__ void col_madd(const Tile8& t, float (&madd)[8][4]) const {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const g8_i32x4 f = g8_lds_read4(t.meta + run_col(t, b, q));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) madd[b * 4 + q][j] = f[j] != 0 ? -INFINITY : 0.f;
+      }
+  }
+};
+
+// fp32 logits (sim_score with a caller buffer): S = acc / T, masked columns -inf   (dpr_task.py:104,211)
+struct Epi8Store : Epi8Base {
+  float* S;
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    meta_fix(t);
+    const int i = t.lane & 31;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cn = run_col(t, b, q);
+        const g8_i32x4 f = g8_lds_read4(t.meta + cn);
+        const int n = t.n0 + cn;
+        if (n >= sim.N) continue;  // N % 4 == 0: a run is inside or outside as a whole
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int m = t.m0 + t.wm * 128 + a * 32 + i;
+          if (m >= sim.M) continue;
+          float4 v;
+          v.x = f[0] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 0] * sim.inv_T;
+          v.y = f[1] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 1] * sim.inv_T;
+          v.z = f[2] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 2] * sim.inv_T;
+          v.w = f[3] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 3] * sim.inv_T;
+          *reinterpret_cast<float4*>(S + (size_t)m * sim.N + n) = v;
+        }
+      }
+  }
+};
+
+constexpr float kG8Log2e = 1.4426950408889634f, kG8Ln2 = 0.6931471805599453f;
+
+// Training forward WITHOUT the logits (dpr_task.py:211-212): per (row, 64-column wave strip) the maximum and sum exp(S - max)
+// go to part_m / part_s [M][npart] (npart = 4 * column tiles), the gold logit to sim.gold.  The logits themselves are never
+// stored: 8192 x 65536 of them are 2 GiB each way; the backward recomputes them tile by tile (Epi8G).
+struct Epi8Stats : Epi8Base {
+  float* part_m;
+  float* part_s;
+  int npart;
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    meta_fix(t);
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float madd[8][4];
+    col_madd(t, madd);
+    const bool anygold = sim.y != nullptr && tile_has_gold(t);
+    const float s2 = sim.inv_T * kG8Log2e;
+    const f32x2 s2v = {s2, s2};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x2 v[8][2];  // log2 units
+      float mx = -INFINITY;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x2 x = {acc.v[a][b][q * 4 + u * 2], acc.v[a][b][q * 4 + u * 2 + 1]};
+            const f32x2 md = {madd[b * 4 + q][u * 2], madd[b * 4 + q][u * 2 + 1]};
+            v[b * 4 + q][u] = x * s2v + md;
+            mx = fmaxf(mx, fmaxf(v[b * 4 + q][u][0], v[b * 4 + q][u][1]));
+          }
+      mx = g8_max_x32(mx);
+      const float mref = mx == -INFINITY ? 0.f : mx;
+      const f32x2 mr = {mref, mref};
+      f32x2 sm2 = {0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x2 d = v[c][u] - mr;
+          const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+          sm2 += e;
+        }
+      const float sm = g8_sum_x32(sm2[0] + sm2[1]);
+      const int m = t.m0 + t.wm * 128 + a * 32 + i;
+      if (h == 0 && m < sim.M) {
+        const size_t at = (size_t)m * npart + t.bx * 4 + t.wn;
+        part_m[at] = mx * kG8Ln2;
+        part_s[at] = sm;
+      }
+      if (anygold) {
+        const int yi = g8_lds_read(t.meta + 256 + t.wm * 128 + a * 32 + i);
+        const int rel = yi - (t.n0 + t.wn * 64 + h * 4);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (rel == b * 32 + q * 8 + j) sim.gold[m] = madd[b * 4 + q][j] != 0.f ? -INFINITY : acc.v[a][b][q * 4 + j] * sim.inv_T;
+      }
+    }
+  }
+};
+
+// Backward, first half (autograd of dpr_task.py:211-212 into the scores): the logits are recomputed (same GEMM, bit-identical
+// accumulators) and leave the tile as G = (softmax - onehot) * grad_scale in bf16, 2 bytes per score instead of the 4 + 4 + 2 of
+// store / re-read / G.  row_lse: natural-log logsumexp of every row (g8_lse_kernel).
+struct Epi8G : Epi8Base {
+  const float* row_lse;  // [M]
+  uint16_t* G;           // [M][N] bf16
+  float grad_scale;
+  __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const {
+    if (e >= 512 && e < 768) return row_lse + min(m0 + e - 512, sim.M - 1);
+    return base_src(m0, n0, e);
+  }
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    meta_fix(t);
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float madd[8][4];
+    col_madd(t, madd);
+    const bool anygold = sim.y != nullptr && tile_has_gold(t);
+    const float s2 = sim.inv_T * kG8Log2e;
+    const f32x2 s2v = {s2, s2};
+    const f32x2 gs = {grad_scale, grad_scale};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int lrow = t.wm * 128 + a * 32 + i;
+      const int m = t.m0 + lrow;
+      const float lse2 = __int_as_float(g8_lds_read(t.meta + 512 + lrow)) * kG8Log2e;
+      int rel = -1;
+      if (anygold) rel = g8_lds_read(t.meta + 256 + lrow) - (t.n0 + t.wn * 64 + h * 4);
+      const f32x2 l2 = {lse2, lse2};
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x2 g[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x2 x = {acc.v[a][b][q * 4 + u * 2], acc.v[a][b][q * 4 + u * 2 + 1]};
+            const f32x2 md = {madd[b * 4 + q][u * 2], madd[b * 4 + q][u * 2 + 1]};
+            const f32x2 d = (x * s2v + md) - l2;
+            f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};  // exp2(-inf) == 0 at masked columns
+            if (anygold) {
+              if (rel == b * 32 + q * 8 + u * 2) e[0] -= 1.0f;
+              if (rel == b * 32 + q * 8 + u * 2 + 1) e[1] -= 1.0f;
+            }
+            g[u] = e * gs;
+          }
+          const int n = t.n0 + run_col(t, b, q);
+          if (m < sim.M && n < sim.N)
+            *reinterpret_cast<uint2*>(G + (size_t)m * sim.N + n) = make_uint2(cvt_pk_bf16(g[0][0], g[0][1]), cvt_pk_bf16(g[1][0], g[1][1]));
+        }
+    }
+  }
+};
+
+// Validation rank metrics without the score matrix (dpr_task.py:235-246): rank = 1 + #{S > gold} + #{S == gold, column < gold
+// column} -- the position of the gold column in the reference's stable descending sort.  gold_val[m] must be the SAME number
+// this GEMM produces for (m, y[m]): g8_gold_kernel runs the identical MFMA sequence on the gathered context rows.
+struct Epi8Count : Epi8Base {
+  const float* gold_val;  // [M]
+  int* count;             // [M], zeroed by the caller; += per wave strip
+  __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const {
+    if (e >= 512 && e < 768) return gold_val + min(m0 + e - 512, sim.M - 1);
+    return base_src(m0, n0, e);
+  }
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    meta_fix(t);
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float madd[8][4];
+    col_madd(t, madd);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int lrow = t.wm * 128 + a * 32 + i;
+      const int m = t.m0 + lrow;
+      const float gv = __int_as_float(g8_lds_read(t.meta + 512 + lrow));
+      const int ycol = g8_lds_read(t.meta + 256 + lrow);
+      const int nbase = t.n0 + t.wn * 64 + h * 4;
+      int c = 0;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = madd[b * 4 + q][j] != 0.f ? -INFINITY : acc.v[a][b][q * 4 + j] * sim.inv_T;
+            const int n = nbase + b * 32 + q * 8 + j;
+            c += (n < sim.N && (v > gv || (v == gv && n < ycol))) ? 1 : 0;
+          }
+      c = g8_isum_x32(c);
+      if (h == 0 && m < sim.M && c != 0) atomicAdd(count + m, c);
+    }
+  }
+};
+
+// ---- the small kernels around the GEMM passes -------------------------------------------------------------------------------------
+// Row logsumexp from the strip statistics of Epi8Stats, row loss = lse - gold (dpr_task.py:212, CrossEntropyLoss per row).
+// One wave per row; fixed reduction order.
+__global__ __launch_bounds__(256) void g8_lse_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s, int npart,
+                                                     const float* __restrict__ gold, int M, float* __restrict__ lse_ws,
+                                                     float* __restrict__ row_lse, float* __restrict__ row_loss, float* __restrict__ loss_ws) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* pm = part_m + (size_t)row * npart;
+  const float* ps = part_s + (size_t)row * npart;
+  float mx = -INFINITY;
+  for (int k = lane; k < npart; k += 64) mx = fmaxf(mx, pm[k]);
+  mx = wave_max(mx);
+  float sm = 0.f;
+  if (mx != -INFINITY)
+    for (int k = lane; k < npart; k += 64) {
+      const float m = pm[k];
+      if (m != -INFINITY) sm += ps[k] * __expf(m - mx);
+    }
+  sm = wave_sum(sm);
+  if (lane == 0) {
+    const float lse = mx == -INFINITY ? -INFINITY : mx + logf(sm);
+    const float loss = lse - gold[row];
+    lse_ws[row] = lse;
+    loss_ws[row] = loss;
+    if (row_lse != nullptr) row_lse[row] = lse;
+    if (row_loss != nullptr) row_loss[row] = loss;
+  }
+}
+
+// The logit of every row's gold column, bit-identical to what gemm8p_kernel accumulates for that element: one wave per 32 rows runs
+// the same v_mfma_f32_32x32x16_bf16 chain (k slices of 16 in increasing order, from zero) on the rows of Q against the GATHERED rows
+// C[y[m]] and keeps the diagonal.  Lane (i, h) holds D[n' = 8*(r >> 2) + 4*h + (r & 3)][m' = i]: the diagonal element of row i is
+// register ((i >> 3) << 2) | (i & 3) of the lane with h == (i >> 2) & 1.
+__global__ __launch_bounds__(64) void g8_gold_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ C, int M, int N, int K,
+                                                     const int64_t* __restrict__ y, int64_t y_offset, EpiSim mask_src, float inv_T,
+                                                     float* __restrict__ gold) {
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int m = min(blockIdx.x * 32 + i, M - 1);
+  const int yc = (int)(y[m] + y_offset);
+  const int c = min(max(yc, 0), N - 1);
+  const uint16_t* qa = Q + (size_t)m * K + h * 8;
+  const uint16_t* cb = C + (size_t)c * K + h * 8;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int k = 0; k < K; k += 16) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(qa + k);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(cb + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc, 0, 0, 0);
+  }
+  const int want = ((i >> 3) << 2) | (i & 3);
+  float v = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v = want == r ? acc[r] : v;
+  if (h == ((i >> 2) & 1) && blockIdx.x * 32 + i < M) {
+    const bool masked = yc < 0 || yc >= N || mask_src.mask_at(c) != 0;
+    gold[m] = masked ? -INFINITY : v * inv_T;
+  }
+}
+
+// rank[m] = 1 + count[m]
+__global__ void g8_rank_finish_kernel(const int* __restrict__ count, int M, int64_t* __restrict__ rank) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m < M) rank[m] = 1 + (int64_t)count[m];
+}
+
+}  // namespace dprhot

@@ -290,6 +290,17 @@ class HipKernels:
                         "dprhot_rank_of_gold")
         return out
 
+    def sim_rank(self, Qb, Cb, y, colmask=None, inv_T=1.0, y_offset=0):
+        """rank_of_gold of the scores Qb x Cb^T * inv_T (masked columns -inf) without the score matrix at large shapes."""
+        self._require_gpu(Qb, Cb, y, colmask)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        rank = torch.empty(B, dtype=torch.int64, device=Qb.device)
+        ws = self._workspace(Qb.device, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_sim_rank(_ptr(Qb), B, _ptr(Cb), Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T),
+                                                 _ptr(rank), _ptr(ws), ws.numel(), self._stream()), "dprhot_sim_rank")
+        return rank
+
     def topk(self, S, k):
         self._require_gpu(S)
         rows, cols = S.shape
@@ -715,6 +726,29 @@ def rank_of_gold(S, labels, kernels=None):
     if S.shape[1] % 4 != 0:
         S = torch.nn.functional.pad(S, (0, 4 - S.shape[1] % 4), value=float("-inf"))
     return kn.rank_of_gold(S, labels)
+
+
+def rank_and_loss(q, c, labels, colmask=None, inv_T=1.0, kernels=None):
+    """(ranks [Nq] int64, mean cross-entropy) of scores = q x c^T * inv_T with masked columns at -inf -- what
+    compute_rank_metrics + self.loss (dpr_task.py:235-246,:299) derive from the score matrix, here without ever storing it
+    when the problem is large (validation over a whole epoch's embeddings: 8192 x 65536 logits would be 2 GiB)."""
+    kn = kernels if kernels is not None else default_kernels()
+    Nc = c.shape[0]
+    Nc_pad = _pad_cols(Nc)
+    Qb = kn.empty(tuple(q.shape), _BF16, q)
+    kn.cast_bf16(q, Qb)
+    Cb = kn.empty((Nc_pad, c.shape[1]), _BF16, c)
+    kn.cast_bf16(c, Cb[:Nc])
+    m8 = torch.zeros(Nc_pad, dtype=torch.uint8, device=c.device)
+    if colmask is not None:
+        m8[:Nc].copy_(colmask.view(torch.uint8) if colmask.dtype == torch.bool else colmask)
+    if Nc_pad != Nc:
+        Cb[Nc:].zero_()
+        m8[Nc:] = 1
+    y = torch.as_tensor(labels, dtype=torch.long, device=q.device)
+    ranks = kn.sim_rank(Qb, Cb, y, m8, inv_T)
+    _, _, loss_sum, _, _ = kn.inbatch_fwd(Qb, Cb, y, 0, m8, inv_T, 1.0, want_logits=False, want_G=False)
+    return ranks, (loss_sum / q.shape[0]).reshape(())
 
 
 def topk(S, k, kernels=None):

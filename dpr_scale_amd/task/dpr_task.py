@@ -227,6 +227,9 @@ class DenseRetrieverTask(LightningModule):
         looks the gold index up with one host sync per row (:237-245); here one count kernel, one sync."""
         labels = torch.as_tensor(target_labels, dtype=torch.long, device=pred_scores.device)
         ranks = hotpath.rank_of_gold(pred_scores.float(), labels, self.kernels)
+        return self._rank_stats(ranks)
+
+    def _rank_stats(self, ranks):
         r = ranks.double()
         stats = torch.stack([r.sum(), (1.0 / r).sum(), (ranks - 1 < self.k).double().sum()]).tolist()
         return int(stats[0]), stats[1], int(stats[2])
@@ -252,11 +255,20 @@ class DenseRetrieverTask(LightningModule):
                 c_g, m_g = self.all_gather((c_all, m_all))
                 labels = [x + c_g.size(1) * self.global_rank for x in labels]
                 c_all, m_all = c_g.flatten(0, 1), m_g.flatten(0, 1)
-            scores = self.sim_score(q_all, c_all, m_all)
             count = q_all.size(0)
-            ctx_count = scores.size(1) - torch.sum(m_all)
-            rank, mrr, score = self.compute_rank_metrics(scores, labels)
-            loss = self.loss(scores, torch.tensor(labels, dtype=torch.long, device=scores.device))
+            ctx_count = c_all.size(0) - torch.sum(m_all)
+            cls = type(self)
+            stock = (cls.sim_score is DenseRetrieverTask.sim_score and cls.compute_rank_metrics is DenseRetrieverTask.compute_rank_metrics
+                     and isinstance(self.loss, HotCrossEntropyLoss) and q_all.is_cuda)
+            if stock:
+                # the reference's formulation (:291-302) through the score-free kernels: ranks by count-greater inside the
+                # similarity GEMM, loss from its online softmax statistics -- the [Nq, Nc] matrix is never stored
+                ranks, loss = hotpath.rank_and_loss(q_all.detach(), c_all.detach(), labels, m_all.reshape(-1), 1.0, self.kernels)
+                rank, mrr, score = self._rank_stats(ranks)
+            else:
+                scores = self.sim_score(q_all, c_all, m_all)
+                rank, mrr, score = self.compute_rank_metrics(scores, labels)
+                loss = self.loss(scores, torch.tensor(labels, dtype=torch.long, device=scores.device))
         self.log_dict({
             f"{log_prefix}_avg_rank": rank / count,
             f"{log_prefix}_mrr": mrr / count,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 140 /* 0.1.40: + skinny-M step plan (B <= 128), pairwise scores, top-k up to 1024 */
+#define DPRHOT_VERSION 150 /* 0.1.50: + no-logits forward at large shapes (dprhot_dscores), dprhot_sim_rank */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -119,7 +119,13 @@ int dprhot_rank_of_gold(const float* S, int rows, int cols, const int64_t* y, in
  *   2. logsumexp from those pairs, then one streaming pass over the logits producing G (bf16), row_loss,
  *      row_lse and loss_sum[0] = sum_i row_loss[i] (fixed-point integer atomics: deterministic).
  * S_out may be NULL (logits live in the workspace) or a [B,Nc] fp32 buffer (debug / parity / eval).
- * row_loss, row_lse, G may be NULL.  `workspace` must hold dprhot_workspace_bytes(B, Nc, d) bytes. */
+ * row_loss, row_lse, G may be NULL.  `workspace` must hold dprhot_workspace_bytes(B, Nc, d) bytes.
+ * LARGE shapes (>= 256 tiles of 256 x 256, B > 128, d % 128 == 0) with S_out == NULL run the NO-LOGITS plan instead: the
+ * logits are never stored (at B = 8192, Nc = 65536 they would be 2 GiB, written once and read once) --
+ *   1. sim GEMM whose epilogue keeps only (max, sum-exp) per row and 64-column strip plus the gold logit,
+ *   2. logsumexp / loss from those,
+ *   3. the same GEMM again (bit-identical accumulators), its epilogue writing G = (softmax - onehot) * grad_scale as bf16.
+ * The workspace of such a shape holds no logit buffer.  Passing S_out selects the two-launch plan above at any shape. */
 int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y,
                        int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss,
                        float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace,
@@ -139,13 +145,31 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
  * Short rows (Nc <= 4096 and B <= 64): dprhot_sim_stats writes up to 4 split-K slabs of PARTIAL logits into the
  * workspace and leaves S_out alone; the summed logits exist only after dprhot_softmax_finish, which writes
  * them to its S_in argument when that is non-NULL (there S_in is an output).  Callers that want logits from
- * one call use dprhot_sim_fwd. */
+ * one call use dprhot_sim_fwd.
+ * No-logits shapes (see dprhot_inbatch_fwd) with S_out / S_in == NULL: dprhot_sim_stats leaves only statistics,
+ * dprhot_softmax_finish turns them into row_lse / row_loss / loss_sum and must be given G == NULL (there are no logits to
+ * stream; DPRHOT_E_UNSUPPORTED otherwise), and dprhot_dscores is the third launch. */
 int dprhot_sim_stats(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y,
                      int64_t y_offset, const uint8_t* colmask, float inv_T, float* S_out, void* workspace,
                      size_t workspace_bytes, void* stream);
 int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t* y, int64_t y_offset,
                           float grad_scale, float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Third launch of the no-logits forward: G[B,Nc] (bf16) = (softmax(S) - onehot(y + y_offset)) * grad_scale with
+ * S = (Q x C^T) * inv_T recomputed tile by tile on the MFMA (never stored).  row_lse [B]: the rows' logsumexp, or NULL to use
+ * what dprhot_softmax_finish left in `workspace`.  DPRHOT_E_UNSUPPORTED at shapes that are not no-logits shapes. */
+int dprhot_dscores(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                   const uint8_t* colmask, float inv_T, float grad_scale, const float* row_lse, dprhot_bf16* G,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* compute_rank_metrics (dpr_task.py:235-246) straight from the embeddings: rank as dprhot_rank_of_gold of
+ * S = (Q x C^T) * inv_T with masked columns at -inf, bit-exact.  At no-logits shapes S is never written: the gold logits
+ * come from a gathered mini GEMM that runs the identical MFMA chain, the count-greater happens in the similarity GEMM's
+ * epilogue.  Smaller problems score into the workspace and count there. */
+int dprhot_sim_rank(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                    const uint8_t* colmask, float inv_T, int64_t* rank, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* The same forward reading the encoder outputs as they are (fp32), so that no separate cast launch and no extra
  * round trip through HBM is needed: q [B,d] fp32; c [Nc,d] fp32 when the rank holds every column (world size

@@ -714,3 +714,100 @@ def test_short_and_long_forward_plans_agree(kn, dev, monkeypatch):
     assert np.abs(outs[0][2] - outs[1][2]).max() <= 2.0 ** -8 * np.abs(outs[1][2]).max()  # bf16 G: at most 1 ulp apart
     fin = np.isfinite(outs[1][3])
     assert np.array_equal(fin, np.isfinite(outs[0][3])) and rel(outs[0][3][fin], outs[1][3][fin]) <= 1e-6
+
+
+# ---- large shapes: the no-logits forward (gemm8p.h) and the score-free rank --------------------------------------------------
+NL_SHAPES = [(4096, 4096, 256), (1000, 16392, 128), (300, 70000, 128)]  # >= 256 tiles of 256 x 256; ragged rows and columns
+
+
+def _nl_problem(B, Nc, d, seed, dev, dup=False):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16)
+    c = (torch.randn(Nc, d, generator=gen) * d ** -0.25).to(torch.bfloat16)
+    if dup:  # exact score ties: copies of context rows spread over the matrix
+        src = torch.randint(0, Nc, (Nc // 16,), generator=gen)
+        dst = torch.randint(0, Nc, (Nc // 16,), generator=gen)
+        c[dst] = c[src]
+    y = torch.randint(0, Nc, (B,), generator=gen)
+    mask = torch.rand(Nc, generator=gen) < 0.05
+    mask[y[: B // 2]] = False  # half of the gold columns may be masked (-inf gold logit)
+    return q.to(dev), c.to(dev), y.to(dev), mask.to(torch.uint8).to(dev)
+
+
+@pytest.mark.parametrize("B,Nc,d", NL_SHAPES)
+def test_no_logits_forward_equals_the_two_launch_plan(B, Nc, d, kn, dev):
+    """dprhot_inbatch_fwd without S_out at a large shape runs statistics pass -> logsumexp -> dScores pass (logits recomputed, never
+    stored); with S_out it runs the round-1 plan (logits stored, streaming softmax).  Same loss, logsumexp, G."""
+    Qb, Cb, y, m8 = _nl_problem(B, Nc, d, 11, dev)
+    m8[y] = 0
+    assert kn._lib.workspace_bytes(B, Nc, d) < B * Nc * 4, "the workspace of a no-logits shape holds no logit buffer"
+    rl0, lse0, ls0, G0, S0 = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=True)
+    rl1, lse1, ls1, G1, S1 = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
+    assert S1 is None
+    assert ((lse1 - lse0).abs().max() / lse0.abs().max()).item() <= 1e-6
+    assert ((rl1 - rl0).abs().max() / rl0.abs().max()).item() <= 1e-5
+    assert abs(ls1.item() - ls0.item()) <= 1e-5 * abs(ls0.item())
+    g0, g1 = G0.float(), G1.float()
+    assert ((g1 - g0).abs() <= 2.0 ** -7 * g0.abs() + 1e-12).all()  # bf16: at most one ulp apart (exp2 vs exp formulation)
+    assert torch.all(g1[:, m8.bool()] == 0) and g1.sum(dim=1).abs().max().item() <= 2e-2 / B
+    # against fp32 torch on the stored logits of the other plan
+    ref = torch.softmax(S0, dim=1)
+    ref[torch.arange(B, device=dev), y] -= 1.0
+    assert ((g1 - ref / B).abs().max() / (ref / B).abs().max()).item() <= 2.0 ** -8
+
+
+def test_no_logits_forward_from_fp32_inputs_and_autograd(dev):
+    """The fp32 entry point and the autograd operator at a no-logits shape against fp32 torch (reference formulation,
+    dpr_task.py:197-212)."""
+    from dpr_scale_amd.hotpath import inbatch_contrastive_loss
+
+    B, K, d = 2048, 16, 128  # Nc = 32768: 8 x 128 tiles
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev)
+    c = (torch.randn(B * K, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev)
+    y = (torch.arange(B) * K).to(dev)
+    mask = (torch.rand(B * K, generator=gen) < 0.02).to(dev)
+    mask[y] = False
+    tq, tc = q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    loss = inbatch_contrastive_loss(tq, tc, y, mask, 0.7)
+    loss.backward()
+    rq, rc = q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    S = (rq @ rc.T).masked_fill(mask[None, :], float("-inf")) / 0.7
+    ref = torch.nn.functional.cross_entropy(S, y)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) <= LOSS_RTOL * abs(ref.item())
+    assert ((tq.grad - rq.grad).abs().max() / rq.grad.abs().max()).item() <= GRAD_RTOL
+    assert ((tc.grad - rc.grad).abs().max() / rc.grad.abs().max()).item() <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("B,Nc,d", NL_SHAPES + [(64, 1000, 64)])
+def test_score_free_rank_is_bit_exact(B, Nc, d, kn, dev):
+    """dprhot_sim_rank (gold logits from the gathered mini GEMM + count-greater in the GEMM epilogue; no score matrix at large
+    shapes) == rank_of_gold of the stored scores == position in the reference's stable descending sort, ties included."""
+    Nc8 = (Nc + 7) // 8 * 8
+    Qb, Cb, y, m8 = _nl_problem(B, Nc8, d, 23, dev, dup=True)
+    S = kn.sim(Qb, Cb, m8, 1.0)
+    want = kn.rank_of_gold(S, y)
+    got = kn.sim_rank(Qb, Cb, y, m8, 1.0)
+    assert torch.equal(got, want)
+    sub = torch.arange(0, B, max(1, B // 64), device=dev)
+    order = torch.sort(S[sub], dim=1, descending=True, stable=True).indices
+    ref_rank = (order == y[sub][:, None]).nonzero()[:, 1] + 1
+    assert torch.equal(got[sub], ref_rank)
+
+
+def test_rank_and_loss_helper_matches_score_matrix_path(kn, dev):
+    from dpr_scale_amd import hotpath
+
+    B, Nc, d = 1024, 16390, 128  # ragged column count: padded with masked columns inside
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev)
+    c = (torch.randn(Nc, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev)
+    y = torch.randint(0, Nc, (B,), generator=gen).to(dev)
+    mask = (torch.rand(Nc, generator=gen) < 0.05).to(dev)
+    mask[y] = False
+    ranks, loss = hotpath.rank_and_loss(q, c, y, mask, 1.0, kn)
+    S = hotpath.sim_score(q, c, mask, 1.0, kn)
+    assert torch.equal(ranks, hotpath.rank_of_gold(S, y, kn))
+    ref = torch.nn.functional.cross_entropy(S, y)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
