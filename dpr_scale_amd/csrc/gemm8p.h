@@ -86,8 +86,10 @@ struct Tile8 {
   int wm, wn;       // wave position (2 x 4): rows wm * 128.., columns wn * 64..
   int lane, tid;
   int bx, by, nbx;  // tile indices, column-tile count
-  float* scratch;   // LDS, g8_scratch_bytes
-  int* meta;        // LDS: the tile's 1024 input words, fetched by LDS-DMA from Epi::meta_src while the previous tile was computed
+  float* scratch;   // LDS, g8_scratch_bytes (gemm8p) / unused (gemm2w)
+  int* meta;        // LDS: the tile's input words, fetched by LDS-DMA from Epi::meta_src while the previous tile was computed
+  int ncol = G2_B;  // tile columns: 256 (gemm8p.h, 4 wave strips) or 128 (gemm2w.h, 2 wave strips)
+  int nthr = G2_THREADS;
 };
 
 // The wave's 128 x 64 accumulators: v[a][b] (a < 4, b < 2) of 16 registers; lane (i = lane & 31, h = lane >> 5), register r:
@@ -313,7 +315,7 @@ __device__ __forceinline__ int g8_isum_x32(int v) {
 //   meta[e]          (e < 256)  1 where tile column e is masked or outside the matrix, else 0
 //   meta[256 + e]    gold column of tile row e (global column index), -1: none / row outside the matrix
 //   meta[512 + e]    second row word, untouched here (Epi8G: row logsumexp, Epi8Count: gold logit)
-//   meta[768 + w]    (w < 4) != 0 when a gold column of the rows fixed by wave 4 + w falls inside this tile
+//   meta[768 + w]    (w < 4) != 0 when a gold column of the rows fixed by wave w falls inside this tile
 struct Epi8Base {
   EpiSim sim;         // mask source (colmask / packed layout), M, N, inv_T, y, y_offset, gold
   const void* dummy;  // any valid device address: source of the words that have no input (no mask, no labels)
@@ -335,22 +337,23 @@ struct Epi8Base {
   }
   __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const { return base_src(m0, n0, e); }
   __device__ __forceinline__ void meta_fix(const Tile8& t) const {
-    if (t.tid < 256) {
-      const int e = t.tid, n = t.n0 + e;
+    if (t.tid < 256) {  // row entry tid
+      const int e = t.tid;
+      const int rawy = g8_lds_read(t.meta + 256 + e);
+      const int yi = (sim.y != nullptr && t.m0 + e < sim.M) ? rawy + (int)sim.y_offset : -1;
+      g8_lds_write(t.meta + 256 + e, yi);
+      const bool hit = yi >= t.n0 && yi < t.n0 + t.ncol;
+      const unsigned long long any = __ballot(hit);
+      if (t.lane == 0) g8_lds_write(t.meta + 768 + (t.tid >> 6), any != 0ull ? 1 : 0);
+    }
+    if (t.tid >= t.nthr - t.ncol) {  // column entry: the last ncol threads (512 threads: a different half than the rows)
+      const int e = t.tid - (t.nthr - t.ncol), n = t.n0 + e;
       const int raw = g8_lds_read(t.meta + e);
       const uint8_t* b = mask_byte(min(n, sim.N - 1));
       int flag = n >= sim.N ? 1 : 0;
       if (b != nullptr) flag |= ((raw >> ((reinterpret_cast<uintptr_t>(b) & 3) * 8)) & 0xff) != 0 ? 1 : 0;
       if (sim.packed != nullptr) flag |= (min(n, sim.N - 1) % sim.p_rows_c) >= sim.p_n_ctx ? 1 : 0;
       g8_lds_write(t.meta + e, flag);
-    } else {
-      const int e = t.tid - 256;
-      const int rawy = g8_lds_read(t.meta + 256 + e);
-      const int yi = (sim.y != nullptr && t.m0 + e < sim.M) ? rawy + (int)sim.y_offset : -1;
-      g8_lds_write(t.meta + 256 + e, yi);
-      const bool hit = yi >= t.n0 && yi < t.n0 + G2_B;
-      const unsigned long long any = __ballot(hit);
-      if (t.lane == 0) g8_lds_write(t.meta + 768 + ((t.tid >> 6) - 4), any != 0ull ? 1 : 0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     g8_bar();
@@ -406,7 +409,7 @@ struct Epi8Store : Epi8Base {
 constexpr float kG8Log2e = 1.4426950408889634f, kG8Ln2 = 0.6931471805599453f;
 
 // Training forward WITHOUT the logits (dpr_task.py:211-212): per (row, 64-column wave strip) the maximum and sum exp(S - max)
-// go to part_m / part_s [M][npart] (npart = 4 * column tiles), the gold logit to sim.gold.  The logits themselves are never
+// go to part_m / part_s [M][npart] (npart = column tiles x wave strips per tile), the gold logit to sim.gold.  The logits themselves are never
 // stored: 8192 x 65536 of them are 2 GiB each way; the backward recomputes them tile by tile (Epi8G).
 struct Epi8Stats : Epi8Base {
   float* part_m;
@@ -450,7 +453,7 @@ struct Epi8Stats : Epi8Base {
       const float sm = g8_sum_x32(sm2[0] + sm2[1]);
       const int m = t.m0 + t.wm * 128 + a * 32 + i;
       if (h == 0 && m < sim.M) {
-        const size_t at = (size_t)m * npart + t.bx * 4 + t.wn;
+        const size_t at = (size_t)m * npart + t.bx * (t.ncol >> 6) + t.wn;
         part_m[at] = mx * kG8Ln2;
         part_s[at] = sm;
       }
