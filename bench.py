@@ -136,8 +136,15 @@ class HotPathStep:
                         self.gscale, 1.0, P(self.go), P(self.row_loss), P(self.row_lse), P(self.loss_sum), P(self.G), P(self.dQ),
                         P(self.dC), ws, wsb, st)
         self.a_sim = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, None, ws, wsb, st)
+        # no-logits shapes (large B x Nc: the workspace then holds no logit buffer): softmax_finish only derives logsumexp / loss
+        # from the strip statistics, the dScores come from a third launch that recomputes the logits (dprhot_dscores)
+        self.nl = self.ws_bytes < 4 * B * Nc
         self.a_fin = (None, B, Nc, d, P(self.y), off, self.gscale, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
-                      P(self.G), ws, wsb, st)
+                      None if self.nl else P(self.G), ws, wsb, st)
+        self.a_dsc = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, self.gscale, None, P(self.G),
+                      ws, wsb, st)
+        self.rank = torch.empty(B, dtype=torch.int64, device=self.G.device)
+        self.a_rank = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, P(self.rank), ws, wsb, st)
 
     def _call(self, fn, args):
         rc = fn(*args)
@@ -171,6 +178,12 @@ class HotPathStep:
 
     def k_softmax(self):
         self._call(self.lib.dprhot_softmax_finish, self.a_fin)
+
+    def k_dscores(self):
+        self._call(self.lib.dprhot_dscores, self.a_dsc)
+
+    def k_rank(self):
+        self._call(self.lib.dprhot_sim_rank, self.a_rank)
 
     def k_step(self):
         if self.packed_step:
@@ -329,15 +342,27 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
 
 
 def roofline_at_scale(dev, d, B=8192, Nc=8192):
-    """Extra information (never `value`): the same three kernels families at a size where a roofline means something
-    -- B x Nc = 8192 x 8192 logits per rank (one large-batch step on one GPU), per-launch HIP-event timing as above."""
+    """Extra information (never `value`): the same kernel families at a size where a roofline means something -- B x Nc =
+    8192 x 8192 logits per rank (one large-batch step on one GPU), per-launch HIP-event timing as above.  At this size the
+    library runs the no-logits forward: statistics GEMM (sim_gemm) -> logsumexp (lse_loss) -> dScores GEMM that recomputes the
+    logits and writes G as bf16 (dscores_gemm) -> the backward pair (backward_gemms); score_free_rank is the validation-side
+    count-greater GEMM (gold mini-GEMM + count + finish)."""
     hp = HotPathStep(B, Nc // B, d, 1.0, 1, 0, dev)
     bn, bd, nd = float(B) * Nc, float(B) * d, float(Nc) * d
     hp.k_prep()
-    out = {"workload": f"B={B} x Nc={Nc} x d={d} (bf16 operands resident), per launch"}
-    for name, fn, by, fl, bound in (("sim_gemm", hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d, "mfma"),
-                                    ("softmax_dscores", hp.k_softmax, 6 * bn, 0.0, "hbm"),
-                                    ("backward_gemms", hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d, "mfma")):
+    out = {"workload": f"B={B} x Nc={Nc} x d={d} (bf16 operands resident), per launch",
+           "forward_plan": "no-logits (stats GEMM -> lse -> dScores GEMM)" if hp.nl else "logits stored (sim GEMM -> streaming softmax)"}
+    if hp.nl:
+        rows = (("sim_gemm", hp.k_sim, 2 * (bd + nd) + 8 * bn / 64, 2 * bn * d, "mfma"),
+                ("lse_loss", hp.k_softmax, 8 * bn / 64 + 12 * B, 0.0, "hbm"),
+                ("dscores_gemm", hp.k_dscores, 2 * (bd + nd) + 2 * bn, 2 * bn * d, "mfma"),
+                ("backward_gemms", hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d, "mfma"),
+                ("score_free_rank", hp.k_rank, 2 * (bd + nd), 2 * bn * d, "mfma"))
+    else:
+        rows = (("sim_gemm", hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d, "mfma"),
+                ("softmax_dscores", hp.k_softmax, 6 * bn, 0.0, "hbm"),
+                ("backward_gemms", hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d, "mfma"))
+    for name, fn, by, fl, bound in rows:
         us = time_kernel(hp, fn, reps=20, iters=3)
         if bound == "mfma":
             ach = fl / us * 1e-6
@@ -347,6 +372,10 @@ def roofline_at_scale(dev, d, B=8192, Nc=8192):
             ach = by / us * 1e-3
             out[name] = {"us": round(us, 1), "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4)}
+    if hp.nl:
+        out["forward_us"] = round(out["sim_gemm"]["us"] + out["lse_loss"]["us"] + out["dscores_gemm"]["us"], 1)
+        out["step_us"] = round(out["forward_us"] + out["backward_gemms"]["us"], 1)
+        out["step_mfma_frac"] = round(8 * bn * d / out["step_us"] * 1e-6 / MFMA_PEAK_TFLOPS, 4)
     del hp
     torch.cuda.empty_cache()
     return out

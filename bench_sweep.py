@@ -35,12 +35,14 @@ def main():
         kern = {
             "sim_stats_f32": (hp.k_sim32, 6 * bd + 6 * nd + 4 * bn, 2 * bn * d),
             "prep": (hp.k_prep, 6 * (bd + nd), 0.0),
-            "sim_stats_bf16": (hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d),
-            "softmax_finish": (hp.k_softmax, 6 * bn, 0.0),
-            "bwd_pair": (hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d),
+            "sim_stats_bf16": (hp.k_sim, 2 * (bd + nd) + (0 if hp.nl else 4 * bn), 2 * bn * d),
+            "softmax_finish": (hp.k_softmax, 8 * bn / 64 if hp.nl else 6 * bn, 0.0),
         }
+        if hp.nl:  # no-logits forward: the dScores come from a GEMM pass that recomputes the logits
+            kern["dscores"] = (hp.k_dscores, 2 * (bd + nd) + 2 * bn, 2 * bn * d)
+        kern["bwd_pair"] = (hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d)
         reps = 20 if bn * d < 1e11 else 4
-        row = {"B": B, "Nc": Nc, "d": d}
+        row = {"B": B, "Nc": Nc, "d": d, "forward_plan": "no-logits" if hp.nl else "logits"}
         tot = 0.0
         for name, (fn, by, fl) in kern.items():
             us = time_kernel(hp, fn, reps=reps, iters=5)

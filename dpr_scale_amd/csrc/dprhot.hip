@@ -22,6 +22,7 @@
 #include "gemm_bf16.h"
 #include "gemm256.h"
 #include "gemm8p.h"
+#include "gemm8pb.h"
 #include "rowwise.h"
 #include "step_small.h"
 #include "skinny.h"
@@ -323,7 +324,7 @@ DqPlan dq_plan(int B, int Nc, int d) {
     if (splits > 16) splits = 16;
     if (splits < 1) splits = 1;
     p.tile = kBigTile;
-    p.kchunk = cdiv(cdiv(Nc, 64), splits) * 64;
+    p.kchunk = cdiv(cdiv(Nc, 128), splits) * 128;  // an even number of 64-deep K steps per slice (gemm8pb.h)
     p.splits = cdiv(Nc, p.kchunk);
     return p;
   }
@@ -1047,6 +1048,21 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     const int nbx1 = cdiv(d, G2_B), nby1 = cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
     a1.kchunk = B;  // dC: one K range (B % 64 == 0)
     const int grid = nbx1 * nby1 + nbx2 * nby2 * p.splits;
+    static const bool no8 = getenv("DPRHOT_NO_8PB") != nullptr;
+    if (!no8 && B % 128 == 0 && Nc % 128 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9) {
+      // the phase-interleaved schedule (gemm8pb.h): an even number of K steps per unit, byte offsets in 32 bits
+      auto k8 = gemm8p_bwd_kernel<Epi8Scale>;
+      static bool attr8_done = false;
+      if (!attr8_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+        attr8_done = true;
+      }
+      const Epi8Scale s1{e1.out, e1.M, e1.N, e1.h_scale, e1.d_scale, e1.stamp_src, e1.stamp_period, e1.stamp_row};
+      const Epi8Scale s2{e2.out, e2.M, e2.N, e2.h_scale, e2.d_scale, e2.stamp_src, e2.stamp_period, e2.stamp_row};
+      hipLaunchKernelGGL(k8, dim3((unsigned)grid), dim3(G2_THREADS), g8_lds_total, st, a1, s1, nbx1, nby1, a2, s2, nbx2, nby2, p.splits);
+      HIP_TRY(hipGetLastError());
+      return launch_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, ws, wl, st, /*gemm_too=*/false);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g2_lds_total, st, a1, e1, nbx1, nby1, a2, e2, nbx2, nby2, p.splits);
     HIP_TRY(hipGetLastError());
     return launch_dq(G, C, B, Nc, d, h_scale, d_scale, dQ, ws, wl, st, /*gemm_too=*/false);

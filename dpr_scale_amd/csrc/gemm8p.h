@@ -501,10 +501,10 @@ struct Epi8G : Epi8Base {
       if (anygold) rel = g8_lds_read(t.meta + 256 + lrow) - (t.n0 + t.wn * 64 + h * 4);
       const f32x2 l2 = {lse2, lse2};
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b) {
+        unsigned pk[4][2];  // run q: two dwords = 4 bf16 = columns q*8 + h*4 ..
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x2 g[2];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const f32x2 x = {acc.v[a][b][q * 4 + u * 2], acc.v[a][b][q * 4 + u * 2 + 1]};
@@ -515,12 +515,20 @@ struct Epi8G : Epi8Base {
               if (rel == b * 32 + q * 8 + u * 2) e[0] -= 1.0f;
               if (rel == b * 32 + q * 8 + u * 2 + 1) e[1] -= 1.0f;
             }
-            g[u] = e * gs;
+            const f32x2 g = e * gs;
+            pk[q][u] = cvt_pk_bf16(g[0], g[1]);
           }
-          const int n = t.n0 + run_col(t, b, q);
-          if (m < sim.M && n < sim.N)
-            *reinterpret_cast<uint2*>(G + (size_t)m * sim.N + n) = make_uint2(cvt_pk_bf16(g[0][0], g[0][1]), cvt_pk_bf16(g[1][0], g[1][1]));
+        // Lanes i and i + 32 hold the two halves of every 8-column run.  One v_permlane32_swap per dword pairs run 2p (kept by the
+        // lower lane) with run 2p + 1 (kept by the upper lane): every lane then owns one WHOLE run = 16 contiguous bytes, and the
+        // two lanes of a row write 32 contiguous bytes -- half the store instructions, twice the bytes per request (guide T21).
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+          const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+          const int n = t.n0 + t.wn * 64 + b * 32 + (2 * pr + h) * 8;
+          if (m < sim.M && n < sim.N) *reinterpret_cast<uint4*>(G + (size_t)m * sim.N + n) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
         }
+      }
     }
   }
 };
@@ -539,25 +547,38 @@ struct Epi8Count : Epi8Base {
     meta_fix(t);
     const int i = t.lane & 31, h = t.lane >> 5;
     float madd[8][4];
-    col_madd(t, madd);
+    col_madd(t, madd);  // columns outside the matrix are flagged too: -inf there, never counted (they lie behind every gold column)
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int lrow = t.wm * 128 + a * 32 + i;
       const int m = t.m0 + lrow;
       const float gv = __int_as_float(g8_lds_read(t.meta + 512 + lrow));
-      const int ycol = g8_lds_read(t.meta + 256 + lrow);
-      const int nbase = t.n0 + t.wn * 64 + h * 4;
       int c = 0;
+      bool tie = false;
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float v = madd[b * 4 + q][j] != 0.f ? -INFINITY : acc.v[a][b][q * 4 + j] * sim.inv_T;
-            const int n = nbase + b * 32 + q * 8 + j;
-            c += (n < sim.N && (v > gv || (v == gv && n < ycol))) ? 1 : 0;
+            // fma(acc, 1/T, 0) is acc / T as the logit store rounds it; fma(acc, 1/T, -inf) is the masked column's -inf
+            const float v = fmaf(acc.v[a][b][q * 4 + j], sim.inv_T, madd[b * 4 + q][j]);
+            c += v > gv ? 1 : 0;
+            tie |= v == gv;
           }
+      if (__ballot(tie) != 0ull) {  // exact ties (always: the tile that holds the gold column itself): lower column index first
+        const int ycol = g8_lds_read(t.meta + 256 + lrow);
+        const int nbase = t.n0 + t.wn * 64 + h * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float v = fmaf(acc.v[a][b][q * 4 + j], sim.inv_T, madd[b * 4 + q][j]);
+              c += (v == gv && nbase + b * 32 + q * 8 + j < ycol) ? 1 : 0;
+            }
+      }
       c = g8_isum_x32(c);
       if (h == 0 && m < sim.M && c != 0) atomicAdd(count + m, c);
     }
