@@ -80,10 +80,23 @@ def bench_rank(nq, nc, d, iters):
         ranks = (indices == y[:, None]).nonzero()[:, 1] + 1
         return ranks.sum(), (1.0 / ranks.double()).sum(), (ranks <= 1).sum()
 
+    def free():  # ranks AND mean loss without the score matrix (what _eval_epoch_end runs): count-greater GEMM + statistics GEMM
+        from dpr_scale_amd.hotpath import rank_and_loss
+
+        r, loss = rank_and_loss(q, c, y, None, 1.0, kn)
+        return r.sum(), (1.0 / r.double()).sum(), (r <= 1).sum(), loss
+
     t_ours, o = _time(ours, iters)
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    t_free, f = _time(free, iters)
+    peak_free = torch.cuda.max_memory_allocated() - base
     t_ref, r = _time(ref, iters)
     return {"what": "rank", "workload": f"Nq={nq} Nc={nc} d={d} fp32 embeddings in, fp32 logits",
             "ms": round(t_ours * 1e3, 3), "queries_per_s": round(nq / t_ours, 1),
+            "score_free_ms_ranks_and_loss": round(t_free * 1e3, 3), "score_free_sum_rank": int(f[0]),
+            "score_free_equals_score_matrix_ranks": bool(int(f[0]) == int(o[0]) and float(f[1]) == float(o[1])),
+            "score_free_peak_extra_bytes": int(peak_free), "score_matrix_bytes": int(nq) * int(nc) * 4,
             "torch_matmul_sort_ms": round(t_ref * 1e3, 3), "speedup_vs_torch": round(t_ref / t_ours, 2),
             "sum_rank": int(o[0]), "torch_sum_rank": int(r[0]), "note": "torch scores in fp32/TF32-off matmul; ours bf16 inputs"}
 
