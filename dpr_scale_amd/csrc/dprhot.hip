@@ -357,7 +357,7 @@ int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >
 // Few query rows against many contexts (skinny.h): B <= 128 (a multiple of 32), d a multiple of 128 up to 1024, 2048 <= Nc <= 16384
 // (measured: at Nc ~ 1000 the short-row plan below is as fast or faster)
 // (beyond that the per-unit recomputation of the row logsumexp from Nc / 128 tile values stops being cheap).
-struct SkPlan { bool ok; int nt, nrb, ksteps, nslices; };
+struct SkPlan { bool ok; int nt, nts, scols, nrb, ksteps, nslices; };
 SkPlan sk_plan(int B, int Nc, int d) {
   static const bool off = getenv("DPRHOT_NO_SKINNY") != nullptr;
   static const int min_nc = []() { const char* e = getenv("DPRHOT_SKINNY_MIN_NC"); return e ? atoi(e) : 2048; }();
@@ -365,6 +365,14 @@ SkPlan sk_plan(int B, int Nc, int d) {
   p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
          Nc <= 16384 && !(B <= SS_ROWS && Nc <= SS_MAXNC);
   p.nt = cdiv(Nc, SK_COLS);
+  {
+    // sim unit width: 128 columns x 4 ring slots (default) or DPRHOT_SK_COLS=64: 64 columns x 8 slots -- twice the units, two thirds of a
+    // unit's K range in flight at once.  Measured at cfg3 per rank: 12.4 vs 11.0 us for the sim launch (and 7.5 vs 5.8 us for the G launch,
+    // which then folds twice the tile statistics): the unit is not bound by its ring refills.  Kept as an A/B switch.
+    static const bool narrow = []() { const char* e = getenv("DPRHOT_SK_COLS"); return e && atoi(e) == 64; }();
+    p.scols = narrow ? SK_SCOLS : SK_COLS;
+  }
+  p.nts = cdiv(Nc, p.scols);  // statistics tiles = sim units per row block
   p.nrb = cdiv(B, SK_ROWS);
   const int nk = cdiv(Nc, 64), ndt = d / SK_QN;
   int ns = kNumCU / 2 / ndt;  // dQ units: (slice of contexts) x (64 columns of d); ~half a unit per CU measured best: the
@@ -482,19 +490,19 @@ int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
 }
 
 // ---- few rows x many contexts: the four launches of skinny.h -------------------------------------------------------
-template <int NCH>
-int launch_sk_sim(const SkSimArgs& a, int grid, hipStream_t st) {
+template <int NCH, int COLS, int SLOTS>
+int launch_sk_sim_c(const SkSimArgs& a, int grid, hipStream_t st) {
   const size_t lds = sk_sim_lds();
   static bool attr_done[2] = {false, false};  // benign race: idempotent
   if (a.q != nullptr) {
-    auto kern = sk_sim_kernel<NCH, true>;
+    auto kern = sk_sim_kernel<NCH, true, COLS, SLOTS>;
     if (!attr_done[0]) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_done[0] = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SK_THREADS), lds, st, a);
   } else {
-    auto kern = sk_sim_kernel<NCH, false>;
+    auto kern = sk_sim_kernel<NCH, false, COLS, SLOTS>;
     if (!attr_done[1]) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_done[1] = true;
@@ -503,6 +511,10 @@ int launch_sk_sim(const SkSimArgs& a, int grid, hipStream_t st) {
   }
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
+}
+template <int NCH>
+int launch_sk_sim(const SkSimArgs& a, int grid, int scols, hipStream_t st) {
+  return scols == SK_COLS ? launch_sk_sim_c<NCH, SK_COLS, SK_SLOTS>(a, grid, st) : launch_sk_sim_c<NCH, SK_SCOLS, 2 * SK_SLOTS>(a, grid, st);
 }
 
 int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int Nc, int d, const int64_t* y, int64_t y_offset,
@@ -514,17 +526,17 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   float* gold = reinterpret_cast<float*>(ws + wl.gold);
   SkSimArgs a{q, nullptr, Cb, Qb, B, Nc, d, y, y_offset, colmask, inv_T, S, tile_lse, gold, g_packed.base, g_packed.rows_c,
               g_packed.n_ctx, g_packed.row_bytes};
-  const int grid1 = sk.nrb * sk.nt;
+  const int grid1 = sk.nrb * sk.nts;
   int rc = DPRHOT_OK;
   switch (d / 128) {  // NCH = d / 64
-    case 1: rc = launch_sk_sim<2>(a, grid1, st); break;
-    case 2: rc = launch_sk_sim<4>(a, grid1, st); break;
-    case 3: rc = launch_sk_sim<6>(a, grid1, st); break;
-    case 4: rc = launch_sk_sim<8>(a, grid1, st); break;
-    case 5: rc = launch_sk_sim<10>(a, grid1, st); break;
-    case 6: rc = launch_sk_sim<12>(a, grid1, st); break;
-    case 7: rc = launch_sk_sim<14>(a, grid1, st); break;
-    case 8: rc = launch_sk_sim<16>(a, grid1, st); break;
+    case 1: rc = launch_sk_sim<2>(a, grid1, sk.scols, st); break;
+    case 2: rc = launch_sk_sim<4>(a, grid1, sk.scols, st); break;
+    case 3: rc = launch_sk_sim<6>(a, grid1, sk.scols, st); break;
+    case 4: rc = launch_sk_sim<8>(a, grid1, sk.scols, st); break;
+    case 5: rc = launch_sk_sim<10>(a, grid1, sk.scols, st); break;
+    case 6: rc = launch_sk_sim<12>(a, grid1, sk.scols, st); break;
+    case 7: rc = launch_sk_sim<14>(a, grid1, sk.scols, st); break;
+    case 8: rc = launch_sk_sim<16>(a, grid1, sk.scols, st); break;
     default: return fail(DPRHOT_E_UNSUPPORTED, "skinny step: d=%d", d);
   }
   if (rc) return rc;
@@ -533,7 +545,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     static const int gp = []() { const char* e = getenv("DPRHOT_SK_GPARTS"); return e ? atoi(e) : 0; }();  // tuning aid
     int pp = gp > 0 ? gp : parts;
     while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
-    SkGArgs g{S, tile_lse, gold, sk.nt, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
+    SkGArgs g{S, tile_lse, gold, sk.nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
     hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp)), dim3(SK_THREADS), 0, st, g);
     HIP_TRY(hipGetLastError());
   }

@@ -26,14 +26,15 @@ namespace dprhot {
 
 constexpr int SK_THREADS = 256;
 constexpr int SK_ROWS = 32;    // query rows of a sim unit
-constexpr int SK_COLS = 128;   // context columns of a sim / dC unit = the statistics tile
+constexpr int SK_COLS = 128;   // context columns of a dC unit (and of the wide sim unit)
+constexpr int SK_SCOLS = 64;   // narrow sim unit (DPRHOT_SK_COLS=64, an A/B switch: measured slower, see sk_plan in dprhot.hip)
 constexpr int SK_KC = 64;      // k per ring slot of the sim kernel
 constexpr int SK_SLOTS = 4;
 constexpr int SK_MAXB = 128;
 constexpr int SK_DN = 128;     // d columns of a dC unit
 constexpr int SK_QN = 64;      // d columns of a dQ unit
 constexpr int SK_QSLOTS = 3;   // ring slots (64 contexts each) of a dQ unit (72 KiB: two workgroups per CU)
-constexpr int SK_MAXG = 16;    // groups of 4 statistics tiles per half row: Nc <= 16384
+constexpr int SK_MAXG = 32;    // groups of 4 statistics tiles per half row: 256 tiles (Nc <= 16384 at 64 columns per tile)
 
 // bijective XCD-contiguous renumbering: consecutive results run on ONE XCD (workgroup w runs on XCD w % 8)
 __device__ __forceinline__ int sk_xcd_order(int wg, int nwg) {
@@ -45,7 +46,7 @@ template <int N>
 __device__ __forceinline__ void sk_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until at most n * PER vector-memory operations of this wave are outstanding (n in 0..5)
+// wait until at most n * PER vector-memory operations of this wave are outstanding (n in 0..7)
 template <int PER>
 __device__ __forceinline__ void sk_wait_younger(int n) {
   switch (n) {
@@ -54,7 +55,9 @@ __device__ __forceinline__ void sk_wait_younger(int n) {
     case 2: sk_wait_vm<2 * PER>(); break;
     case 3: sk_wait_vm<3 * PER>(); break;
     case 4: sk_wait_vm<4 * PER>(); break;
-    default: sk_wait_vm<5 * PER>(); break;
+    case 5: sk_wait_vm<5 * PER>(); break;
+    case 6: sk_wait_vm<6 * PER>(); break;
+    default: sk_wait_vm<7 * PER>(); break;
   }
 }
 __device__ __forceinline__ void sk_barrier() {
@@ -77,31 +80,33 @@ struct SkSimArgs {
   const uint8_t* colmask;  // [Nc] or nullptr
   float inv_T;
   float* S;              // [B][Nc]
-  float* tile_lse;       // [ceil(nt/4)][B][4]: logsumexp of row i over the 128 columns of tile t at [t >> 2][i][t & 3]
+  float* tile_lse;       // [ceil(nt/4)][B][4]: logsumexp of row i over the columns of statistics tile t at [t >> 2][i][t & 3]
   float* gold;           // [B]
   const uint8_t* packed;   // packed multi-rank layout (EpiSim::mask_at), or nullptr
   int p_rows_c, p_n_ctx, p_row_bytes;
 };
 
 constexpr int SK_ASTAGE = 2 * SK_ROWS * SK_KC;  // elements: two [32 rows][64 k] images of the q rows
-inline size_t sk_sim_lds() { return (size_t)SK_ASTAGE * 2 + (size_t)SK_SLOTS * SK_COLS * SK_KC * 2; }
+inline size_t sk_sim_lds() { return (size_t)SK_ASTAGE * 2 + (size_t)SK_SLOTS * SK_COLS * SK_KC * 2; }  // = 8 slots x 64 columns
 
 // A_F32: q is fp32 (rounded to bf16 right after the loads land; the ct == 0 units also write the bf16 rows to Qb).
 // NCH = d / 64 (compile-time: the q rows of the unit live in registers, one 16-byte bf16 chunk per thread and k chunk).
 // LDS = 72 KiB -> two workgroups per CU: all units of cfg3 per rank (4 x 65 = 260) are resident at once, and one
 // workgroup's MFMA / epilogue overlaps the other's loads.
-template <int NCH, bool A_F32>
+// COLS = columns of a unit (128 with SLOTS = 4 ring slots, or 64 with 8): every wave multiplies COLS / 4 of them.
+template <int NCH, bool A_F32, int COLS = SK_COLS, int SLOTS = SK_SLOTS>
 __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
   constexpr int D = NCH * SK_KC;
-  constexpr int IPC = SK_COLS * SK_KC * 2 / 1024 / 4;  // DMA instructions per wave and ring slot (4)
+  constexpr int IPC = COLS * SK_KC * 2 / 1024 / 4;  // DMA instructions per wave and ring slot (4 / 2)
+  constexpr int CPW = COLS / 4, NB = CPW / 16;       // columns per wave, 16-column MFMA blocks per wave
   uint16_t* const Ast = sk_smem;                      // 2 x [32][64]: 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
-  uint16_t* const ring = sk_smem + SK_ASTAGE;         // SK_SLOTS x [128 n][64 k], same swizzle
+  uint16_t* const ring = sk_smem + SK_ASTAGE;         // SLOTS x [COLS n][64 k], same swizzle
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nrb = (p.B + SK_ROWS - 1) / SK_ROWS;
   const int unit = sk_xcd_order(blockIdx.x, gridDim.x);
   const int rb = unit % nrb, ct = unit / nrb;
-  const int m0 = rb * SK_ROWS, n0 = ct * SK_COLS;
+  const int m0 = rb * SK_ROWS, n0 = ct * COLS;
   DPRHOT_TMB(0, 0);
 
   // ---- every global read of the unit's first phase, back to back: the q rows (registers: thread t holds the 8 values
@@ -131,24 +136,24 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     cof[j] = (unsigned)min(n0 + row, p.Nc - 1) * (unsigned)D + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
   }
   auto issue = [&](int kc, int slot) {
-    uint16_t* dst = ring + slot * (SK_COLS * SK_KC);
+    uint16_t* dst = ring + slot * (COLS * SK_KC);
 #pragma unroll
     for (int j = 0; j < IPC; ++j)
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + cof[j] + kc * SK_KC), (g2_lds_ptr*)(dst + (wave * IPC + j) * 512), 16, 0, 0);
   };
 #pragma unroll
-  for (int c = 0; c < SK_SLOTS; ++c)
+  for (int c = 0; c < SLOTS; ++c)
     if (c < NCH) issue(c, c);
   // mask bytes and labels: raw loads only (a select on a loaded value here would park an s_waitcnt in front of everything
   // that follows); they are turned into what the epilogue needs there
   // (branch-free: one unconditional byte load per column from a valid address)
   const bool have_mask = p.packed != nullptr || p.colmask != nullptr;
   const uint8_t* const mbase = p.packed != nullptr ? p.packed : (p.colmask != nullptr ? p.colmask : reinterpret_cast<const uint8_t*>(p.y));
-  uint8_t mraw[2];
-  bool mover[2];
+  uint8_t mraw[NB];
+  bool mover[NB];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = min(n0 + wave * 32 + nb * 16 + i16, p.Nc - 1);
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = min(n0 + wave * CPW + nb * 16 + i16, p.Nc - 1);
     const int rc = p.packed != nullptr ? p.p_rows_c : 1;
     const int r = n / rc, j = n - r * rc;
     mover[nb] = p.packed != nullptr && j >= p.p_n_ctx;  // mask / padding rows of the packed buffer: always masked
@@ -174,11 +179,11 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     }
   }
   DPRHOT_TMB(0, 2);
-  f32x4 acc[2][2];
+  f32x4 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
@@ -192,41 +197,42 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
       const sk_u32x4 val = {abf[c].x, abf[c].y, abf[c].z, abf[c].w};
       asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(val) : "memory");
     }
-    sk_wait_younger<IPC>(min(c + SK_SLOTS - 1, NCH - 1) - c);  // this wave's share of chunk c has landed
+    sk_wait_younger<IPC>(min(c + SLOTS - 1, NCH - 1) - c);  // this wave's share of chunk c has landed
     sk_barrier();                                                // ... everybody's has; the q chunk is in place
-    const uint16_t* Bs = ring + (c % SK_SLOTS) * (SK_COLS * SK_KC);
+    const uint16_t* Bs = ring + (c % SLOTS) * (COLS * SK_KC);
 #pragma unroll
     for (int kk = 0; kk < SK_KC / 32; ++kk) {
-      bf16x8 af[2], bf[2];
+      bf16x8 af[2], bf[NB];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int row = a * 16 + i16;
         af[a] = *reinterpret_cast<const bf16x8*>(Ac + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
       }
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int row = wave * 32 + b * 16 + i16;
+      for (int b = 0; b < NB; ++b) {
+        const int row = wave * CPW + b * 16 + i16;
         bf[b] = *reinterpret_cast<const bf16x8*>(Bs + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
-    if (c + SK_SLOTS < NCH) {
+    if (c + SLOTS < NCH) {
       sk_barrier();  // every wave is done reading this slot
-      issue(c + SK_SLOTS, c % SK_SLOTS);
+      issue(c + SLOTS, c % SLOTS);
     }
   }
-  sk_barrier();  // the ring is free: slot 0 becomes the fp32 logit tile [32][132]
+  sk_barrier();  // the ring is free: its start becomes the fp32 logit tile [32][COLS + 4]
   DPRHOT_TMB(0, 3);
 
   // ---- epilogue: mask, 1/T -> LDS tile -> per-row tile logsumexp, gold logit, coalesced fp32 store
-  constexpr int TS = SK_COLS + 4;
+  constexpr int TS = COLS + 4;
+  constexpr int QD = COLS / 32;  // float4 runs per thread in the statistics / store phase (8 threads per row)
   float* const T = reinterpret_cast<float*>(ring);
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int col = wave * 32 + b * 16 + i16;
+  for (int b = 0; b < NB; ++b) {
+    const int col = wave * CPW + b * 16 + i16;
     const bool masked = (n0 + col >= p.Nc) || mover[b] || (have_mask && mraw[b] != 0);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -237,10 +243,10 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
   {
     const int row = m0 + srow;
     const int yi = yraw + (int)p.y_offset - n0;  // gold column relative to the tile
-    float4 v[4];
+    float4 v[QD];
     float mx = -INFINITY;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
+    for (int qd = 0; qd < QD; ++qd) {
       v[qd] = *reinterpret_cast<const float4*>(T + srow * TS + (qd * 8 + sseg) * 4);
       mx = fmaxf(mx, fmaxf(fmaxf(v[qd].x, v[qd].y), fmaxf(v[qd].z, v[qd].w)));
     }
@@ -248,13 +254,13 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     float sm = 0.f;
     if (mx != -INFINITY) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) sm += __expf(v[qd].x - mx) + __expf(v[qd].y - mx) + __expf(v[qd].z - mx) + __expf(v[qd].w - mx);
+      for (int qd = 0; qd < QD; ++qd) sm += __expf(v[qd].x - mx) + __expf(v[qd].y - mx) + __expf(v[qd].z - mx) + __expf(v[qd].w - mx);
     }
     sm = ss_sum8(sm);
     if (row < p.B) {
       if (sseg == 0) p.tile_lse[((size_t)(ct >> 2) * p.B + row) * 4 + (ct & 3)] = mx == -INFINITY ? -INFINITY : mx + logf(sm);
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
+      for (int qd = 0; qd < QD; ++qd) {
         const int col = (qd * 8 + sseg) * 4;
         if (n0 + col < p.Nc) *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col) = v[qd];
         if (yi >= col && yi < col + 4) p.gold[row] = yi == col ? v[qd].x : (yi == col + 1 ? v[qd].y : (yi == col + 2 ? v[qd].z : v[qd].w));
