@@ -32,6 +32,8 @@
 // What did not work (profiles/r02_g8_ablation.txt): the wave groups in step (-33 %), one barrier per phase (-21 %), a 4-wave
 // workgroup with one wave per SIMD and no hand-over at all (scratch/negative/gemm1w.h: the barrier then idles the pipe, -33 %).
 // The loop is at 66 % MFMA-busy cycles with a null epilogue; its barrier / MFMA skeleton alone (no DMA, no reads) reaches 69-72 %.
+// It is POWER-limited: on zero-filled operands the same launch is 47 % faster (1.90 vs 1.29 PFLOP/s), and the two-phase variant
+// below (SCHED = 2: 16 MFMAs per section, half the hand-overs) is bit-identical and exactly as fast.
 #pragma once
 #include "gemm256.h"
 #include "rowwise.h"
@@ -142,7 +144,7 @@ __device__ __forceinline__ bf16x8 g8_frag32(const uint16_t* T, int r0, int kk, i
 
 // VAR: ablation switches of scratch/g8probe.hip (timing only, results are garbage): 1 no s_setprio, 2 wave groups in step,
 // 4 one barrier per phase, 8 no DMA after the prologue, 16 no fragment reads; the library always builds VAR = 0.
-template <class Epi, int VAR = 0>
+template <class Epi, int VAR = 0, int SCHED = 4>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm8p_kernel(GemmArgs p, Epi epi, int nbx, int nby) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -200,6 +202,14 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm8p_kernel(GemmArgs p, Epi e
     g8_wait_vm<10>();                                                                                                             \
   }
 
+  // the same without the wait (SCHED 2 issues one or three half-tiles per load section and waits once)
+#define G8_STAGE_NW(P, O0, O1, TT, IMG)                                                                                           \
+  if (!((VAR & 8) && dma_off)) {                                                                                                  \
+    const char* base_ = reinterpret_cast<const char*>(P) + (size_t)(((TT) >= nt ? (TT) - nt : (TT)) * (G2_BK * 2));               \
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(base_ + (size_t)(O0)), (g2_lds_ptr*)((IMG) + (wave * 2 + 0) * 512), 16, 0, 0); \
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(base_ + (size_t)(O1)), (g2_lds_ptr*)((IMG) + (wave * 2 + 1) * 512), 16, 0, 0); \
+  }
+
   int tile = blockIdx.x, bx, by;
   g2_tile_of(tile, nbx, nby, bx, by);
   aim(bx, by);
@@ -210,21 +220,30 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm8p_kernel(GemmArgs p, Epi e
   G8Acc acc;
   acc.zero();
 
-  // ---- prologue: the first tile's epilogue inputs, the DMAs of phases -7 .. -1 in schedule order, the B0 read of phase -1
+  // ---- prologue: the first tile's epilogue inputs, then the DMAs the steady state would have issued before phase 0, in its order
   fetch_meta(bx, by, meta0);
-  G8_STAGE(p.B, ob00, ob01, 0, img(0, 2));
-  G8_STAGE(p.A, oa00, oa01, 0, img(0, 0));
-  G8_STAGE(p.B, ob10, ob11, 0, img(0, 3));
-  G8_STAGE(p.A, oa10, oa11, 0, img(0, 1));
-  G8_STAGE(p.B, ob00, ob01, 1, img(1, 2));
-  G8_STAGE(p.A, oa00, oa01, 1, img(1, 0));  // ... vmcnt(10): B0(0) has landed
-  g8_bar();
-  g8_bar();
-  G8_RD_B(bq[0], img(0, 2));
-  G8_STAGE(p.B, ob10, ob11, 1, img(1, 3));  // ... A0(0) has landed
-  g8_wait_lgkm0();
-  g8_bar();
-  g8_bar();
+  if constexpr (SCHED == 4) {
+    G8_STAGE(p.B, ob00, ob01, 0, img(0, 2));
+    G8_STAGE(p.A, oa00, oa01, 0, img(0, 0));
+    G8_STAGE(p.B, ob10, ob11, 0, img(0, 3));
+    G8_STAGE(p.A, oa10, oa11, 0, img(0, 1));
+    G8_STAGE(p.B, ob00, ob01, 1, img(1, 2));
+    G8_STAGE(p.A, oa00, oa01, 1, img(1, 0));  // ... vmcnt(10): B0(0) has landed
+    g8_bar();
+    g8_bar();
+    G8_RD_B(bq[0], img(0, 2));
+    G8_STAGE(p.B, ob10, ob11, 1, img(1, 3));  // ... A0(0) has landed
+    g8_wait_lgkm0();
+    g8_bar();
+    g8_bar();
+  } else {
+    G8_STAGE_NW(p.B, ob00, ob01, 0, img(0, 2)); G8_STAGE_NW(p.A, oa00, oa01, 0, img(0, 0)); G8_STAGE_NW(p.B, ob10, ob11, 0, img(0, 3));
+    G8_STAGE_NW(p.A, oa10, oa11, 0, img(0, 1));
+    G8_STAGE_NW(p.B, ob00, ob01, 1, img(1, 2)); G8_STAGE_NW(p.A, oa00, oa01, 1, img(1, 0)); G8_STAGE_NW(p.B, ob10, ob11, 1, img(1, 3));
+    g8_wait_vm<8>();  // A0, B0, B1 of K step 0 (and the epilogue words) have landed
+    g8_bar();
+    g8_bar();
+  }
 
   int par = 0;  // meta buffer of the current tile
   dma_off = true;
@@ -272,8 +291,53 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm8p_kernel(GemmArgs p, Epi e
     G8_MM(1, 0, bq[PAR]);                                                                                        \
     if constexpr (!(VAR & 4)) g8_bar();                                                                          \
   }
-      G8_KSTEP(0, t, t == nt - 2);
-      G8_KSTEP(1, t + 1, false);
+      // SCHED 2: a K step is TWO phases of 16 MFMAs (the matrix pipe changes hands 4 instead of 8 times per K step):
+      //   X(t): reads A0, B0, B1 (t)    DMA A1(t+1)             MFMAs (0,0) (0,1)
+      //   Y(t): reads A1 (t)            DMA A0, B0, B1 (t+2)    MFMAs (1,0) (1,1)
+      // Every load section retires its reads (lgkmcnt(0)) BEFORE its barrier, so an image may be overwritten ONE phase after its
+      // last read (the lagging wave group has retired its reads before the barrier the leading group's next section starts
+      // behind); every half-tile has two phases (~1200 MFMA cycles) between its DMA and the wait that covers it: vmcnt(8).
+#define G8_KSTEP2(PAR, T, SWITCH)                                                                                \
+  {                                                                                                              \
+    /* X */                                                                                                      \
+    G8_RD_A(img(PAR, 0));                                                                                        \
+    G8_RD_B(bq[0], img(PAR, 2));                                                                                 \
+    G8_RD_B(bq[1], img(PAR, 3));                                                                                 \
+    G8_STAGE_NW(p.A, oa10, oa11, (T) + 1, img((PAR) ^ 1, 1));                                                    \
+    g8_wait_vm<8>();                                                                                             \
+    if (SWITCH) {                                                                                                \
+      next = tile + (int)gridDim.x;                                                                              \
+      has_next = next < ntiles;                                                                                  \
+      if (has_next) {                                                                                            \
+        g2_tile_of(next, nbx, nby, nbx_, nby_);                                                                  \
+        aim(nbx_, nby_);                                                                                         \
+        fetch_meta(nbx_, nby_, meta0 + (par ^ 1) * 1024);                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+    g8_wait_lgkm0();                                                                                             \
+    g8_bar();                                                                                                    \
+    G8_MM(0, 0, bq[0]);                                                                                          \
+    G8_MM(0, 1, bq[1]);                                                                                          \
+    g8_bar();                                                                                                    \
+    /* Y */                                                                                                      \
+    G8_RD_A(img(PAR, 1));                                                                                        \
+    G8_STAGE_NW(p.B, ob00, ob01, (T) + 2, img(PAR, 2));                                                          \
+    G8_STAGE_NW(p.A, oa00, oa01, (T) + 2, img(PAR, 0));                                                          \
+    G8_STAGE_NW(p.B, ob10, ob11, (T) + 2, img(PAR, 3));                                                          \
+    g8_wait_vm<8>();                                                                                             \
+    g8_wait_lgkm0();                                                                                             \
+    g8_bar();                                                                                                    \
+    G8_MM(1, 0, bq[0]);                                                                                          \
+    G8_MM(1, 1, bq[1]);                                                                                          \
+    g8_bar();                                                                                                    \
+  }
+      if constexpr (SCHED == 4) {
+        G8_KSTEP(0, t, t == nt - 2);
+        G8_KSTEP(1, t + 1, false);
+      } else {
+        G8_KSTEP2(0, t, t == nt - 2);
+        G8_KSTEP2(1, t + 1, false);
+      }
     }
     if (!(VAR & 2) && wm == 0) g8_bar();  // both wave groups in step again
 

@@ -104,6 +104,13 @@ int main(int argc, char** argv) {
   void (*k_var[6])(GemmArgs, Epi8Null, int, int) = {gemm8p_kernel<Epi8Null, 1>, gemm8p_kernel<Epi8Null, 2>, gemm8p_kernel<Epi8Null, 4>,
                                                     gemm8p_kernel<Epi8Null, 8>, gemm8p_kernel<Epi8Null, 16>, gemm8p_kernel<Epi8Null, 24>};
   for (auto k : k_var) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+  auto k3_store = gemm8p_kernel<Epi8Store, 0, 2>; auto k3_stats = gemm8p_kernel<Epi8Stats, 0, 2>; auto k3_null = gemm8p_kernel<Epi8Null, 0, 2>;
+  auto k3_g = gemm8p_kernel<Epi8G, 0, 2>; auto k3_count = gemm8p_kernel<Epi8Count, 0, 2>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_store), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_stats), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_null), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k3_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
   auto k2_store = gemm2w_kernel<Epi8Store>; auto k2_stats = gemm2w_kernel<Epi8Stats>; auto k2_null = gemm2w_kernel<Epi8Null>;
   auto k2_g = gemm2w_kernel<Epi8G>; auto k2_count = gemm2w_kernel<Epi8Count>;
   auto k2_nodma = gemm2w_kernel<Epi8Null, 8>; auto k2_noread = gemm2w_kernel<Epi8Null, 16>; auto k2_neither = gemm2w_kernel<Epi8Null, 24>;
@@ -132,7 +139,8 @@ int main(int argc, char** argv) {
     std::vector<int64_t> hy(M);
     for (int m = 0; m < M; ++m) hy[m] = (int64_t)((m * 7919u + 13u) % (unsigned)N);
     uint16_t *A, *B; float *S0, *S1, *pm, *ps, *gold; uint8_t* mask; int64_t* y;
-    for (int use2 = 0; use2 < 2; ++use2) {
+    for (int mode = 0; mode < 3; ++mode) {
+    const int use2 = mode == 1;
     const int nbx = use2 ? (N + 127) / 128 : (N + 255) / 256, nby = (M + 255) / 256, npart = use2 ? nbx * 2 : nbx * 4;
     const int nbx_old = (N + 255) / 256;
     CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&S0, (size_t)M * N * 4)); CK(hipMalloc(&S1, (size_t)M * N * 4));
@@ -148,7 +156,7 @@ int main(int argc, char** argv) {
     const int thr = use2 ? 256 : 512; const size_t lds = use2 ? w2_lds_total : g8_lds_total;
     std::vector<float> h0((size_t)M * N), h1((size_t)M * N), h2((size_t)M * N);
     CK(hipMemset(S1, 0xff, (size_t)M * N * 4));
-    hipLaunchKernelGGL(use2 ? k2_store : k_new_store, dim3(grid), dim3(thr), lds, 0, a, e1, nbx, nby);
+    hipLaunchKernelGGL(mode == 1 ? k2_store : (mode == 2 ? k3_store : k_new_store), dim3(grid), dim3(thr), lds, 0, a, e1, nbx, nby);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(h0.data(), S0, h0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), S1, h1.size() * 4, hipMemcpyDeviceToHost));
     size_t diff = 0; for (size_t i = 0; i < h0.size(); ++i) diff += memcmp(&h0[i], &h1[i], 4) != 0;
@@ -165,14 +173,14 @@ int main(int argc, char** argv) {
     int racy = 0;
     for (int rep = 0; rep < 10; ++rep) {
       CK(hipMemset(S1, 0xff, (size_t)M * N * 4));
-      hipLaunchKernelGGL(use2 ? k2_store : k_new_store, dim3(grid), dim3(thr), lds, 0, a, e1, nbx, nby);
+      hipLaunchKernelGGL(mode == 1 ? k2_store : (mode == 2 ? k3_store : k_new_store), dim3(grid), dim3(thr), lds, 0, a, e1, nbx, nby);
       CK(hipMemcpy(h2.data(), S1, h2.size() * 4, hipMemcpyDeviceToHost));
       racy += memcmp(h1.data(), h2.data(), h1.size() * 4) != 0;
     }
     // statistics epilogue against the host (from the logits just checked)
     Epi8Stats e2{}; e2.sim = e1.sim; e2.dummy = A; e2.part_m = pm; e2.part_s = ps; e2.npart = npart;
     CK(hipMemset(pm, 0xff, (size_t)M * npart * 4)); CK(hipMemset(gold, 0xff, M * 4));
-    hipLaunchKernelGGL(use2 ? k2_stats : k_new_stats, dim3(grid), dim3(thr), lds, 0, a, e2, nbx, nby);
+    hipLaunchKernelGGL(mode == 1 ? k2_stats : (mode == 2 ? k3_stats : k_new_stats), dim3(grid), dim3(thr), lds, 0, a, e2, nbx, nby);
     std::vector<float> hpm((size_t)M * npart), hps((size_t)M * npart), hg(M);
     CK(hipMemcpy(hpm.data(), pm, hpm.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hps.data(), ps, hps.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hg.data(), gold, M * 4, hipMemcpyDeviceToHost));
@@ -195,11 +203,11 @@ int main(int argc, char** argv) {
     const float gscale = 0.37f;
     Epi8G e3{}; e3.sim = e1.sim; e3.dummy = A; e3.row_lse = lse_d; e3.G = Gd; e3.grad_scale = gscale;
     CK(hipMemset(Gd, 0xff, (size_t)M * N * 2));
-    hipLaunchKernelGGL(use2 ? k2_g : k_new_g, dim3(grid), dim3(thr), lds, 0, a, e3, nbx, nby);
+    hipLaunchKernelGGL(mode == 1 ? k2_g : (mode == 2 ? k3_g : k_new_g), dim3(grid), dim3(thr), lds, 0, a, e3, nbx, nby);
     hipLaunchKernelGGL(g8_gold_kernel, dim3((M + 31) / 32), dim3(64), 0, 0, A, B, M, N, K, y, (int64_t)0, e1.sim, inv_T, gold2);
     CK(hipMemset(cnt, 0, M * 4));
     Epi8Count e4{}; e4.sim = e1.sim; e4.dummy = A; e4.gold_val = gold2; e4.count = cnt;
-    hipLaunchKernelGGL(use2 ? k2_count : k_new_count, dim3(grid), dim3(thr), lds, 0, a, e4, nbx, nby);
+    hipLaunchKernelGGL(mode == 1 ? k2_count : (mode == 2 ? k3_count : k_new_count), dim3(grid), dim3(thr), lds, 0, a, e4, nbx, nby);
     hipLaunchKernelGGL(g8_rank_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, 0, cnt, M, rank_d);
     std::vector<float> hl(M), hg2(M); std::vector<uint16_t> hG((size_t)M * N); std::vector<int64_t> hr(M);
     CK(hipMemcpy(hl.data(), lse_d, M * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hg2.data(), gold2, M * 4, hipMemcpyDeviceToHost));
@@ -225,7 +233,7 @@ int main(int argc, char** argv) {
     if (!(lse2_err < 1e-5 && gold2_bad == 0 && rank_bad == 0 && g_err < 6e-3)) fails++;
     (void)hipFree(lse_d); (void)hipFree(loss_d); (void)hipFree(gold2); (void)hipFree(Gd); (void)hipFree(cnt); (void)hipFree(rank_d);
     const bool ok = diff == 0 && racy == 0 && maxerr < 1e-3 && lse_err < 1e-5 && gold_bad == 0;
-    printf("%s %5d x %6d x %4d: %zu of %zu logits differ from gemm256, host spot err %.2e, %d of 10 reruns differ, lse err %.2e, gold mismatches %zu  %s\n", use2 ? "2w" : "8p", M, N, K, diff,
+    printf("%s %5d x %6d x %4d: %zu of %zu logits differ from gemm256, host spot err %.2e, %d of 10 reruns differ, lse err %.2e, gold mismatches %zu  %s\n", mode == 1 ? "2w" : (mode == 2 ? "8p/2" : "8p"), M, N, K, diff,
            h0.size(), maxerr, racy, lse_err, gold_bad, ok ? "ok" : "FAIL");
     fails += !ok;
     (void)hipFree(A); (void)hipFree(B); (void)hipFree(S0); (void)hipFree(S1); (void)hipFree(mask); (void)hipFree(y); (void)hipFree(pm); (void)hipFree(ps); (void)hipFree(gold);
@@ -256,8 +264,10 @@ int main(int argc, char** argv) {
     Epi8Null e3{out, A}; EpiNull e4{out};
     EpiSim e5 = es; e5.S = S; e5.y = nullptr;
     hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1));
+    const bool zero_ops = argc > 2 && !strcmp(argv[2], "zero");
+    if (zero_ops) { CK(hipMemset(A, 0, hA.size() * 2)); CK(hipMemset(B, 0, hB.size() * 2)); printf("operands zero-filled\n"); }
     for (int round = 0; round < 3; ++round) {
-      for (int which = 0; which < 24; ++which) {
+      for (int which = 0; which < 28; ++which) {
         CK(hipEventRecord(ev0, 0));
         for (int it = 0; it < 5; ++it) {
           if (which == 0) hipLaunchKernelGGL(k_new_null, dim3(256), dim3(512), g8_lds_total, 0, a, e3, nbx, nby);
@@ -270,6 +280,10 @@ int main(int argc, char** argv) {
           if (which == 13) hipLaunchKernelGGL(k_new_g, dim3(nbx * nby), dim3(512), g8_lds_total, 0, a, e7, nbx, nby);
           if (which == 14) hipLaunchKernelGGL(k_new_store, dim3(nbx * nby), dim3(512), g8_lds_total, 0, a, e1, nbx, nby);
           if (which == 15) hipLaunchKernelGGL(k_new_g, dim3(512), dim3(512), g8_lds_total, 0, a, e7, nbx, nby);
+          if (which == 24) hipLaunchKernelGGL(k3_null, dim3(256), dim3(512), g8_lds_total, 0, a, e3, nbx, nby);
+          if (which == 25) hipLaunchKernelGGL(k3_stats, dim3(256), dim3(512), g8_lds_total, 0, a, e2, nbx, nby);
+          if (which == 26) hipLaunchKernelGGL(k3_g, dim3(256), dim3(512), g8_lds_total, 0, a, e7, nbx, nby);
+          if (which == 27) hipLaunchKernelGGL(k3_count, dim3(256), dim3(512), g8_lds_total, 0, a, e8, nbx, nby);
           if (which == 16) hipLaunchKernelGGL(k2_null, dim3(512), dim3(256), w2_lds_total, 0, a, e3, nbx * 2, nby);
           if (which == 17) hipLaunchKernelGGL(k2_stats, dim3(512), dim3(256), w2_lds_total, 0, a, e2b, nbx * 2, nby);
           if (which == 18) hipLaunchKernelGGL(k2_store, dim3(512), dim3(256), w2_lds_total, 0, a, e1, nbx * 2, nby);
@@ -284,7 +298,7 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, ev0, ev1)); ms /= 5;
         const char* names[] = {"8-phase null", "8-phase stats (no logits)", "8-phase store fp32", "gemm256 persistent null", "gemm256 store fp32 (one wg per tile)",
                                "8-phase G pass (bf16 dScores)", "8-phase rank count", "  no setprio", "  wave groups in step", "  one barrier per phase (invalid)",
-                               "  no DMA", "  no fragment reads", "  no DMA, no fragment reads", "G pass, one workgroup per tile", "store fp32, one workgroup per tile", "G pass, 512 workgroups (2 tiles each)", "2w null", "2w stats (no logits)", "2w store fp32", "2w G pass (bf16 dScores)", "2w rank count", "  2w no DMA", "  2w no fragment reads", "  2w neither"};
+                               "  no DMA", "  no fragment reads", "  no DMA, no fragment reads", "G pass, one workgroup per tile", "store fp32, one workgroup per tile", "G pass, 512 workgroups (2 tiles each)", "2w null", "2w stats (no logits)", "2w store fp32", "2w G pass (bf16 dScores)", "2w rank count", "  2w no DMA", "  2w no fragment reads", "  2w neither", "two-phase null", "two-phase stats", "two-phase G pass", "two-phase rank count"};
         if (round > 0 && !(time_only && which >= 7 && which < 13 && argc < 3)) printf("round %d %-40s %.1f us  %.0f TFLOP/s\n", round, names[which], ms * 1e3, 2.0 * M * N * K / ms * 1e-9);
       }
     }
