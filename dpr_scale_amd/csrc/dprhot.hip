@@ -787,6 +787,15 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
       continue;
     }
     // scores that cannot enter the top-k never leave the GEMM tile
+    if (nl_ok(nq, cols, d)) {  // the phase-interleaved kernel (gemm8p.h); thresholds arrive with the tile's input words
+      const Epi8Filter e8{values, indices, k, nq, cols, (long long)(id_offset + j0), cnt, S, cand_j, Q};
+      GemmArgs a8{Q, Cj, nq, cols, d, d, d, d};
+      if (int rc = launch_g8(a8, e8, st)) return rc;
+      TopkArgs p8{S, nq, cols, (long long)cols, (long long)(id_offset + j0), k, values, indices, 0, cand_j, cnt};
+      hipLaunchKernelGGL(topk_stream_kernel, dim3(nq), dim3(256), 0, st, p8);
+      HIP_TRY(hipGetLastError());
+      continue;
+    }
     const int tile = (force_tile() < 0 && big_ok(nq, cols, d)) ? kBigTile : pick_tile(nq, cols, d, 1, 2 * kNumCU);
     GemmArgs a{Q, Cj, nq, cols, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
     EpiFilter epi{values, indices, k, nq, cols, (long long)(id_offset + j0), cnt, S, cand_j};

@@ -649,6 +649,63 @@ struct Epi8Count : Epi8Base {
   }
 };
 
+// Retrieval epilogue (run_retrieval_pytorch.py:149-150 without the score matrix; EpiFilter of gemm_bf16.h on this kernel): a score
+// only leaves the tile when it ranks ahead of the row's current k-th best (score desc, passage id asc); such scores are appended to
+// the row's candidate list, which the top-k merge kernel folds into the state.  The thresholds arrive with the tile's input words.
+struct Epi8Filter {
+  const float* kth_val;     // state values  [M][k]
+  const int64_t* kth_idx;   // state ids     [M][k]  (-1: slot unfilled)
+  int k;
+  int M, N;
+  long long col_offset;     // passage id of column 0
+  int* cnt;                 // [M] candidates appended so far (the merge kernel resets it)
+  float* cand_v;            // [M][N]
+  int* cand_j;              // [M][N]
+  const void* dummy;
+  __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const {
+    if (e >= 512 && e < 768) return kth_val + (size_t)min(m0 + e - 512, M - 1) * k + (k - 1);
+    return dummy;
+  }
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float tv[4];
+    bool any = false;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      tv[a] = __int_as_float(g8_lds_read(t.meta + 512 + t.wm * 128 + a * 32 + i));
+      // branch-free screen: once the thresholds have risen almost no tile holds a score that reaches its row's k-th best
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) any |= acc.v[a][b][r] >= tv[a];
+    }
+    if (!any) return;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int m = t.m0 + t.wm * 128 + a * 32 + i;
+      if (m >= M) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
+          const float v = acc.v[a][b][r];
+          if (!(n < N && v >= tv[a])) continue;
+          bool take = v > tv[a];
+          if (!take) {  // exact tie with the k-th best -> lower passage id wins (-1: slot unfilled)
+            const long long ti = kth_idx[(size_t)m * k + k - 1];
+            take = ti < 0 || col_offset + n < ti;
+          }
+          if (take) {
+            const int pos = atomicAdd(&cnt[m], 1);
+            cand_v[(size_t)m * N + pos] = v;
+            cand_j[(size_t)m * N + pos] = n;
+          }
+        }
+    }
+  }
+};
+
 // ---- the small kernels around the GEMM passes -------------------------------------------------------------------------------------
 // Row logsumexp from the strip statistics of Epi8Stats, row loss = lse - gold (dpr_task.py:212, CrossEntropyLoss per row).
 // One wave per row; the loss sum is a second tiny launch (reduce_sum_kernel, fixed order).  (A last-arriving-workgroup sum inside
