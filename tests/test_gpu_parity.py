@@ -812,3 +812,43 @@ def test_rank_and_loss_helper_matches_score_matrix_path(kn, dev):
     assert torch.equal(ranks, hotpath.rank_of_gold(S, y, kn))
     ref = torch.nn.functional.cross_entropy(S, y)
     assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+
+
+def test_packed_multi_rank_step_at_a_no_logits_shape(kn, dev):
+    """Large per-rank batch over several ranks, emulated on one GPU: dprhot_inbatch_step_packed_f32 then runs the no-logits forward
+    with the column mask read from the gathered buffer's mask rows (Epi8Base::mask_byte, packed layout) and stamps the loss numerator
+    into dC_part.  Checked against the unpacked formulation of the same step (mask vector from dprhot_unpack_mask, logits stored)."""
+    W, B, K, d = 2, 1024, 16, 128  # Nc = 2 * packed_rows(16384, 128) ~ 33 k columns: 4 x 129 tiles
+    n_ctx = B * K
+    rows_c = kn.packed_rows(n_ctx, d)
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    qs = [(torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev) for _ in range(W)]
+    cs = [(torch.randn(n_ctx, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev) for _ in range(W)]
+    ms = [(torch.rand(n_ctx, generator=gen) < 0.03) for _ in range(W)]
+    y = (torch.arange(B) * K)
+    for m in ms:
+        m[y] = False
+    sends = []
+    for r in range(W):
+        send = torch.empty((rows_c, d), dtype=torch.bfloat16, device=dev)
+        kn.pack_ctx(cs[r], ms[r].to(torch.uint8).to(dev), send)
+        sends.append(send)
+    Cb = torch.cat(sends, 0).contiguous()
+    assert kn._lib.workspace_bytes(B, W * rows_c, d) < B * W * rows_c * 4  # a no-logits shape
+    colmask = torch.empty(W * rows_c, dtype=torch.uint8, device=dev)
+    kn.unpack_mask(Cb, W, n_ctx, colmask)
+    yd = y.to(dev)
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    for r in range(W):
+        _, _, ls, _, dq, dcp = kn.inbatch_step_packed_f32(qs[r], Cb, Qb, W, r, n_ctx, yd, 1.0, 1.0 / (W * B))
+        rl, lse, ls_ref, G, S = kn.inbatch_fwd_f32(qs[r], None, Qb, Cb, yd, r * rows_c, colmask, 1.0, 1.0 / (W * B), want_logits=True)
+        dq_ref, dc_ref = kn.inbatch_bwd(G, Qb, Cb, 1.0, one)
+        assert abs(ls.item() - ls_ref.item()) <= 1e-5 * abs(ls_ref.item())
+        assert ((dq - dq_ref).abs().max() / dq_ref.abs().max()).item() <= 2e-3
+        stamped = dcp.clone()
+        for k in range(W):
+            assert abs(stamped[k * rows_c + n_ctx, 0].item() - ls.item()) <= 1e-6 * abs(ls.item())  # the loss numerator rides here
+            stamped[k * rows_c + n_ctx, 0] = 0.0
+        assert ((stamped - dc_ref).abs().max() / dc_ref.abs().max()).item() <= 2e-3
+        assert torch.all(stamped.view(W, rows_c, d)[:, n_ctx:] == 0)  # mask rows: masked columns have G == 0 exactly
