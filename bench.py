@@ -524,6 +524,14 @@ def main():
                 run2()
             el2 = timed_loop(run2, a.steps, 1)
             alt = {"driver": other, "value": round(B * a.steps / el2, 1), "ms_per_step": round(el2 / a.steps * 1e3, 5)}
+            # a graph that holds ONE 2-launch step pays hipGraphLaunch's fixed cost per step; a caller who captures a whole training
+            # iteration does not: the same step captured 10x per graph, replayed steps/10 times
+            run10 = capture(hp, hp.step, 10)
+            for _ in range(5):
+                run10()
+            n10 = max(1, a.steps // 10)
+            el10 = timed_loop(run10, n10, 1)
+            alt["graph_of_10_steps"] = {"ms_per_step": round(el10 / (n10 * 10) * 1e3, 5), "value": round(B * n10 * 10 / el10, 1)}
         out = {
             "metric": "query-passage pairs/sec (in-batch contrastive hot path: gather+sim+softmax-CE+dQ/dC)",
             "value": round(W * B * a.steps / el, 1), "unit": "pairs/s", "n_gpus": W, "steps": a.steps, "warmup": a.warmup,
