@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the line an MI355X box produced for the committed code
-(profiles/r01_v6_bench_n1.json): every key the driver and the judge read is present and well-formed."""
+(profiles/r02_v3_bench_n1.json): every key the driver and the judge read is present and well-formed."""
 import json
 import os
 
@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_v3_bench_n1.json")))
     for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)]:
@@ -22,3 +22,10 @@ def test_committed_bench_line_has_the_contract_keys():
     assert roof["traffic"] is None or roof["traffic"] > 0
     cpu = line["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
+    # round 2: the blocks the judge asked for ride in the same line
+    for key in ("cpu_baseline_reference", "end_to_end", "roofline_at_scale", "roofline_cfg3_rank", "timing", "rccl_ranks"):
+        assert key in line, key
+    assert line["timing"]["statistic"] == "median" and line["timing"]["repeats"] >= 31
+    at = line["roofline_at_scale"]
+    for k in ("sim_gemm", "dscores_gemm", "backward_gemms"):
+        assert at[k]["bound"] == "mfma" and abs(at[k]["frac"] - at[k]["achieved"] / at[k]["peak"]) <= 1e-3
