@@ -370,7 +370,7 @@ SkPlan sk_plan(int B, int Nc, int d) {
     // unit's K range in flight at once.  Measured at cfg3 per rank: 12.4 vs 11.0 us for the sim launch (and 7.5 vs 5.8 us for the G launch,
     // which then folds twice the tile statistics): the unit is not bound by its ring refills.  Kept as an A/B switch.
     static const bool narrow = []() { const char* e = getenv("DPRHOT_SK_COLS"); return e && atoi(e) == 64; }();
-    p.scols = narrow ? SK_SCOLS : SK_COLS;
+    p.scols = (narrow && cdiv(Nc, SK_SCOLS) <= 8 * SK_MAXG) ? SK_SCOLS : SK_COLS;
   }
   p.nts = cdiv(Nc, p.scols);  // statistics tiles = sim units per row block
   p.nrb = cdiv(B, SK_ROWS);
@@ -546,7 +546,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     int pp = gp > 0 ? gp : parts;
     while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
     SkGArgs g{S, tile_lse, gold, sk.nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
-    hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp)), dim3(SK_THREADS), 0, st, g);
+    hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp + 1)), dim3(SK_THREADS), 0, st, g);
     HIP_TRY(hipGetLastError());
   }
   {

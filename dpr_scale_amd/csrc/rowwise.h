@@ -36,15 +36,22 @@ __device__ __forceinline__ float dprhot_row16_sum(float v) {
   return v + dprhot_dpp_ror<1>(v);
 }
 
+// Whole-wave reductions, every lane receives the result.  VALU only: four DPP row rotations inside each row of 16 lanes, then
+// v_permlane16_swap / v_permlane32_swap (with D = S = x they leave x[l] and x[l ^ 16] resp. x[l ^ 32] side by side in every lane)
+// across the four rows.  (The __shfl_xor butterfly these replace lowers to six ds_bpermute round trips of ~120 cycles each.)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = dprhot_row16_max(v);
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = dprhot_row16_sum(v);
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll

@@ -34,7 +34,8 @@ constexpr int SK_MAXB = 128;
 constexpr int SK_DN = 128;     // d columns of a dC unit
 constexpr int SK_QN = 64;      // d columns of a dQ unit
 constexpr int SK_QSLOTS = 3;   // ring slots (64 contexts each) of a dQ unit (72 KiB: two workgroups per CU)
-constexpr int SK_MAXG = 32;    // groups of 4 statistics tiles per half row: 256 tiles (Nc <= 16384 at 64 columns per tile)
+constexpr int SK_MAXG = 16;    // groups of 4 statistics tiles per half row: 128 tiles (Nc <= 16384 at 128 columns per tile; doubling it
+                               // for the narrow sim unit costs the loss workgroup of sk_g_kernel 1.5 us: 5.8 -> 7.3 us for the launch)
 
 // bijective XCD-contiguous renumbering: consecutive results run on ONE XCD (workgroup w runs on XCD w % 8)
 __device__ __forceinline__ int sk_xcd_order(int wg, int nwg) {
@@ -318,10 +319,12 @@ __device__ __forceinline__ float sk_row_lse(const float* tile_lse, int nt, int B
   return mx + logf(sm);  // every lane holds the same bits (butterfly reductions)
 }
 
-// grid = B * parts workgroups: workgroup (row, part) turns its share of the row's logits into G.  Every wave derives the
-// row logsumexp itself (<= 2 KB of tile values); workgroup 0 additionally writes row_lse / row_loss / loss_sum for all rows.
+// grid = B * parts + 1 workgroups: workgroup (row, part) turns its share of the row's logits into G.  Every wave derives the
+// row logsumexp itself (<= 2 KB of tile values); the last workgroup writes row_lse / row_loss / loss_sum for all rows.
 __global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool loss_wg = (int)blockIdx.x == p.B * p.parts;  // the ONE extra workgroup: row_lse / row_loss / loss_sum of all rows, next to
+  if (!loss_wg) {                                         // (not after) the G workgroups -- as workgroup 0's second job it was the tail
   const int row = blockIdx.x / p.parts, part = blockIdx.x - row * p.parts;
   const int cpr = p.Nc >> 3;                       // 8-column chunks per row
   const int per = (cpr + p.parts - 1) / p.parts;   // chunks of this part
@@ -354,7 +357,9 @@ __global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
       *reinterpret_cast<uint4*>(p.G + (size_t)row * p.Nc + j) = make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
     }
   }
-  if (blockIdx.x == 0) {
+  return;
+  }
+  {
     // the loss of ALL rows: thread (row = tid & 127, half = tid >> 7) folds the tile groups half, half + 2, ... of its row
     // (lanes = rows: coalesced 16-byte loads, all of them in flight at once); the halves meet in LDS; fixed-order sum
     __shared__ float s_m[SK_MAXB], s_s[SK_MAXB], s_l[SK_MAXB];
@@ -582,37 +587,43 @@ __device__ __forceinline__ void sk_dq_unit(const SkBwdArgs& p, int unit, uint16_
       }
     }
     sk_barrier();
+    // Both k slices of the step are read before the first wait: one LDS round trip per step instead of two (the step is a latency
+    // chain: barrier -> reads -> MFMAs -> barrier -> DMA issue).
+    // The transpose reads go through inline asm: hipcc parks an s_waitcnt vmcnt(0) in front of the builtin form whenever an
+    // LDS-DMA is in flight (it cannot tell the slots apart), which would drain the whole ring at every step.  An asm read is
+    // invisible to its counters, hence the explicit lgkmcnt(0) + sched_barrier behind the block (guide section 5.7, form iii).
+    bf16x8 af[2][2];
+    bf16x4 lo[2][4], hi[2][4];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[2], bf[4];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int row = wave * 32 + a * 16 + i16;
-        af[a] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
+        af[kk][a] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
       }
-      // The transpose reads go through inline asm: hipcc parks an s_waitcnt vmcnt(0) in front of the builtin form whenever an
-      // LDS-DMA is in flight (it cannot tell the slots apart), which would drain the whole ring at every step.  An asm read is
-      // invisible to its counters, hence the explicit lgkmcnt(0) + sched_barrier behind the block (guide section 5.7, form iii).
-      bf16x4 lo[4], hi[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int k = kk * 32 + g4 * 8 + (i16 >> 2);
         const unsigned addr = (unsigned)(uintptr_t)(lds_bf16x4*)(Bs + k * SK_QN + ((b ^ sk_swz64(k)) << 4) + (i16 & 3) * 4);
-        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(lo[b]), "=&v"(hi[b]) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(lo[kk][b]), "=&v"(hi[kk][b]) : "v"(addr));
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 bf[4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         bf16x8 r;
-        r[0] = lo[b][0]; r[1] = lo[b][1]; r[2] = lo[b][2]; r[3] = lo[b][3];
-        r[4] = hi[b][0]; r[5] = hi[b][1]; r[6] = hi[b][2]; r[7] = hi[b][3];
+        r[0] = lo[kk][b][0]; r[1] = lo[kk][b][1]; r[2] = lo[kk][b][2]; r[3] = lo[kk][b][3];
+        r[4] = hi[kk][b][0]; r[5] = hi[kk][b][1]; r[6] = hi[kk][b][2]; r[7] = hi[kk][b][3];
         bf[b] = r;
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], acc[a][b], 0, 0, 0);
     }
     if (s + SK_QSLOTS < ns) {
       sk_barrier();
