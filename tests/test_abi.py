@@ -61,6 +61,13 @@ def test_argument_validation_is_host_side():
     assert lib.dprhot_comm_init(null, 2, 0, null) == -1
     assert lib.dprhot_allgather_ctx(null, null, null, 0, null) == -1
     assert lib.dprhot_comm_destroy(null) == 0  # destroying nothing is fine
+    # round 2: the no-logits forward and the score-free rank
+    assert lib.dprhot_dscores(null, 8192, null, 8192, 768, null, 0, null, 1.0, 1.0, null, null, null, 0, null) == -1  # NULL pointers
+    assert lib.dprhot_sim_rank(null, 8, null, 8, 64, null, 0, null, 1.0, null, null, 0, null) == -1
+    big, small = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.dprhot_workspace_bytes(8192, 65536, 768, ctypes.byref(big)) == 0
+    assert big.value < 8192 * 65536 * 4, "a no-logits shape must not reserve a logit buffer"
+    assert lib.dprhot_workspace_bytes(1024, 8192, 768, ctypes.byref(small)) == 0 and small.value >= 1024 * 8192 * 4  # logits stored here
     rows = ctypes.c_int(0)
     assert lib.dprhot_packed_rows(256, 768, ctypes.byref(rows)) == 0 and rows.value == 264  # 256 rows + 1 mask row -> 8-row multiple
     with pytest.raises(_lib.DprhotError):
