@@ -366,10 +366,13 @@ SkPlan sk_plan(int B, int Nc, int d) {
          Nc <= 16384 && !(B <= SS_ROWS && Nc <= SS_MAXNC);
   p.nt = cdiv(Nc, SK_COLS);
   {
-    // sim unit width: 128 columns x 4 ring slots (default) or DPRHOT_SK_COLS=64: 64 columns x 8 slots -- twice the units, two thirds of a
-    // unit's K range in flight at once.  Measured at cfg3 per rank: 12.4 vs 11.0 us for the sim launch (and 7.5 vs 5.8 us for the G launch,
-    // which then folds twice the tile statistics): the unit is not bound by its ring refills.  Kept as an A/B switch.
-    static const bool narrow = []() { const char* e = getenv("DPRHOT_SK_COLS"); return e && atoi(e) == 64; }();
+    // sim unit width: 128 columns x 4 ring slots, or 64 columns x 8 slots (twice the units, two thirds of a unit's K range in flight).
+    // The narrow unit pays when the wide ones would leave most of the chip idle (B = 32 x Nc = 2112, cfg2 gathered over 8 ranks: 17
+    // wide units, step 18.8 -> 17.6 us); with every CU busy it loses (cfg3 per rank, 260 wide units: sim 12.4 vs 11.0 us, and the G
+    // launch then folds twice the tile statistics).  DPRHOT_SK_COLS=64 / 128 forces one.
+    static const int forced = []() { const char* e = getenv("DPRHOT_SK_COLS"); return e ? atoi(e) : 0; }();
+    const bool few = cdiv(B, SK_ROWS) * cdiv(Nc, SK_COLS) < kNumCU / 2;
+    const bool narrow = forced == 64 || (forced != 128 && few);
     p.scols = (narrow && cdiv(Nc, SK_SCOLS) <= 8 * SK_MAXG) ? SK_SCOLS : SK_COLS;
   }
   p.nts = cdiv(Nc, p.scols);  // statistics tiles = sim units per row block

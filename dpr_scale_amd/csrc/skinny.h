@@ -27,7 +27,7 @@ namespace dprhot {
 constexpr int SK_THREADS = 256;
 constexpr int SK_ROWS = 32;    // query rows of a sim unit
 constexpr int SK_COLS = 128;   // context columns of a dC unit (and of the wide sim unit)
-constexpr int SK_SCOLS = 64;   // narrow sim unit (DPRHOT_SK_COLS=64, an A/B switch: measured slower, see sk_plan in dprhot.hip)
+constexpr int SK_SCOLS = 64;   // narrow sim unit: chosen when the wide units would leave most CUs idle (sk_plan in dprhot.hip)
 constexpr int SK_KC = 64;      // k per ring slot of the sim kernel
 constexpr int SK_SLOTS = 4;
 constexpr int SK_MAXB = 128;
