@@ -8,8 +8,33 @@ then every rank recomputes the whole [W*B, W*B*K] matrix.  What this path does (
   backward  reduce-scatter(sum) of the [Nc, d] dC partials -> this rank's [B*K, d] rows
   logging   all-reduce(sum) of one float (the loss numerator)
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _allpairs():
+    """DPRHOT_PATH_COLLECTIVES=allpairs: the path's all-gather and reduce-scatter as DIRECT ALL-PAIRS EXCHANGES (SURVEY.md section 8(e)
+    "Topology"): on the fully connected 8-GPU node every pair of GPUs owns an xGMI link, so a rank's W - 1 transfers use W - 1 links
+    at once -- all-gather = every rank sends its block to everybody (grouped send/recv), reduce-scatter = every rank sends chunk k to
+    rank k and adds the W chunks it receives in FP32 in a fixed order.  Modelled on 7 links x ~153 GB/s per direction (cfg3, W = 8):
+    all-gather of 1.5 MiB per rank ~10 us against ~70 us for a ring (7 sequential hops over one link each); reduce-scatter of 25 MB of
+    fp32 partials ~20 us + a 6 us local sum against ~140 us.  UNMEASURED on hardware (one-GPU boxes): the default stays RCCL's own
+    all-gather / reduce-scatter; equivalence is covered by the gloo tests."""
+    return os.environ.get("DPRHOT_PATH_COLLECTIVES", "") == "allpairs"
+
+
+class _Then:
+    """A collective's work handle plus what has to run on the waiting stream once it is done."""
+
+    def __init__(self, work, then):
+        self.work, self.then = work, then
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.then()
 
 
 def world(group=None):
@@ -28,6 +53,11 @@ def all_gather_rows(send: torch.Tensor, out: torch.Tensor, group=None, async_op=
     ContiguousDistributedSampler padding, utils.py:48-60, and DPRTransform padding, dpr_transform.py:143-161)."""
     W, _ = world(group)
     assert out.shape[0] == W * send.shape[0], (out.shape, send.shape, W)
+    if _allpairs():
+        s2, o2 = (send.view(torch.float16), out.view(torch.float16)) if (send.dtype == torch.bfloat16 and not _is_nccl(group)) else (send, out)
+        if _is_nccl(group):  # grouped send/recv of the ONE send buffer to every peer: no staging copy
+            return dist.all_to_all(list(o2.chunk(W, dim=0)), [s2] * W, group=group, async_op=async_op)
+        return dist.all_to_all_single(o2, s2.repeat(W, *([1] * (s2.dim() - 1))), group=group, async_op=async_op)  # gloo (CPU tests)
     if send.dtype == torch.bfloat16 and not _is_nccl(group):
         # gloo has no bf16: ship the bit patterns in a 2-byte type it knows (all-gather only moves bytes)
         return dist.all_gather_into_tensor(out.view(torch.float16), send.view(torch.float16), group=group,
@@ -40,6 +70,19 @@ def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_
     W, r = world(group)
     n = out.shape[0]
     assert inp.shape[0] == W * n
+    if _allpairs():
+        tmp = torch.empty_like(inp)  # chunk k: what rank k computed for MY columns
+        bytes_only = inp.dtype == torch.bfloat16 and not _is_nccl(group)
+        work = dist.all_to_all_single(tmp.view(torch.float16) if bytes_only else tmp, inp.view(torch.float16) if bytes_only else inp,
+                                      group=group, async_op=async_op)
+
+        def add_up():  # fixed order, fp32 accumulation (a bf16 wire is rounded once per partial, never inside the sum)
+            torch.sum(tmp.view(W, n, *inp.shape[1:]).float() if tmp.dtype != torch.float32 else tmp.view(W, n, *inp.shape[1:]), dim=0, out=out)
+
+        if async_op:
+            return _Then(work, add_up)
+        add_up()
+        return None
     if _is_nccl(group):
         return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     # gloo (CPU tests): no reduce-scatter -- all-reduce then keep the own slice (bf16: gloo cannot add it; the rounded values

@@ -45,11 +45,16 @@ def _worker(rank, W, port, meta, q, overlapped=False):
 
 
 @pytest.mark.parametrize("name,port,overlapped", [("w2_ddp", 29711, False), ("w4_ddp", 29712, False), ("w2_ddp", 29713, True),
-                                                  ("w4_ddp", 29714, "bf16wire")])
+                                                  ("w4_ddp", 29714, "bf16wire"), ("w4_ddp", 29715, "allpairs"),
+                                                  ("w2_ddp", 29716, "allpairs_bf16wire")])
 def test_ddp_branch_matches_reference(name, port, overlapped, monkeypatch):
-    """overlapped == "bf16wire": DPRHOT_DC_WIRE=bf16 -- the reduce-scatter of the dC partials ships bf16."""
-    if overlapped == "bf16wire":
-        monkeypatch.setenv("DPRHOT_DC_WIRE", "bf16")  # inherited by the spawned ranks
+    """overlapped == "bf16wire": DPRHOT_DC_WIRE=bf16 -- the reduce-scatter of the dC partials ships bf16.
+    "allpairs": DPRHOT_PATH_COLLECTIVES=allpairs -- all-gather / reduce-scatter as direct all-pairs exchanges."""
+    if isinstance(overlapped, str):
+        if "bf16wire" in overlapped:
+            monkeypatch.setenv("DPRHOT_DC_WIRE", "bf16")  # inherited by the spawned ranks
+        if "allpairs" in overlapped:
+            monkeypatch.setenv("DPRHOT_PATH_COLLECTIVES", "allpairs")
         overlapped = True
     meta, g = load_golden(name)
     W = meta["W"]
