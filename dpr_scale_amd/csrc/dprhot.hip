@@ -361,9 +361,10 @@ struct SkPlan { bool ok; int nt, nts, scols, nrb, ksteps, nslices; };
 SkPlan sk_plan(int B, int Nc, int d) {
   static const bool off = getenv("DPRHOT_NO_SKINNY") != nullptr;
   static const int min_nc = []() { const char* e = getenv("DPRHOT_SKINNY_MIN_NC"); return e ? atoi(e) : 2048; }();
+  static const bool no_small = getenv("DPRHOT_NO_SMALL_STEP") != nullptr;  // tuning aid: lets the skinny plan take the small-step shapes
   SkPlan p{};
   p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
-         Nc <= 16384 && !(B <= SS_ROWS && Nc <= SS_MAXNC);
+         Nc <= 16384 && (no_small || !(B <= SS_ROWS && Nc <= SS_MAXNC));
   p.nt = cdiv(Nc, SK_COLS);
   {
     // sim unit width: 128 columns x 4 ring slots, or 64 columns x 8 slots (twice the units, two thirds of a unit's K range in flight).

@@ -522,15 +522,20 @@ struct Epi8Stats : Epi8Base {
         part_s[at] = sm;
       }
       if (anygold) {
+        // the lane holds the gold column of its row iff rel = b*32 + q*8 + j with j < 4 (bit 2 clear): one select chain, one store
         const int yi = g8_lds_read(t.meta + 256 + t.wm * 128 + a * 32 + i);
         const int rel = yi - (t.n0 + t.wn * 64 + h * 4);
+        const int idx = ((rel >> 5) << 4) | (((rel >> 3) & 3) << 2) | (rel & 3);  // register index b*16 + q*4 + j
+        float gv = 0.f, gm = 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (rel == b * 32 + q * 8 + j) sim.gold[m] = madd[b * 4 + q][j] != 0.f ? -INFINITY : acc.v[a][b][q * 4 + j] * sim.inv_T;
+          for (int r = 0; r < 16; ++r) {
+            const bool hit = idx == b * 16 + r;
+            gv = hit ? acc.v[a][b][r] : gv;
+            gm = hit ? madd[b * 4 + (r >> 2)][r & 3] : gm;
+          }
+        if (rel >= 0 && rel < 64 && (rel & 4) == 0 && m < sim.M) sim.gold[m] = gm != 0.f ? -INFINITY : gv * sim.inv_T;
       }
     }
   }
