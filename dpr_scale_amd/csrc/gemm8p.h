@@ -713,8 +713,9 @@ struct Epi8Filter {
 
 // ---- the small kernels around the GEMM passes -------------------------------------------------------------------------------------
 // Row logsumexp from the strip statistics of Epi8Stats, row loss = lse - gold (dpr_task.py:212, CrossEntropyLoss per row).
-// One wave per row; the loss sum is a second tiny launch (reduce_sum_kernel, fixed order).  (A last-arriving-workgroup sum inside
-// this kernel was tried: the agent-scope fence every workgroup then needs made it 146 us instead of 5 + 5.)
+// One wave per row; the loss sum is a second tiny launch (reduce_sum_kernel, fixed order).  (Summing inside this kernel was tried
+// both ways: a last-arriving workgroup that re-reads the row losses needs an agent-scope fence per workgroup -- 146 us instead of
+// 6 + 6; one fixed-point ticket atomic per workgroup (loss_ticket_add) serialises 2048 atomics on one address -- 28 us.)
 __global__ __launch_bounds__(256) void g8_lse_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s, int npart,
                                                      const float* __restrict__ gold, int M, float* __restrict__ lse_ws,
                                                      float* __restrict__ row_lse, float* __restrict__ row_loss, float* __restrict__ loss_ws) {
