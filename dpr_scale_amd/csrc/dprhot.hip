@@ -79,6 +79,18 @@ E with_loss_stamp(E e) {
     if (e_ != hipSuccess) return fail(DPRHOT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// "dynamic LDS size raised for this kernel" is a per-device fact (one code object per device): one bit per device ordinal
+struct AttrOnce {
+  unsigned long long devs = 0;
+  static int cur() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d & 63;
+  }
+  bool operator!() const { return !((devs >> cur()) & 1ull); }
+  void operator=(bool) { devs |= 1ull << cur(); }  // benign race: idempotent
+};
+
 #define REQUIRE(cond, ...) \
   do {                     \
     if (!(cond)) return fail(DPRHOT_E_INVALID, __VA_ARGS__); \
@@ -162,7 +174,7 @@ template <int BM, int BN, int BK, bool AK, bool BKM, bool TR, class Epi, bool AF
 int launch_one(const GemmArgs& a, const Epi& epi, int splits, hipStream_t st) {
   auto kern = gemm_bf16_kernel<BM, BN, BK, 2, 2, AK, BKM, TR, Epi, AF, BF>;
   constexpr size_t lds = gemm_lds_bytes<BM, BN, BK, AK, BKM>();
-  static bool attr_done = false;  // benign race: idempotent
+  static AttrOnce attr_done;  // benign race: idempotent
   if (lds > 48 * 1024 && !attr_done) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -179,7 +191,7 @@ int launch_one(const GemmArgs& a, const Epi& epi, int splits, hipStream_t st) {
 template <class Epi, bool PERSIST>
 int launch_big(const GemmArgs& a, const Epi& epi, hipStream_t st) {
   auto kern = gemm256_kernel<Epi, PERSIST>;
-  static bool attr_done = false;  // benign race: idempotent
+  static AttrOnce attr_done;  // benign race: idempotent
   if (!attr_done) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2_lds_total));
     attr_done = true;
@@ -196,7 +208,7 @@ int launch_big(const GemmArgs& a, const Epi& epi, hipStream_t st) {
 template <class Epi, int SCHED = 4>
 int launch_g8(const GemmArgs& a, const Epi& epi, hipStream_t st) {
   auto kern = gemm8p_kernel<Epi, 0, SCHED>;
-  static bool attr_done = false;  // benign race: idempotent
+  static AttrOnce attr_done;  // benign race: idempotent
   if (!attr_done) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
     attr_done = true;
@@ -266,7 +278,7 @@ int launch_pair_one(const GemmArgs& a1, const EpiScaleF32& e1, const GemmArgs& a
                     hipStream_t st) {
   auto kern = gemm_pair_kernel<C1, C2, EpiScaleF32, EpiScaleF32>;
   constexpr size_t lds = C1::lds > C2::lds ? C1::lds : C2::lds;
-  static bool attr_done = false;
+  static AttrOnce attr_done;
   if (lds > 48 * 1024 && !attr_done) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
@@ -499,7 +511,7 @@ int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
 template <int NCH, int COLS, int SLOTS>
 int launch_sk_sim_c(const SkSimArgs& a, int grid, hipStream_t st) {
   const size_t lds = sk_sim_lds();
-  static bool attr_done[2] = {false, false};  // benign race: idempotent
+  static AttrOnce attr_done[2];  // benign race: idempotent
   if (a.q != nullptr) {
     auto kern = sk_sim_kernel<NCH, true, COLS, SLOTS>;
     if (!attr_done[0]) {
@@ -561,7 +573,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     SkBwdArgs b{G, Qb, Cb, B, Nc, d, h_scale, d_scale, dC_part, loss_sum, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0,
                 g_packed.n_ctx, sk.ksteps, sk.nslices, part, ndq_pad};
     const size_t lds = sk_bwd_lds();
-    static bool attr_done = false;
+    static AttrOnce attr_done;
     if (!attr_done) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_done = true;
@@ -1067,7 +1079,7 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
                                  : EpiScaleF32{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
   if (p.big) {
     auto kern = gemm256_bwd_kernel<EpiScaleF32>;
-    static bool attr_done = false;  // benign race: idempotent
+    static AttrOnce attr_done;  // benign race: idempotent
     if (!attr_done) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2_lds_total));
       attr_done = true;
@@ -1079,7 +1091,7 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     if (!no8 && B % 128 == 0 && Nc % 128 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9) {
       // the phase-interleaved schedule (gemm8pb.h): an even number of K steps per unit, byte offsets in 32 bits
       auto k8 = gemm8p_bwd_kernel<Epi8Scale>;
-      static bool attr8_done = false;
+      static AttrOnce attr8_done;
       if (!attr8_done) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
         attr8_done = true;
@@ -1156,7 +1168,8 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
 #define DPRHOT_SS_LAUNCH(CPT, NS)                                                                                              \
   do {                                                                                                                         \
     auto kern = step_small_kernel<CPT, tw, NS>;                                                                                  \
-    static size_t attr = 0; /* benign race: idempotent */                                                                      \
+    static size_t attr_dev[64] = {}; /* per device; benign race: idempotent */                                                 \
+    size_t& attr = attr_dev[lds > 48 * 1024 ? AttrOnce::cur() : 0];                                                            \
     if (lds > 48 * 1024 && attr < lds) {                                                                                       \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       attr = lds;                                                                                                              \

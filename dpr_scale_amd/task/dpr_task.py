@@ -14,6 +14,8 @@ same logged metric names and the same checkpoint layout (`query_encoder.*` / `co
 The maths per rank is identical (tests/golden/*_ddp.npz come from the reference's own
 DDP branch).  Every device op goes through libdprhot.so (dpr_scale_amd.hotpath); there is no CPU fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.optim.lr_scheduler import LambdaLR
@@ -97,6 +99,9 @@ class DenseRetrieverTask(LightningModule):
         self.pretrained_checkpoint_path = pretrained_checkpoint_path
         self.softmax_temperature = softmax_temperature
         self.setup_done = False
+        # multi-GPU step: contexts first (collectives hidden under the query tower) unless the reference's order
+        # is asked for (dropout RNG stream identical to the reference's, see training_step)
+        self.context_tower_first = os.environ.get("DPRHOT_TOWER_ORDER", "") != "reference"
 
     # ---- model construction / checkpoints (reference :55-92) -------------------------------------------
     def setup(self, stage: str):
@@ -192,12 +197,14 @@ class DenseRetrieverTask(LightningModule):
         pos, mask = batch["pos_ctx_indices"], batch["ctx_mask"]
         T = self.softmax_temperature
         if (self.in_batch_negatives and self._is_distributed() and hotpath.D.world(None)[0] > 1
-                and type(self).forward is DenseRetrieverTask.forward):
+                and type(self).forward is DenseRetrieverTask.forward and self.context_tower_first):
             # Multi-GPU (reference :163-195).  Context tower FIRST: its rows go into the one all-gather, which then
             # runs on RCCL's stream underneath the query tower; in backward the reduce-scatter of dC overlaps the
             # query-tower backward the same way (hotpath.ContextGather / defer_context_grad).  The encoders are
-            # independent, so the order does not change q or c.  A subclass that overrides forward() keeps the
-            # reference's call below.
+            # independent, so the order changes q and c only through the dropout RNG stream (the reference draws the
+            # query tower's masks first); set `context_tower_first = False` (or DPRHOT_TOWER_ORDER=reference) for a
+            # seed-for-seed comparison -- the collectives then run exposed.  A subclass that overrides forward()
+            # keeps the reference's call below.
             c = self.encode_contexts(batch["contexts_ids"])
             c, pending = hotpath.defer_context_grad(c)
             gather = hotpath.ContextGather(c, mask, None, self.kernels)
