@@ -122,7 +122,7 @@ def _task_worker(rank, W, port, q):
 
     hotpath.ContextGather = CountingGather
     out = {}
-    for mode in ("overlapped", "plain"):
+    for mode in ("overlapped", "plain", "switch"):
         torch.manual_seed(0)  # same weights on every rank and in both modes
         task = hydra_compat.instantiate(cfg.task, _recursive_=False)
         task.kernels = OracleKernels()
@@ -135,11 +135,14 @@ def _task_worker(rank, W, port, q):
                 def forward(self, query_ids, contexts_ids):
                     return self.encode_queries(query_ids), self.encode_contexts(contexts_ids)
             task.__class__ = Plain
+        if mode == "switch":  # the documented knob for seed-for-seed runs: reference order on the base class
+            task.context_tower_first = False
         loss = task.training_step(batch, 0)
         loss.backward()
         grads = torch.cat([p.grad.flatten() for p in task.parameters() if p.grad is not None])
         out[mode] = (loss.item(), grads)
-    assert len(started) == 1, started  # the early gather ran in exactly one of the two modes
+    assert len(started) == 1, started  # the early gather ran in exactly one of the three modes
+    assert out["switch"][0] == out["plain"][0] and torch.equal(out["switch"][1], out["plain"][1])
     q.put((rank, out["overlapped"][0], out["plain"][0], (out["overlapped"][1] - out["plain"][1]).abs().max().item(),
            out["plain"][1].abs().max().item()))
     dist.barrier()
