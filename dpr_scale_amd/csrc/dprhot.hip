@@ -746,6 +746,11 @@ int dprhot_pairwise_bwd(const float* g, const float* q, const float* c, int B, i
   return DPRHOT_OK;
 }
 
+static void launch_topk(const TopkArgs& p, int rows, hipStream_t st) {
+  if (p.k <= TK_KSMALL) hipLaunchKernelGGL((topk_stream_kernel<1024, TK_KSMALL, 4>), dim3(rows), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((topk_stream_kernel<4096, TK_KMAX, 8>), dim3(rows), dim3(256), 0, st, p);
+}
+
 int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values,
                        int64_t* indices, int first, void* stream) {
   REQUIRE(S && values && indices, "NULL pointer");
@@ -753,7 +758,7 @@ int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t c
           (long long)ld, k);
   REQUIRE(col_offset >= 0, "negative col_offset");
   TopkArgs p{S, rows, cols, (long long)ld, (long long)col_offset, k, values, indices, first ? 1 : 0, nullptr, nullptr};
-  hipLaunchKernelGGL(topk_stream_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, p);
+  launch_topk(p, rows, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
 }
@@ -810,7 +815,7 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
       GemmArgs a8{Q, Cj, nq, cols, d, d, d, d};
       if (int rc = launch_g8(a8, e8, st)) return rc;
       TopkArgs p8{S, nq, cols, (long long)cols, (long long)(id_offset + j0), k, values, indices, 0, cand_j, cnt};
-      hipLaunchKernelGGL(topk_stream_kernel, dim3(nq), dim3(256), 0, st, p8);
+      launch_topk(p8, nq, st);
       HIP_TRY(hipGetLastError());
       continue;
     }
@@ -819,7 +824,7 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
     EpiFilter epi{values, indices, k, nq, cols, (long long)(id_offset + j0), cnt, S, cand_j};
     if (int rc = launch_gemm<true, true>(tile, a, epi, 1, st)) return rc;
     TopkArgs p{S, nq, cols, (long long)cols, (long long)(id_offset + j0), k, values, indices, 0, cand_j, cnt};
-    hipLaunchKernelGGL(topk_stream_kernel, dim3(nq), dim3(256), 0, st, p);
+    launch_topk(p, nq, st);
     HIP_TRY(hipGetLastError());
   }
   return DPRHOT_OK;

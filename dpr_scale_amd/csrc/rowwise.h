@@ -698,20 +698,27 @@ __global__ __launch_bounds__(256) void pairwise_bwd_kernel(const float* __restri
 // Streaming top-k per row (torch.topk of run_retrieval_pytorch.py:149-150,156-157, and its shard re-merge
 // :272-277), in the total order (score desc, column asc).  State = the k best so far, sorted, in HBM
 // ([rows][k] values + int64 columns); one workgroup per row folds one chunk of columns into it:
-//   scan the chunk in windows of 8192 columns (32 values per thread in registers, ONE barrier per window),
-//   append the values that beat the current k-th entry to an LDS buffer, and whenever the buffer fills up
-//   bitonic-sort buffer + state (2048 slots) and keep the k best -- the threshold only ever rises, so after the
-//   first windows almost nothing is appended and the kernel is a pure stream over the scores.
+//   scan the chunk in windows of 4096 / 8192 columns (16 / 32 values per thread in registers, the next window's loads in flight,
+//   every row starting at a different window), append the values that beat the current k-th entry to an LDS buffer, and merge
+//   buffer + state when enough are waiting -- the threshold only ever rises, so after the first windows almost nothing is
+//   appended and the kernel is a pure stream over the scores (268 MB in 62 us = 4.3 TB/s at 1024 x 65536).
+//   k <= 256 (12 KB of LDS, 4 rows per CU): merges by COUNTING (the state is sorted, so an entry's new position is a count:
+//   no sort, two barriers); an empty state first takes the k-th best of the 256 per-thread maxima of its first window as a
+//   bound (a valid lower bound of the row's k-th best: k elements are at or ahead of it), so ~3 % of that window qualifies
+//   instead of all of it.  k <= 1024 (48 KB): bitonic sort of buffer + state (up to 4096 slots).
+//   A candidate list of <= 256 entries (what the GEMM's filter epilogue leaves of a warm chunk) is merged by counting straight
+//   from / to HBM.
 // Exact and deterministic (the buffer order is arbitrary, the sort is by the total order).  k <= 1024.
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool tk_before(float v1, long long j1, float v2, long long j2) {  // (v1,j1) ranks ahead of (v2,j2)
   return v1 > v2 || (v1 == v2 && j1 < j2);
 }
 
-constexpr int TK_P = 4096;           // sort size
 constexpr int TK_KMAX = 1024;        // run_retrieval_pytorch.py takes any --topk; dragon/README recipes use 1000
-constexpr int TK_CAP = TK_P - TK_KMAX;  // candidate slots
-constexpr int TK_WIN = 8;            // 1024-column steps per window
+// two sizes of the kernel: sort size P (LDS: 12 bytes per slot), state slots KM, candidate slots P - KM.  k <= 256 runs on
+// 12 KB of LDS (every row of a 1024-query batch resident at once), k <= 1024 on 48 KB (three rows per CU)
+constexpr int TK_KSMALL = 256;
+constexpr int TK_SMALL = 256;        // candidate lists up to here are merged by counting (no sort)
 
 struct TopkArgs {
   const float* S;  // [rows][ld]
@@ -728,8 +735,61 @@ struct TopkArgs {
   int* cnt;
 };
 
+// number of ranks the candidate (cv, ci) pushes the entry (v, id) down: ties in the value are rare, the 64-bit id compare sits behind
+// a branch that almost never runs
+__device__ __forceinline__ int tk_ahead(float cv, long long ci, float v, long long id) {
+  int a = cv > v ? 1 : 0;
+  if (__builtin_expect(cv == v, 0)) a = ci < id ? 1 : 0;
+  return a;
+}
+
+// state [0,k) (sorted best-first) + candidates [k, k+cnt) (any order) -> the k best, sorted, in [0,k); k + cnt <= NS * 256.
+// By counting, no sort: a state entry moves down by the number of candidates ahead of it, a candidate lands at (state entries
+// ahead of it, by bisection) + (candidates ahead of it).  NS entries per thread, cnt broadcast reads, two barriers.
+template <int NS>
+__device__ __forceinline__ void tk_merge_count(float* sv, long long* si, int k, int cnt, int tid) {
+  float v[NS];
+  long long id[NS];
+  int r[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int e = tid + s * 256;
+    const bool on = e < k + cnt;
+    v[s] = on ? sv[e] : -INFINITY;
+    id[s] = on ? si[e] : 0x7fffffffffffffffLL;
+    int rr = e;
+    if (on && e >= k) {
+      int lo = 0, hi = k;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tk_before(sv[mid], si[mid], v[s], id[s])) lo = mid + 1; else hi = mid;
+      }
+      rr = lo;
+    }
+    r[s] = on ? rr : 0x40000000;
+  }
+#pragma unroll 4
+  for (int j = k; j < k + cnt; ++j) {
+    const float cv = sv[j];
+    const long long ci = si[j];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) r[s] += tk_ahead(cv, ci, v[s], id[s]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (r[s] < k) { sv[r[s]] = v[s]; si[r[s]] = id[s]; }
+  __syncthreads();
+}
+
+template <bool COUNTING>  // the 12 KB kernel (k <= 256, <= 1024 slots) merges by counting; the 48 KB one sorts
 __device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cnt, int tid) {
-  // sort state [0,k) + candidates [k, k+cnt) (padded to a power of two P) best-first
+  if (COUNTING) {
+    if (k + cnt <= 256) return tk_merge_count<1>(sv, si, k, cnt, tid);
+    if (k + cnt <= 512) return tk_merge_count<2>(sv, si, k, cnt, tid);
+    return tk_merge_count<4>(sv, si, k, cnt, tid);
+  }
+  // bitonic sort of everything (padded to a power of two P) best-first
   int P = 64;
   while (P < k + cnt) P <<= 1;
   for (int i = k + cnt + tid; i < P; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
@@ -749,7 +809,24 @@ __device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cn
   }
 }
 
-__global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
+#ifdef TK_TIMING  // scratch/tk_probe.hip: per-workgroup time (10 ns ticks) spent in each part of the kernel, thread 0's view
+__device__ unsigned long long g_tk_tm[4096 * 8];
+#define TK_T0() unsigned long long tk_last_ = wall_clock64(), tk_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TK_T(i) do { const unsigned long long t_ = wall_clock64(); tk_acc_[i] += t_ - tk_last_; tk_last_ = t_; } while (0)
+#define TK_TN(i) (tk_acc_[i] += 1)
+#define TK_TEND() do { if (tid == 0) for (int i_ = 0; i_ < 8; ++i_) g_tk_tm[(size_t)blockIdx.x * 8 + i_] = tk_acc_[i_]; } while (0)
+#else
+#define TK_T0()
+#define TK_T(i)
+#define TK_TN(i)
+#define TK_TEND()
+#endif
+
+template <int TK_P, int TK_KM, int TK_WIN>
+__global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(TopkArgs p) {
+  constexpr int TK_CAP = TK_P - TK_KM;
+  constexpr int TK_FOLD_AT = TK_CAP - 512 < 384 ? TK_CAP - 512 : 384;  // a fold appends up to 512 values
+  static_assert(TK_KM + TK_SMALL <= TK_P && TK_KM + 257 <= TK_P, "scratch areas behind the state");
   __shared__ float sv[TK_P];
   __shared__ long long si[TK_P];
   __shared__ int s_cnt, s_win2[2];  // window counters alternate: the reset of one never races the adds into the other
@@ -764,86 +841,194 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
     si[i] = j < 0 ? 0x7fffffffffffffffLL : j;
   }
   if (tid == 0) { s_cnt = 0; s_win2[0] = 0; s_win2[1] = 0; }
+  if (p.cnt != nullptr && ncols <= TK_SMALL) {
+    // A warm chunk leaves a row a handful of candidates (~k * chunk / columns seen): no sort.  The state is sorted, so the
+    // final position of every entry is a count: state entry i moves down by the number of candidates ahead of it, a candidate
+    // lands at (state entries ahead of it, by bisection) + (candidates ahead of it).  Two barriers instead of ~40.
+    float* cv = sv + TK_KM;
+    long long* ci = si + TK_KM;
+    for (int i = tid; i < ncols; i += 256) {
+      cv[i] = Srow[i];
+      ci[i] = p.col_offset + Jrow[i];
+    }
+    __syncthreads();
+    if (tid == 0) p.cnt[row] = 0;
+    for (int e = tid; e < k + ncols; e += 256) {
+      float v;
+      long long id;
+      int r;
+      if (e < k) {
+        v = sv[e]; id = si[e]; r = e;
+      } else {
+        v = cv[e - k]; id = ci[e - k];
+        int lo = 0, hi = k;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (tk_before(sv[mid], si[mid], v, id)) lo = mid + 1; else hi = mid;
+        }
+        r = lo;
+      }
+#pragma unroll 8
+      for (int j = 0; j < ncols; ++j) r += tk_ahead(cv[j], ci[j], v, id);
+      if (r < k) {
+        p.vals[(size_t)row * k + r] = v;
+        p.idx[(size_t)row * k + r] = id == 0x7fffffffffffffffLL ? -1 : (int64_t)id;
+      }
+    }
+    return;
+  }
+  TK_T0();
   __syncthreads();
   if (p.cnt != nullptr && tid == 0) p.cnt[row] = 0;
   float tv = sv[k - 1];
   long long ti = si[k - 1];
+  // incl: (tv, ti) is an element of THIS window that is not in the state yet (the bound of an empty state, below): it qualifies too
+  bool incl = false;
+  // merging costs (k + m) * m compares for m waiting candidates: merge early and often (the threshold rises sooner, too)
+  const int flush_at = TK_P <= 1024 ? max(k, 64) : min(TK_CAP / 2, max(256, 2 * k));
   const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.S) & 15) == 0);
   int wpar = 0;
-  for (int base = 0; base < ncols; base += TK_WIN * 1024, wpar ^= 1) {
-    float v[TK_WIN][4];
-    int cj[TK_WIN][4];  // column of each value (implicit for a score matrix, loaded for a candidate list)
-    int mine = 0;
+  // Rows are a power-of-two stride apart (ld * 4 bytes): workgroups walking their rows in step would all be on the same few HBM
+  // channels at any moment.  Every row starts at a different window and wraps around (the result does not depend on the order).
+  const int nwin = (ncols + TK_WIN * 1024 - 1) / (TK_WIN * 1024), nfull = ncols / (TK_WIN * 1024);
+  const int win0 = nfull > 0 ? (int)(((unsigned)row * 7u) % (unsigned)nfull) : 0;
+  // the next window's loads are in flight while this one is examined (a window is a dependent trip to HBM otherwise)
+  float vn[TK_WIN][4];
+  int cn[TK_WIN][4];
+  auto load_window = [&](int itx) {
+    const int b = ((win0 + itx) % nwin) * (TK_WIN * 1024);
 #pragma unroll
     for (int w = 0; w < TK_WIN; ++w) {
-      const int j = base + w * 1024 + tid * 4;
+      const int j = b + w * 1024 + tid * 4;
       if (vec && j + 3 < ncols) {
         const float4 x = *reinterpret_cast<const float4*>(Srow + j);
-        v[w][0] = x.x; v[w][1] = x.y; v[w][2] = x.z; v[w][3] = x.w;
+        vn[w][0] = x.x; vn[w][1] = x.y; vn[w][2] = x.z; vn[w][3] = x.w;
         if (Jrow != nullptr) {
           const int4 y = *reinterpret_cast<const int4*>(Jrow + j);
-          cj[w][0] = y.x; cj[w][1] = y.y; cj[w][2] = y.z; cj[w][3] = y.w;
+          cn[w][0] = y.x; cn[w][1] = y.y; cn[w][2] = y.z; cn[w][3] = y.w;
         }
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[w][e] = (j + e < ncols) ? Srow[j + e] : NAN;  // NaN never qualifies
-          if (Jrow != nullptr) cj[w][e] = (j + e < ncols) ? Jrow[j + e] : 0;
+          vn[w][e] = (j + e < ncols) ? Srow[j + e] : NAN;  // NaN never qualifies
+          if (Jrow != nullptr) cn[w][e] = (j + e < ncols) ? Jrow[j + e] : 0;
         }
       }
-      if (Jrow == nullptr) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cj[w][e] = j + e;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) mine += tk_before(v[w][e], p.col_offset + cj[w][e], tv, ti) ? 1 : 0;
     }
-    if (mine) atomicAdd(&s_win2[wpar], mine);
-    __syncthreads();
-    const int win = s_win2[wpar], cnt0 = s_cnt;
-    if (tid == 0) s_win2[wpar ^ 1] = 0;  // the OTHER counter (next window's): nobody touches it before the next barrier pair
-    __syncthreads();
-    if (win == 0) continue;  // (uniform) the common case once the threshold has risen
-    if (cnt0 + win <= TK_CAP) {
+  };
+  if (nwin > 0) load_window(0);
+  for (int it = 0; it < nwin; ++it, wpar ^= 1) {
+    const int base = ((win0 + it) % nwin) * (TK_WIN * 1024);
+    float v[TK_WIN][4];
+    int cj[TK_WIN][4];  // column of each value (implicit for a score matrix, loaded for a candidate list)
+    int mine = 0;
+#pragma unroll
+    for (int w = 0; w < TK_WIN; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[w][e] = vn[w][e];
+        cj[w][e] = Jrow != nullptr ? cn[w][e] : base + w * 1024 + tid * 4 + e;
+      }
+    if (it + 1 < nwin) load_window(it + 1);
+    if (p.first && it == 0 && p.cnt == nullptr && k <= 256 && base + 1024 <= ncols) {
+      // Empty state: everything would qualify and the first window alone would cost a 2048-slot sort per 1024 values.  A valid
+      // bound is cheap: the 256 per-thread maxima are 256 distinct elements, so the k-th best of them has k elements at or ahead
+      // of it -- the row's k-th best cannot rank behind it.  Only values at or ahead of the bound enter the buffer (~1.5 % of a
+      // window of random scores for k = 100).
+      float bv = -INFINITY;
+      long long bj = 0x7fffffffffffffffLL;
 #pragma unroll
       for (int w = 0; w < TK_WIN; ++w)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const long long gj = p.col_offset + cj[w][e];
-          if (tk_before(v[w][e], gj, tv, ti)) {
-            const int pos = atomicAdd(&s_cnt, 1);
-            sv[k + pos] = v[w][e];
-            si[k + pos] = gj;
-          }
+          if (tk_before(v[w][e], gj, bv, bj)) { bv = v[w][e]; bj = gj; }
         }
+      float* mv = sv + TK_KM;
+      long long* mj = si + TK_KM;
+      mv[tid] = bv;
+      mj[tid] = bj;
+      if (tid == 0) { mv[256] = -INFINITY; mj[256] = 0x7fffffffffffffffLL; }
       __syncthreads();
-      if (s_cnt > TK_CAP / 2) {  // uniform
-        tk_flush(sv, si, k, s_cnt, tid);
+      int r = 0;
+#pragma unroll 8
+      for (int t = 0; t < 256; ++t) r += tk_ahead(mv[t], mj[t], bv, bj);
+      if (r == k - 1) { mv[256] = bv; mj[256] = bj; }  // ranks among the maxima are distinct unless sentinels tie (then none
+      __syncthreads();                                  // may match: the bound stays the empty state's, everything qualifies)
+      if (mj[256] != 0x7fffffffffffffffLL || mv[256] > -INFINITY) { tv = mv[256]; ti = mj[256]; incl = true; }
+    }
+    // qualifiers of this window, one bit per held value (a tie in the value is rare: the id compare sits behind a branch; NaN
+    // never qualifies)
+    unsigned qm = 0;
+#pragma unroll
+    for (int w = 0; w < TK_WIN; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = v[w][e];
+        bool q = x > tv;
+        if (__builtin_expect(x == tv, 0)) {
+          const long long gj = p.col_offset + cj[w][e];
+          q = gj < ti || (incl && gj == ti);
+        }
+        qm |= (q ? 1u : 0u) << (w * 4 + e);
+      }
+    mine = __popc(qm);
+    TK_T(1);  // loads landed, qualifiers counted (window 0: + the bound)
+    if (mine) atomicAdd(&s_win2[wpar], mine);
+    __syncthreads();
+    const int win = s_win2[wpar], cnt0 = s_cnt;
+    if (tid == 0) s_win2[wpar ^ 1] = 0;  // the OTHER counter (next window's): nobody touches it before the next barrier pair
+    __syncthreads();
+    TK_T(2);  // barrier pair
+    if (win == 0) continue;  // (uniform) the common case once the threshold has risen
+    if (cnt0 + win <= TK_CAP) {
+      if (qm) {  // one slot reservation per thread, then plain stores
+        int pos = k + atomicAdd(&s_cnt, mine);
+#pragma unroll
+        for (int w = 0; w < TK_WIN; ++w)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (qm & (1u << (w * 4 + e))) {
+              sv[pos] = v[w][e];
+              si[pos] = p.col_offset + cj[w][e];
+              ++pos;
+            }
+      }
+      __syncthreads();
+      TK_T(3);  // append
+      if (s_cnt > flush_at) {  // uniform
+        tk_flush<(TK_P <= 1024)>(sv, si, k, s_cnt, tid);
         if (tid == 0) s_cnt = 0;
         tv = sv[k - 1];
         ti = si[k - 1];
+        incl = false;
         __syncthreads();
+        TK_T(4);  // flush
+        TK_TN(6);
       }
     } else {
+      TK_TN(7);
       // too many qualifiers for the buffer (in practice the first window of an empty state, where everything qualifies):
-      // fold 512 values at a time and sort as soon as 384 candidates are waiting.  The bitonic sort costs P log^2 P LDS
+      // fold 512 values at a time and sort as soon as TK_FOLD_AT candidates are waiting.  The bitonic sort costs P log^2 P LDS
       // operations (28 us at P = 2048 with four workgroups sharing a CU's LDS, a third of that at P = 1024), and after the
       // very first one the threshold already rejects most of what follows.
 #pragma unroll
       for (int w = 0; w < TK_WIN; ++w) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (s_cnt > 384) {  // uniform (read after a barrier)
-            tk_flush(sv, si, k, s_cnt, tid);
+          if (s_cnt > TK_FOLD_AT) {  // uniform (read after a barrier)
+            tk_flush<(TK_P <= 1024)>(sv, si, k, s_cnt, tid);
             if (tid == 0) s_cnt = 0;
             tv = sv[k - 1];
             ti = si[k - 1];
+            incl = false;
             __syncthreads();
           }
 #pragma unroll
           for (int e = 2 * h; e < 2 * h + 2; ++e) {
             const long long gj = p.col_offset + cj[w][e];
-            if (tk_before(v[w][e], gj, tv, ti)) {
+            // (qm was taken against the window's opening threshold: re-test, the folds raise it)
+            if ((qm & (1u << (w * 4 + e))) && (tk_before(v[w][e], gj, tv, ti) || (incl && v[w][e] == tv && gj == ti))) {
               const int pos = atomicAdd(&s_cnt, 1);
               sv[k + pos] = v[w][e];
               si[k + pos] = gj;
@@ -854,12 +1039,16 @@ __global__ __launch_bounds__(256) void topk_stream_kernel(TopkArgs p) {
       }
     }
   }
-  if (s_cnt > 0) tk_flush(sv, si, k, s_cnt, tid);
+  TK_T(5);  // (slow path, if taken)
+  if (s_cnt > 0) tk_flush<(TK_P <= 1024)>(sv, si, k, s_cnt, tid);
   __syncthreads();
+  TK_T(4);
   for (int i = tid; i < k; i += 256) {
     p.vals[(size_t)row * k + i] = sv[i];
     p.idx[(size_t)row * k + i] = si[i] == 0x7fffffffffffffffLL ? -1 : (int64_t)si[i];
   }
+  TK_T(0);
+  TK_TEND();
 }
 
 }  // namespace dprhot

@@ -340,7 +340,11 @@ def test_tie_rule_bit_exact(dev):
 
 
 @pytest.mark.parametrize("rows,cols,k,levels", [(5, 1000, 10, 4), (3, 70000, 100, 0), (64, 9000, 128, 50), (2, 3, 3, 2),
-                                               (4, 20000, 1, 0), (3, 50000, 1000, 0), (2, 1500, 1024, 7), (5, 30000, 300, 20)])
+                                               (4, 20000, 1, 0), (3, 50000, 1000, 0), (2, 1500, 1024, 7), (5, 30000, 300, 20),
+                                               # empty-state bound + counting merges (k <= 256): heavy ties, all-equal scores,
+                                               # k at the variant boundary, partial / rotated windows
+                                               (8, 65536, 100, 3), (4, 40000, 64, 1), (8, 65536, 256, 0), (6, 4608, 200, 0),
+                                               (1030, 16384, 100, 0), (3, 12289, 257, 5)])
 def test_streaming_topk_equals_stable_sort_prefix(rows, cols, k, levels, kn, dev):
     """torch.topk of run_retrieval_pytorch.py:149-150 under the frozen tie rule, in one piece and folded over pieces
     (the shard re-merge of :272-277); indices bit-exact."""
