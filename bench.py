@@ -296,8 +296,8 @@ def cpu_baseline_reference(B, K, d, T, budget_s=6.0):
 
 def roofline_router(dev, B=128, K=8, d=30528):
     """Extra information (never `value`): the CITADEL router loss (citadel_task.py:249-262) is the same Q x C^T +
-    CrossEntropyLoss on vocabulary-wide vectors (d = 30522, zero-padded to 30528): the one shape of the reference where the
-    step is MFMA-bound.  One in-batch step (forward + backward), per launch and as a whole."""
+    CrossEntropyLoss on vocabulary-wide vectors (d = 30522, zero-padded to 30528): the reference's most arithmetic-heavy use of
+    the path (57 flop/byte at B = 128 -- still left of the ridge).  One in-batch step (forward + backward), per launch and as a whole."""
     hp = HotPathStep(B, K, d, 1.0, 1, 0, dev)
     bn = float(B) * hp.Nc
     out = {"workload": f"router vectors: B={B} x Nc={hp.Nc} x d={d} (30522 padded), fp32 in, one in-batch step"}
@@ -307,8 +307,14 @@ def roofline_router(dev, B=128, K=8, d=30528):
         tot += us
         out[name] = {"us": round(us, 2), "TFLOPs": round(fl / us * 1e-6, 1), "mfma_frac": round(fl / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
     step = time_kernel(hp, hp.k_step, reps=10, iters=5)
-    out.update({"step_us": round(step, 2), "bound": "mfma", "achieved": round(6 * bn * d / step * 1e-6, 1), "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(6 * bn * d / step * 1e-6 / MFMA_PEAK_TFLOPS, 4)})
+    # Which roof: 6 * B * Nc * d flops against fp32 q / c read once, their bf16 copies written and read back by the backward
+    # (same bytes as re-reading fp32), fp32 dQ / dC written, logits and G: 12 * (B + Nc) * d + 12 * B * Nc bytes.  At B = 128
+    # that is 57 flop/byte, far left of the ridge (312 flop/byte): the step is HBM-bound, the MFMA share is reported beside it.
+    algo = 12.0 * (B + hp.Nc) * d + 12.0 * bn
+    out.update({"step_us": round(step, 2), "bound": "hbm", "algorithmic_bytes": algo, "achieved": round(algo / step * 1e-3, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / step * 1e-3 / HBM_PEAK_GBS, 4),
+                "flops": 6 * bn * d, "flop_per_byte": round(6 * bn * d / algo, 1),
+                "mfma_frac": round(6 * bn * d / step * 1e-6 / MFMA_PEAK_TFLOPS, 4)})
     del hp
     torch.cuda.empty_cache()
     return out
