@@ -457,6 +457,10 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
     return p;
   }
   p.tile = B <= 32 ? (d >= 256 ? 5 : 3) : 2;
+  if (wide && B >= 128) {  // tuning aid: tile of the vocabulary-wide sim (0 = 128x128, 1 = 64x128, 2 = 64x64)
+    static const int wt = getenv("DPRHOT_WIDE_TILE") ? atoi(getenv("DPRHOT_WIDE_TILE")) : 2;
+    if (wt >= 0 && wt <= 2) p.tile = wt;
+  }
   const int bk = kTiles[p.tile].bk, ksteps = cdiv(d, bk);
   int splits = ksteps < 4 ? ksteps : 4;
   if (wide) {  // >= 2 workgroups per CU, at least 4 K steps each, at most 32 slabs of partial logits
