@@ -673,16 +673,22 @@ struct Epi8Filter {
   }
   __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
     const int i = t.lane & 31, h = t.lane >> 5;
-    float tv[4];
+    // Screen by the maximum of each 16-value run (one row, 16 of the tile's columns): v_max3 chains instead of a compare per value.
+    // A warm chunk still leaves a wave tile a few qualifiers (~12.5 * k / 100 / chunk index per 128 x 64 scores), so the walk below
+    // is guarded per run as well: only runs that hold one are walked.
+    float tv[4], mx[4][2];
     bool any = false;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       tv[a] = __int_as_float(g8_lds_read(t.meta + 512 + t.wm * 128 + a * 32 + i));
-      // branch-free screen: once the thresholds have risen almost no tile holds a score that reaches its row's k-th best
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b) {
+        float m3 = fmaxf(fmaxf(acc.v[a][b][0], acc.v[a][b][1]), acc.v[a][b][2]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) any |= acc.v[a][b][r] >= tv[a];
+        for (int r = 3; r < 15; r += 2) m3 = fmaxf(fmaxf(m3, acc.v[a][b][r]), acc.v[a][b][r + 1]);
+        mx[a][b] = fmaxf(m3, acc.v[a][b][15]);
+        any |= mx[a][b] >= tv[a];
+      }
     }
     if (!any) return;
 #pragma unroll
@@ -690,7 +696,8 @@ struct Epi8Filter {
       const int m = t.m0 + t.wm * 128 + a * 32 + i;
       if (m >= M) continue;
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b) {
+        if (!(mx[a][b] >= tv[a])) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int n = t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
@@ -707,6 +714,7 @@ struct Epi8Filter {
             cand_j[(size_t)m * N + pos] = n;
           }
         }
+      }
     }
   }
 };
