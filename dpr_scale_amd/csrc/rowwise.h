@@ -718,7 +718,6 @@ constexpr int TK_KMAX = 1024;        // run_retrieval_pytorch.py takes any --top
 // two sizes of the kernel: sort size P (LDS: 12 bytes per slot), state slots KM, candidate slots P - KM.  k <= 256 runs on
 // 12 KB of LDS (every row of a 1024-query batch resident at once), k <= 1024 on 48 KB (three rows per CU)
 constexpr int TK_KSMALL = 256;
-constexpr int TK_SMALL = 256;        // candidate lists up to here are merged by counting (no sort)
 
 struct TopkArgs {
   const float* S;  // [rows][ld]
@@ -826,7 +825,9 @@ template <int TK_P, int TK_KM, int TK_WIN>
 __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(TopkArgs p) {
   constexpr int TK_CAP = TK_P - TK_KM;
   constexpr int TK_FOLD_AT = TK_CAP - 512 < 384 ? TK_CAP - 512 : 384;  // a fold appends up to 512 values
-  static_assert(TK_KM + TK_SMALL <= TK_P && TK_KM + 257 <= TK_P, "scratch areas behind the state");
+  // candidate lists up to TK_NSORT entries are merged by counting, longer ones streamed through the buffer
+  constexpr int TK_NSORT = TK_P <= 1024 ? 256 : 512;
+  static_assert(TK_KM + TK_NSORT <= 6 * 256 && TK_KM + TK_NSORT <= TK_P && TK_KM + 257 <= TK_P, "scratch areas behind the state");
   __shared__ float sv[TK_P];
   __shared__ long long si[TK_P];
   __shared__ int s_cnt, s_win2[2];  // window counters alternate: the reset of one never races the adds into the other
@@ -841,39 +842,23 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
     si[i] = j < 0 ? 0x7fffffffffffffffLL : j;
   }
   if (tid == 0) { s_cnt = 0; s_win2[0] = 0; s_win2[1] = 0; }
-  if (p.cnt != nullptr && ncols <= TK_SMALL) {
-    // A warm chunk leaves a row a handful of candidates (~k * chunk / columns seen): no sort.  The state is sorted, so the
-    // final position of every entry is a count: state entry i moves down by the number of candidates ahead of it, a candidate
-    // lands at (state entries ahead of it, by bisection) + (candidates ahead of it).  Two barriers instead of ~40.
-    float* cv = sv + TK_KM;
-    long long* ci = si + TK_KM;
+  if (p.cnt != nullptr && ncols <= TK_NSORT) {
+    // A warm chunk leaves a row a handful of candidates (~k * chunk / columns seen): no sort.  The state is sorted, so the final
+    // position of every entry is a count (tk_merge_count): two barriers instead of ~40, every candidate read once per thread.
     for (int i = tid; i < ncols; i += 256) {
-      cv[i] = Srow[i];
-      ci[i] = p.col_offset + Jrow[i];
+      sv[k + i] = Srow[i];
+      si[k + i] = p.col_offset + Jrow[i];
     }
     __syncthreads();
     if (tid == 0) p.cnt[row] = 0;
-    for (int e = tid; e < k + ncols; e += 256) {
-      float v;
-      long long id;
-      int r;
-      if (e < k) {
-        v = sv[e]; id = si[e]; r = e;
-      } else {
-        v = cv[e - k]; id = ci[e - k];
-        int lo = 0, hi = k;
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (tk_before(sv[mid], si[mid], v, id)) lo = mid + 1; else hi = mid;
-        }
-        r = lo;
-      }
-#pragma unroll 8
-      for (int j = 0; j < ncols; ++j) r += tk_ahead(cv[j], ci[j], v, id);
-      if (r < k) {
-        p.vals[(size_t)row * k + r] = v;
-        p.idx[(size_t)row * k + r] = id == 0x7fffffffffffffffLL ? -1 : (int64_t)id;
-      }
+    const int n = k + ncols;
+    if (n <= 256) tk_merge_count<1>(sv, si, k, ncols, tid);
+    else if (n <= 512) tk_merge_count<2>(sv, si, k, ncols, tid);
+    else if (n <= 1024) tk_merge_count<4>(sv, si, k, ncols, tid);
+    else tk_merge_count<6>(sv, si, k, ncols, tid);
+    for (int i = tid; i < k; i += 256) {
+      p.vals[(size_t)row * k + i] = sv[i];
+      p.idx[(size_t)row * k + i] = si[i] == 0x7fffffffffffffffLL ? -1 : (int64_t)si[i];
     }
     return;
   }

@@ -386,7 +386,8 @@ def test_topk_state_with_fewer_columns_than_k(kn, dev):
 
 @pytest.mark.parametrize("nq,shards,d,k,chunk", [(9, (4000, 13, 8, 2051), 64, 20, 1024), (130, (50000,), 768, 100, 8192),
                                                  (512, (100000, 40000), 128, 50, 32768),  # >= 256 tiles per chunk: the gemm8p.h filter epilogue
-                                                 (7, (30000, 5000), 128, 1000, 4096)])  # --topk 1000: dragon/README recipes
+                                                 (7, (30000, 5000), 128, 1000, 4096),  # --topk 1000: dragon/README recipes
+                                                 (40, (60000, 9000), 128, 300, 8192)])  # 48 KB variant, counted candidate merges
 def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk, kn, dev):
     """search_index + shard loop (run_retrieval_pytorch.py:141-166, :196-243, :272-277): ids bit-exact against
     the stable top-k of the full score matrix computed by the same similarity kernel; scores against fp32 torch."""
