@@ -546,9 +546,15 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   float* S = S_out ? S_out : reinterpret_cast<float*>(ws + wl.logits);
   float* tile_lse = reinterpret_cast<float*>(ws + wl.part_m);
   float* gold = reinterpret_cast<float*>(ws + wl.gold);
+  // packed layout whose ranks hold a whole number of sim tiles: only the real rows are multiplied (SkSimArgs::tiles_per_rank)
+  static const bool no_remap = getenv("DPRHOT_SK_NO_REMAP") != nullptr;  // A/B
+  const bool remap = !no_remap && g_packed.base != nullptr && g_packed.rows_c > g_packed.n_ctx && g_packed.n_ctx % sk.scols == 0 &&
+                     Nc % g_packed.rows_c == 0;
+  const int tpr = remap ? g_packed.n_ctx / sk.scols : 0;
+  const int nts = remap ? (Nc / g_packed.rows_c) * tpr : sk.nts;
   SkSimArgs a{q, nullptr, Cb, Qb, B, Nc, d, y, y_offset, colmask, inv_T, S, tile_lse, gold, g_packed.base, g_packed.rows_c,
-              g_packed.n_ctx, g_packed.row_bytes};
-  const int grid1 = sk.nrb * sk.nts;
+              g_packed.n_ctx, g_packed.row_bytes, tpr};
+  const int grid1 = sk.nrb * nts;
   int rc = DPRHOT_OK;
   switch (d / 128) {  // NCH = d / 64
     case 1: rc = launch_sk_sim<2>(a, grid1, sk.scols, st); break;
@@ -567,7 +573,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     static const int gp = []() { const char* e = getenv("DPRHOT_SK_GPARTS"); return e ? atoi(e) : 0; }();  // tuning aid
     int pp = gp > 0 ? gp : parts;
     while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
-    SkGArgs g{S, tile_lse, gold, sk.nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
+    SkGArgs g{S, tile_lse, gold, nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
     hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp + 1)), dim3(SK_THREADS), 0, st, g);
     HIP_TRY(hipGetLastError());
   }

@@ -53,6 +53,16 @@ int main(int argc, char** argv) {
       for (int i = 1; i < nst[k]; ++i) printf(" %.2f", ph[i] / nb);
       double dur = 0; for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (r[0]) dur += (r[nst[k] - 1] - r[0]) * 0.01; }
       printf(" | wg duration avg %.2f\n", dur / nb);
+      if (it == 3) {  // the slowest workgroups: who are they, when did they start, when did they end
+        std::vector<std::pair<double, int>> ends;
+        for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (r[0]) ends.push_back({(r[nst[k] - 1] - t0) * 0.01, b}); }
+        std::sort(ends.begin(), ends.end());
+        printf("   end times (us since first start): p50 %.2f p90 %.2f p99 %.2f max %.2f | last 8:", ends[ends.size() / 2].first,
+               ends[ends.size() * 9 / 10].first, ends[ends.size() * 99 / 100].first, ends.back().first);
+        for (size_t i = ends.size() - 8; i < ends.size(); ++i) { const unsigned long long* r = &t[((size_t)k * 4096 + ends[i].second) * 8];
+          printf(" wg%d(start %.2f dur %.2f)", ends[i].second, (r[0] - t0) * 0.01, (r[nst[k] - 1] - r[0]) * 0.01); }
+        printf("\n");
+      }
     }
   }
   float hs; CK(hipMemcpy(&hs, sum, 4, hipMemcpyDeviceToHost)); printf("loss_sum %.4f\n", hs);
