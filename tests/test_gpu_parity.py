@@ -373,6 +373,34 @@ def test_streaming_topk_equals_stable_sort_prefix(rows, cols, k, levels, kn, dev
         assert np.array_equal(st[1], i2.cpu().numpy()) and np.array_equal(st[0], v2.cpu().numpy())
 
 
+@pytest.mark.parametrize("k", [100, 256, 300])
+@pytest.mark.parametrize("pattern", ["ascending", "descending", "mostly_masked", "sawtooth"])
+def test_streaming_topk_adversarial_orders(pattern, k, kn, dev):
+    """Orders that defeat the streaming kernel's shortcuts: every new score beats all earlier ones (each window qualifies whole,
+    the fold path), none does (pure stream), almost everything masked (-inf ties broken by id), a sawtooth (ties across windows)."""
+    rows, cols = 5, 20000
+    j = torch.arange(cols, dtype=torch.float32)
+    if pattern == "ascending":
+        S = j.repeat(rows, 1) + torch.arange(rows).float()[:, None]
+    elif pattern == "descending":
+        S = (cols - j).repeat(rows, 1)
+    elif pattern == "mostly_masked":
+        S = torch.full((rows, cols), float("-inf"))
+        S[:, 7::997] = torch.randn(rows, len(range(7, cols, 997)), generator=torch.Generator().manual_seed(k))
+    else:
+        S = (j % 37).repeat(rows, 1)
+    S = S.to(dev)
+    order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
+    v, i = kn.topk(S, k)
+    assert torch.equal(i, order) and torch.equal(v, S.gather(1, order))
+    v2, i2 = torch.empty_like(v), torch.empty_like(i)
+    first = True
+    for a, b in ((0, 3000), (3000, 3001), (3001, 12000), (12000, cols)):
+        kn.topk_update(S[:, a:], b - a, a, v2, i2, first)
+        first = False
+    assert torch.equal(i2, order) and torch.equal(v2, v)
+
+
 def test_topk_state_with_fewer_columns_than_k(kn, dev):
     S = torch.tensor([[1.0, 3.0, 2.0, 3.0]], device=dev)
     v = torch.empty((1, 6), device=dev)
