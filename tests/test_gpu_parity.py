@@ -885,3 +885,42 @@ def test_packed_multi_rank_step_at_a_no_logits_shape(kn, dev):
             stamped[k * rows_c + n_ctx, 0] = 0.0
         assert ((stamped - dc_ref).abs().max() / dc_ref.abs().max()).item() <= 2e-3
         assert torch.all(stamped.view(W, rows_c, d)[:, n_ctx:] == 0)  # mask rows: masked columns have G == 0 exactly
+
+@pytest.mark.parametrize("W,B,K,d", [(8, 32, 8, 768), (4, 64, 16, 256), (8, 32, 9, 768), (8, 128, 8, 128)])
+def test_packed_skinny_step_tiles_over_real_rows(W, B, K, d, kn, dev):
+    """Few rows x thousands of gathered contexts (skinny.h) in the packed multi-rank layout: when a rank's n_ctx is a whole number
+    of sim tiles the tiles cover the real rows only and the header columns of the logits are written as -inf (cfg2 over 8 ranks:
+    64-column tiles; 4 x 64 x 16: 128-column tiles; K = 9: no whole number of tiles -> tiles over all packed rows).  Checked against
+    the unpacked formulation of the same step (explicit mask vector, label offset)."""
+    n_ctx = B * K
+    rows_c = kn.packed_rows(n_ctx, d)
+    gen = torch.Generator(device="cpu").manual_seed(W * 1000 + K)
+    qs = [(torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev) for _ in range(W)]
+    cs = [(torch.randn(n_ctx, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev) for _ in range(W)]
+    ms = [(torch.rand(n_ctx, generator=gen) < 0.05) for _ in range(W)]
+    y = torch.arange(B) * K
+    for m in ms:
+        m[y] = False
+    sends = []
+    for r in range(W):
+        send = torch.empty((rows_c, d), dtype=torch.bfloat16, device=dev)
+        kn.pack_ctx(cs[r], ms[r].to(torch.uint8).to(dev), send)
+        sends.append(send)
+    Cb = torch.cat(sends, 0).contiguous()
+    colmask = torch.empty(W * rows_c, dtype=torch.uint8, device=dev)
+    kn.unpack_mask(Cb, W, n_ctx, colmask)
+    yd = y.to(dev)
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    for r in (0, W - 1):
+        rl, lse_p, ls, _, dq, dcp = kn.inbatch_step_packed_f32(qs[r], Cb, Qb, W, r, n_ctx, yd, 1.0, 1.0 / (W * B))
+        rl_ref, lse_ref, ls_ref, G, S = kn.inbatch_fwd_f32(qs[r], None, Qb, Cb, yd, r * rows_c, colmask, 1.0, 1.0 / (W * B), want_logits=True)
+        dq_ref, dc_ref = kn.inbatch_bwd(G, Qb, Cb, 1.0, one)
+        assert abs(ls.item() - ls_ref.item()) <= 1e-5 * abs(ls_ref.item())
+        assert torch.allclose(lse_p, lse_ref, rtol=1e-5, atol=1e-5) and torch.allclose(rl, rl_ref, rtol=1e-4, atol=1e-5)
+        assert ((dq - dq_ref).abs().max() / dq_ref.abs().max()).item() <= 2e-3
+        stamped = dcp.clone()
+        for k in range(W):
+            stamped[k * rows_c + n_ctx, 0] = 0.0
+        assert ((stamped - dc_ref).abs().max() / dc_ref.abs().max()).item() <= 2e-3
+        assert torch.all(stamped.view(W, rows_c, d)[:, n_ctx:] == 0)  # header rows: their columns of G are exactly 0
