@@ -705,7 +705,8 @@ __global__ __launch_bounds__(256) void pairwise_bwd_kernel(const float* __restri
 //   k <= 256 (12 KB of LDS, 4 rows per CU): merges by COUNTING (the state is sorted, so an entry's new position is a count:
 //   no sort, two barriers); an empty state first takes the k-th best of the 256 per-thread maxima of its first window as a
 //   bound (a valid lower bound of the row's k-th best: k elements are at or ahead of it), so ~3 % of that window qualifies
-//   instead of all of it.  k <= 1024 (48 KB): bitonic sort of buffer + state (up to 4096 slots).
+//   instead of all of it.  k <= 1024 (48 KB): bitonic sort of buffer + state (up to 4096 slots); an empty state is started by
+//   radix select (see the kernel).
 //   A candidate list of <= 256 entries (what the GEMM's filter epilogue leaves of a warm chunk) is merged by counting straight
 //   from / to HBM.
 // Exact and deterministic (the buffer order is arbitrary, the sort is by the total order).  k <= 1024.
@@ -865,13 +866,95 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
   TK_T0();
   __syncthreads();
   if (p.cnt != nullptr && tid == 0) p.cnt[row] = 0;
+  const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.S) & 15) == 0);
+  if constexpr (TK_P > 1024) {
+    // Large k from an empty state (--topk 1000 of the DRAGON recipes): the buffer scheme below would sort 2048-4096 slots a dozen
+    // times before its threshold is worth anything (1.9 ms for 1024 x 65536, k = 1000).  Radix select instead: histogram the row by
+    // the top byte of an order-preserving key, find the bin the k-th best falls into, refine byte by byte until "everything ahead of
+    // the bin + the bin" fits a 2048-slot sort, collect exactly those, sort once.  Membership is decided on values only (equal
+    // floats have equal keys, -0 == +0), the tie rule on ids by the sort: exact.  2-3 streaming passes + 1 collecting pass.
+    if (p.first && p.cnt == nullptr && ncols >= 4096) {
+      int* hist = reinterpret_cast<int*>(si);  // 256 bins + 3 control words (the state is empty: its slots are free)
+      auto key_of = [](float x) -> unsigned {
+        if (x == 0.f) return 0x80000000u;
+        if (x != x) return 0u;  // NaN ranks last
+        const unsigned u = __float_as_uint(x);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+      };
+      auto for_each = [&](auto&& f) {
+        for (int j0 = tid * 4; j0 < ncols; j0 += 4096) {
+          float x[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u * 1024;
+            if (vec && j + 3 < ncols) {
+              const float4 y = *reinterpret_cast<const float4*>(Srow + j);
+              x[u][0] = y.x; x[u][1] = y.y; x[u][2] = y.z; x[u][3] = y.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) x[u][e] = (j + e < ncols) ? Srow[j + e] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int j = j0 + u * 1024 + e;
+              if (j < ncols) f(x[u][e], j);
+            }
+        }
+      };
+      unsigned prefix = 0;
+      int need = k, shift = 24, total = 0;
+      bool ok = false;
+      for (int pass = 0; pass < 4; ++pass, shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for_each([&](float x, int) {
+          const unsigned key = key_of(x);
+          if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        });
+        __syncthreads();
+        int above = 0;
+        for (int b = tid + 1; b < 256; ++b) above += hist[b];
+        const int mine = hist[tid];
+        if (above < need && need <= above + mine) { hist[256] = tid; hist[257] = need - above; hist[258] = mine; }
+        __syncthreads();
+        prefix = (prefix << 8) | (unsigned)hist[256];
+        need = hist[257];
+        total = (k - need) + hist[258];  // strictly ahead of the bin + the bin itself
+        __syncthreads();
+        if (total <= 2048 || (pass == 3 && total <= TK_P)) { ok = true; break; }
+      }
+      if (ok) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for_each([&](float x, int j) {
+          if ((key_of(x) >> shift) >= prefix) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            sv[pos] = x;
+            si[pos] = p.col_offset + j;
+          }
+        });
+        __syncthreads();
+        tk_flush<false>(sv, si, 0, s_cnt, tid);  // == total; bitonic, best-first
+        for (int i = tid; i < k; i += 256) {
+          p.vals[(size_t)row * k + i] = sv[i];
+          p.idx[(size_t)row * k + i] = si[i] == 0x7fffffffffffffffLL ? -1 : (int64_t)si[i];
+        }
+        return;
+      }
+      // more exact ties at the k-th value than the buffer holds: the streaming scheme below handles that; restore the empty state
+      for (int i = tid; i < k; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
+      __syncthreads();
+    }
+  }
   float tv = sv[k - 1];
   long long ti = si[k - 1];
   // incl: (tv, ti) is an element of THIS window that is not in the state yet (the bound of an empty state, below): it qualifies too
   bool incl = false;
   // merging costs (k + m) * m compares for m waiting candidates: merge early and often (the threshold rises sooner, too)
   const int flush_at = TK_P <= 1024 ? max(k, 64) : min(TK_CAP / 2, max(256, 2 * k));
-  const bool vec = (p.ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.S) & 15) == 0);
   int wpar = 0;
   // Rows are a power-of-two stride apart (ld * 4 bytes): workgroups walking their rows in step would all be on the same few HBM
   // channels at any moment.  Every row starts at a different window and wraps around (the result does not depend on the order).

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+( timeout 600 python -m pytest tests -m gpu -q -x -k "search or topk or retriev" ) 2>&1 | tail -2
+timeout 120 ./scratch/tk_probe 1000 | head -2
+timeout 120 ./scratch/tk_probe 300 | head -2
+timeout 300 python bench_eval.py --what search --iters 8 --k 1000 2>&1 | tail -1 | cut -c1-330
+timeout 300 python bench_eval.py --what search --iters 8 2>&1 | tail -1 | cut -c1-330
