@@ -782,18 +782,8 @@ __device__ __forceinline__ void tk_merge_count(float* sv, long long* si, int k, 
   __syncthreads();
 }
 
-template <bool COUNTING>  // the 12 KB kernel (k <= 256, <= 1024 slots) merges by counting; the 48 KB one sorts
-__device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cnt, int tid) {
-  if (COUNTING) {
-    if (k + cnt <= 256) return tk_merge_count<1>(sv, si, k, cnt, tid);
-    if (k + cnt <= 512) return tk_merge_count<2>(sv, si, k, cnt, tid);
-    return tk_merge_count<4>(sv, si, k, cnt, tid);
-  }
-  // bitonic sort of everything (padded to a power of two P) best-first
-  int P = 64;
-  while (P < k + cnt) P <<= 1;
-  for (int i = k + cnt + tid; i < P; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
-  __syncthreads();
+// bitonic network over P slots (a power of two, already padded), best-first; ends with a barrier
+__device__ __forceinline__ void tk_bitonic(float* sv, long long* si, int P, int tid) {
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = tid; t < P / 2; t += 256) {
@@ -807,6 +797,21 @@ __device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cn
       __syncthreads();
     }
   }
+}
+
+template <bool COUNTING>  // the 12 KB kernel (k <= 256, <= 1024 slots) merges by counting; the 48 KB one sorts
+__device__ __forceinline__ void tk_flush(float* sv, long long* si, int k, int cnt, int tid) {
+  if (COUNTING) {
+    if (k + cnt <= 256) return tk_merge_count<1>(sv, si, k, cnt, tid);
+    if (k + cnt <= 512) return tk_merge_count<2>(sv, si, k, cnt, tid);
+    return tk_merge_count<4>(sv, si, k, cnt, tid);
+  }
+  // bitonic sort of everything (padded to a power of two P) best-first
+  int P = 64;
+  while (P < k + cnt) P <<= 1;
+  for (int i = k + cnt + tid; i < P; i += 256) { sv[i] = -INFINITY; si[i] = 0x7fffffffffffffffLL; }
+  __syncthreads();
+  tk_bitonic(sv, si, P, tid);
 }
 
 #ifdef TK_TIMING  // scratch/tk_probe.hip: per-workgroup time (10 ns ticks) spent in each part of the kernel, thread 0's view
@@ -827,8 +832,8 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
   constexpr int TK_CAP = TK_P - TK_KM;
   constexpr int TK_FOLD_AT = TK_CAP - 512 < 384 ? TK_CAP - 512 : 384;  // a fold appends up to 512 values
   // candidate lists up to TK_NSORT entries are merged by counting, longer ones streamed through the buffer
-  constexpr int TK_NSORT = TK_P <= 1024 ? 256 : 512;
-  static_assert(TK_KM + TK_NSORT <= 6 * 256 && TK_KM + TK_NSORT <= TK_P && TK_KM + 257 <= TK_P, "scratch areas behind the state");
+  constexpr int TK_NSORT = TK_P <= 1024 ? 256 : 2048;
+  static_assert(TK_KM + TK_NSORT <= TK_P && TK_KM + 257 <= TK_P, "scratch areas behind the state");
   __shared__ float sv[TK_P];
   __shared__ long long si[TK_P];
   __shared__ int s_cnt, s_win2[2];  // window counters alternate: the reset of one never races the adds into the other
@@ -844,22 +849,51 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
   }
   if (tid == 0) { s_cnt = 0; s_win2[0] = 0; s_win2[1] = 0; }
   if (p.cnt != nullptr && ncols <= TK_NSORT) {
-    // A warm chunk leaves a row a handful of candidates (~k * chunk / columns seen): no sort.  The state is sorted, so the final
-    // position of every entry is a count (tk_merge_count): two barriers instead of ~40, every candidate read once per thread.
+    // A warm chunk leaves a row a short candidate list (~k * chunk / columns seen): no pass over a score matrix, no sort of the state.
     for (int i = tid; i < ncols; i += 256) {
       sv[k + i] = Srow[i];
       si[k + i] = p.col_offset + Jrow[i];
     }
-    __syncthreads();
-    if (tid == 0) p.cnt[row] = 0;
-    const int n = k + ncols;
-    if (n <= 256) tk_merge_count<1>(sv, si, k, ncols, tid);
-    else if (n <= 512) tk_merge_count<2>(sv, si, k, ncols, tid);
-    else if (n <= 1024) tk_merge_count<4>(sv, si, k, ncols, tid);
-    else tk_merge_count<6>(sv, si, k, ncols, tid);
-    for (int i = tid; i < k; i += 256) {
-      p.vals[(size_t)row * k + i] = sv[i];
-      p.idx[(size_t)row * k + i] = si[i] == 0x7fffffffffffffffLL ? -1 : (int64_t)si[i];
+    if constexpr (TK_P <= 1024) {
+      // k <= 256, <= 256 candidates: every entry's final position is a count (tk_merge_count): two barriers
+      __syncthreads();
+      if (tid == 0) p.cnt[row] = 0;
+      const int n = k + ncols;
+      if (n <= 256) tk_merge_count<1>(sv, si, k, ncols, tid);
+      else tk_merge_count<2>(sv, si, k, ncols, tid);
+      for (int i = tid; i < k; i += 256) {
+        p.vals[(size_t)row * k + i] = sv[i];
+        p.idx[(size_t)row * k + i] = si[i] == 0x7fffffffffffffffLL ? -1 : (int64_t)si[i];
+      }
+    } else {
+      // k up to 1024, up to 2048 candidates: counting would cost (k + m) * m compares.  Sort the candidates alone (bitonic over the
+      // next power of two), then merge two sorted lists by bisection: a candidate lands at (its index) + (state entries ahead of
+      // it), a state entry at (its index) + (candidates ahead of it); results go straight to HBM.
+      int Pm = 64;
+      while (Pm < ncols) Pm <<= 1;
+      for (int i = ncols + tid; i < Pm; i += 256) { sv[k + i] = -INFINITY; si[k + i] = 0x7fffffffffffffffLL; }
+      __syncthreads();
+      if (tid == 0) p.cnt[row] = 0;
+      float* cv = sv + k;
+      long long* ci = si + k;
+      tk_bitonic(cv, ci, Pm, tid);
+      for (int e = tid; e < k + ncols; e += 256) {
+        const bool is_state = e < k;
+        const float v = sv[e];
+        const long long id = si[e];
+        const float* ov = is_state ? cv : sv;       // the OTHER sorted list
+        const long long* oi = is_state ? ci : si;
+        int lo = 0, hi = is_state ? ncols : k;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (tk_before(ov[mid], oi[mid], v, id)) lo = mid + 1; else hi = mid;
+        }
+        const int r = (is_state ? e : e - k) + lo;
+        if (r < k) {
+          p.vals[(size_t)row * k + r] = v;
+          p.idx[(size_t)row * k + r] = id == 0x7fffffffffffffffLL ? -1 : (int64_t)id;
+        }
+      }
     }
     return;
   }
