@@ -136,6 +136,8 @@ class HotPathStep:
                         self.gscale, 1.0, P(self.go), P(self.row_loss), P(self.row_lse), P(self.loss_sum), P(self.G), P(self.dQ),
                         P(self.dC), ws, wsb, st)
         self.a_sim = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, None, ws, wsb, st)
+        self.c_step = (self._prepared(self.lib.dprhot_inbatch_step_packed_f32, self.a_pstep) if self.packed_step
+                       else self._prepared(self.lib.dprhot_inbatch_step_f32, self.a_step))
         # no-logits shapes (large B x Nc: the workspace then holds no logit buffer): softmax_finish only derives logsumexp / loss
         # from the strip statistics, the dScores come from a third launch that recomputes the logits (dprhot_dscores)
         self.nl = self.ws_bytes < 4 * B * Nc
@@ -150,6 +152,24 @@ class HotPathStep:
         rc = fn(*args)
         if rc:
             self._lib.check(rc, fn.__name__)
+
+    def _prepared(self, fn, args):
+        """The argument block converted ONCE into ctypes instances of the prototype's types, and the same symbol through a handle
+        without argtypes (instances pass as they are).  ctypes spends ~3 us per call converting 24 Python objects otherwise -- a
+        third of the cfg2 step, which is two kernel launches long; a C or C++ caller of the ABI never pays that."""
+        if not hasattr(HotPathStep, "_raw"):
+            HotPathStep._raw = ctypes.CDLL(self._lib.LIB_PATH)
+        raw = getattr(HotPathStep._raw, fn.__name__)
+        raw.restype = ctypes.c_int
+        assert len(fn.argtypes) == len(args), fn.__name__
+        conv = tuple(t(v.value if isinstance(v, ctypes._SimpleCData) else v) for t, v in zip(fn.argtypes, args))
+        name = fn.__name__
+
+        def call():
+            rc = raw(*conv)
+            if rc:
+                self._lib.check(rc, name)
+        return call
 
     # the launches of one step
     def k_prep(self):
@@ -186,10 +206,7 @@ class HotPathStep:
         self._call(self.lib.dprhot_sim_rank, self.a_rank)
 
     def k_step(self):
-        if self.packed_step:
-            self._call(self.lib.dprhot_inbatch_step_packed_f32, self.a_pstep)
-        else:
-            self._call(self.lib.dprhot_inbatch_step_f32, self.a_step)
+        self.c_step()
 
     def step(self):
         # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
