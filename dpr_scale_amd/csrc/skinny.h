@@ -96,7 +96,7 @@ inline size_t sk_sim_lds() { return (size_t)SK_ASTAGE * 2 + (size_t)SK_SLOTS * S
 
 // A_F32: q is fp32 (rounded to bf16 right after the loads land; the ct == 0 units also write the bf16 rows to Qb).
 // NCH = d / 64 (compile-time: the q rows of the unit live in registers, one 16-byte bf16 chunk per thread and k chunk).
-// LDS = 72 KiB -> two workgroups per CU: all units of cfg3 per rank (4 x 65 = 260) are resident at once, and one
+// LDS = 72 KiB -> two workgroups per CU: all units of cfg3 per rank (4 x 64 = 256 with tiles_per_rank, else 260) are resident at once, and one
 // workgroup's MFMA / epilogue overlaps the other's loads.
 // COLS = columns of a unit (128 with SLOTS = 4 ring slots, or 64 with 8): every wave multiplies COLS / 4 of them.
 template <int NCH, bool A_F32, int COLS = SK_COLS, int SLOTS = SK_SLOTS>
