@@ -392,6 +392,7 @@ SkPlan sk_plan(int B, int Nc, int d) {
   }
   p.nts = cdiv(Nc, p.scols);  // statistics tiles = sim units per row block
   p.nrb = cdiv(B, SK_ROWS);
+  if (!p.ok) return p;  // (also keeps d < 64 away from the division below: every entry point derives this plan for its workspace layout)
   const int nk = cdiv(Nc, 64), ndt = d / SK_QN;
   int ns = kNumCU / 2 / ndt;  // dQ units: (slice of contexts) x (64 columns of d); ~half a unit per CU measured best: the
   if (ns < 1) ns = 1;         // units run next to the dC units, and fewer slices mean fewer partial sums to write and re-read

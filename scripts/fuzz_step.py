@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Randomised check of the training step (hotpath.inbatch_contrastive_loss, forward + backward through autograd) against the
+reference's formulation in torch ops (dpr_task.py:197-212 on the bf16-rounded embeddings, fp32 math): shapes on both sides of every
+plan boundary (fused small step, skinny step, wide vectors, no-logits forward, phase-interleaved backward), ragged sizes, masks,
+temperatures.  Bars as in tests/test_gpu_parity.py: loss <= 1e-3 relative, gradients <= 1e-2 of their maximum.  Run on an MI355X box."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpr_scale_amd.hotpath import inbatch_contrastive_loss  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(a.seed)
+
+    def pick(pool):
+        return pool[int(torch.randint(0, len(pool), (1,), generator=g))]
+
+    Bs = [1, 3, 8, 31, 32, 33, 64, 100, 128, 129, 256, 300, 512, 1024, 2048]
+    Ks = [1, 2, 3, 8, 9, 16, 33, 64]
+    ds = [8, 64, 80, 128, 256, 768, 1024, 1032, 4096]
+    bad, worst = 0, (0.0, 0.0, 0.0)
+    for case in range(a.cases):
+        B, K, d = pick(Bs), pick(Ks), pick(ds)
+        if B * K > 32768 or B * B * K > (1 << 27) or B * K * d > (1 << 27):
+            continue
+        T = float(pick([0.05, 0.3, 1.0, 2.0]))
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(f"case {case}: B={B} K={K} d={d} T={T}", flush=True)
+        n = B * K
+        q = (torch.randn(B, d, generator=g) * d ** -0.25).to(dev)
+        c = (torch.randn(n, d, generator=g) * d ** -0.25).to(dev)
+        y = (torch.arange(B) * K + torch.randint(0, K, (B,), generator=g)).to(dev)
+        m = (torch.rand(n, generator=g) < pick([0.0, 0.05, 0.3])).to(dev)
+        m[y] = False
+        q1, c1 = q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        loss = inbatch_contrastive_loss(q1, c1, y, m, T, False)
+        loss.backward()
+        qb = q.to(torch.bfloat16).float().requires_grad_(True)
+        cb = c.to(torch.bfloat16).float().requires_grad_(True)
+        S = (qb @ cb.t()).masked_fill(m[None, :], float("-inf")) / T
+        ref = torch.nn.functional.cross_entropy(S, y)
+        ref.backward()
+        el = abs(loss.item() - ref.item()) / max(abs(ref.item()), 1e-6)
+        eq = ((q1.grad - qb.grad).abs().max() / qb.grad.abs().max().clamp_min(1e-30)).item()
+        ec = ((c1.grad - cb.grad).abs().max() / cb.grad.abs().max().clamp_min(1e-30)).item()
+        worst = (max(worst[0], el), max(worst[1], eq), max(worst[2], ec))
+        if not (el <= 1e-3 and eq <= 1e-2 and ec <= 1e-2) or not torch.isfinite(loss):
+            bad += 1
+            print(f"MISMATCH case {case}: B={B} K={K} d={d} T={T}: loss rel {el:.2e}, dQ {eq:.2e}, dC {ec:.2e}")
+    print(f"fuzz_step: {a.cases} cases, {bad} outside the bars; worst loss rel {worst[0]:.2e}, dQ {worst[1]:.2e}, dC {worst[2]:.2e} (of max)")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

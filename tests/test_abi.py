@@ -87,3 +87,21 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         sys.modules.pop("dpr_scale_amd._lib", None)
         if saved is not None:
             sys.modules["dpr_scale_amd._lib"] = saved
+
+def test_plans_are_total_functions_of_the_shape():
+    """Every entry point derives its plans (tiles, splits, workspace layout) from (B, Nc, d) on the host before anything is launched:
+    they must be defined for EVERY accepted shape -- a hidden size below 64 once divided by zero inside the skinny-step plan that
+    the workspace layout consults for all shapes (caught by scripts/fuzz_step.py on the GPU; reproduced here without one)."""
+    import itertools
+
+    from dpr_scale_amd import _lib
+
+    n = 0
+    for B, Nc, d in itertools.product([1, 8, 32, 33, 64, 128, 129, 300, 1024, 8192],
+                                      [8, 64, 256, 1152, 2048, 2112, 4800, 8256, 65536],
+                                      [8, 16, 24, 56, 64, 80, 128, 768, 1024, 4096, 30528]):
+        assert _lib.workspace_bytes(B, Nc, d) > 0
+        n += 1
+    assert n == 990
+    for nq, chunk in itertools.product([1, 7, 1024], [8, 1024, 65536]):
+        assert _lib.search_workspace_bytes(nq, chunk) >= nq * chunk * 8
