@@ -16,6 +16,8 @@ Cases (SURVEY.md section 8 notation, BASELINE.json configs):
   cfg5  W8 B64 K2 d1024       global step, summaries             (configs[4])
   w2/w4 real 2-/4-rank gloo DDP-branch runs (per-rank loss, q.grad, c.grad)
   ties / nib / topk           rank metrics with ties, in_batch_negatives=False branch, top-k
+  router_*                    CITADEL router loss (citadel_task.py:137-153, :240-262) at d = 30522, both sim_score modes
+  router_gather_w2            citadel_task.py:97-135 distributed_gather on 2 real gloo ranks, ragged token lengths
 """
 import json
 import os
@@ -112,8 +114,72 @@ def run_ddp(W, seed, B, K, d, distn, ragged, T, port):
             np.stack([r[2] for r in res]), np.stack([r[3] for r in res]))
 
 
+def _gather_worker(rank, W, port, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from oracle.router_oracle import synth_gather_rank
+
+    qr, cr, mask, pos, teacher = synth_gather_rank(seed, rank)
+    t = lambda d: {k: torch.from_numpy(v).requires_grad_(True) for k, v in d.items()}
+    oq, oc, om, op, ot = ref_shim.reference_distributed_gather(
+        t(qr), t(cr), torch.from_numpy(mask), torch.from_numpy(pos), torch.from_numpy(teacher), rank)
+    q.put((rank, {k: v.detach().numpy() for k, v in oq.items()}, {k: v.detach().numpy() for k, v in oc.items()},
+           om.numpy(), op.numpy(), ot.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def router_fixtures():
+    """f4: /root/reference/dpr_scale/task/citadel_task.py (MultiVecRetrieverTask, unmodified) on seeded router-shaped inputs.
+    dq / dc are [16, 30522] / [64, 30522]: stored as every 31st column plus full row and column sums."""
+    from oracle.router_oracle import ROUTER_D, synth_router
+
+    B, M, d, tau, seed, stride = 16, 4, ROUTER_D, 1.5, SEED0 + 500, 31
+    q, c, mask, pos, teacher = synth_router(seed, B, M, d)
+    t = torch.from_numpy
+    S_dense = ref_shim.reference_citadel_sim_score(t(q), t(c), t(mask), False).numpy()
+    S_pair = ref_shim.reference_citadel_sim_score(t(q), t(c), t(mask), True).numpy()
+    for name, in_batch, coef in [("router_inbatch", True, 0.0), ("router_pairwise", False, 0.0),
+                                 ("router_teacher", True, 0.5), ("router_teacher_only", False, 1.0)]:
+        if not wanted(name):
+            continue
+        loss, dq, dc, logged = ref_shim.reference_router_loss(t(q), t(c), t(mask), t(pos), t(teacher), in_batch, coef, tau)
+        assert float(logged["train_router_loss"].detach()) == loss.item()
+        dq, dc = dq.numpy(), dc.numpy()
+        meta = dict(case=name, B=B, M=M, d=d, seed=seed, tau=tau, in_batch=in_batch, teacher_coef=coef, col_stride=stride,
+                    source="reference citadel_task.py MultiVecRetrieverTask.router_loss / sim_score, fp32 CPU; inputs = "
+                           "oracle.router_oracle.synth_router(seed, B, M, d)")
+        save(name, meta, loss=np.float32(loss.item()), S_dense=S_dense, S_pair=S_pair,
+             dq_cols=dq[:, ::stride].copy(), dc_cols=dc[:, ::stride].copy(),
+             dq_rowsum=dq.astype(np.float64).sum(1), dc_rowsum=dc.astype(np.float64).sum(1),
+             dq_colsum=dq.astype(np.float64).sum(0).astype(np.float32), dc_colsum=dc.astype(np.float64).sum(0).astype(np.float32))
+    if wanted("router_gather_w2"):
+        W, seed = 2, SEED0 + 600
+        ctx = mp.get_context("spawn")
+        qq = ctx.Queue()
+        procs = [ctx.Process(target=_gather_worker, args=(r, W, 29614, seed, qq)) for r in range(W)]
+        for p in procs:
+            p.start()
+        res = sorted([qq.get(timeout=300) for _ in range(W)], key=lambda x: x[0])
+        for p in procs:
+            p.join()
+        arrays = {}
+        for r, oq, oc, om, op, ot in res:
+            for k, v in oq.items():
+                arrays[f"r{r}_q_{k}"] = v
+            for k, v in oc.items():
+                arrays[f"r{r}_c_{k}"] = v
+            arrays[f"r{r}_mask"], arrays[f"r{r}_pos"], arrays[f"r{r}_teacher"] = om, op, ot
+        save("router_gather_w2", dict(case="router_gather_w2", W=W, seed=seed,
+                                      source="reference citadel_task.py distributed_gather on 2 gloo ranks (PL 1.6.4 all_gather "
+                                             "shim); inputs = oracle.router_oracle.synth_gather_rank(seed, rank)"), **arrays)
+
+
 def main():
     assert ref_shim.reference_available(), "needs /root/reference"
+    router_fixtures()
     torch.manual_seed(0)
     torch.set_num_threads(8)
 

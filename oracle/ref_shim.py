@@ -66,6 +66,8 @@ def _install_stubs():
 
             def one(t):
                 with torch.no_grad():
+                    if not isinstance(t, torch.Tensor):  # PL 1.6.4 convert_to_tensors: python numbers become tensors
+                        t = torch.tensor(t)             # (citadel_task.py:87 gathers a python int)
                     t = t.contiguous()
                     out = [torch.zeros_like(t) for _ in range(world)]
                     dist.all_gather(out, t)
@@ -144,3 +146,46 @@ def reference_sim_score(Q, C, mask_cols=None):
 def reference_rank_metrics(S, labels, k=1):
     task = make_reference_task(False, k=k)
     return task.compute_rank_metrics(S, labels)
+
+
+# ---- the CITADEL router loss, from the reference's own citadel_task.py ------------------------
+def load_reference_citadel_class():
+    """Import MultiVecRetrieverTask from /root/reference/dpr_scale/task/citadel_task.py, unmodified (it imports only torch,
+    the pytorch_lightning.strategies markers and dpr_task -- citadel_task.py:4-6 -- so the same three stubs suffice)."""
+    load_reference_task_class()
+    from dpr_scale.task.citadel_task import MultiVecRetrieverTask  # noqa: E402  (the reference's file)
+
+    assert os.path.realpath(sys.modules["dpr_scale.task.citadel_task"].__file__).startswith(
+        os.path.realpath(REFERENCE_ROOT)), "citadel_task resolved to something other than the reference tree"
+    return MultiVecRetrieverTask
+
+
+def make_reference_citadel_task(in_batch=True, teacher_coef=0.0, tau=1.0, distributed=False, rank=0):
+    cls = load_reference_citadel_class()
+    from pytorch_lightning.strategies import DDPStrategy
+
+    task = cls(in_batch=in_batch, teacher_coef=teacher_coef, tau=tau, transform=None, model=None, datamodule=None, optim=None)
+    task.trainer = SimpleNamespace(strategy=DDPStrategy() if distributed else object(), max_epochs=1)
+    task.global_rank = rank
+    return task
+
+
+def reference_citadel_sim_score(q, c, mask, pairwise):
+    """citadel_task.py:137-153, verbatim (note: the pairwise branch dereferences mask before its None check, :141)."""
+    return make_reference_citadel_task().sim_score(q, c, mask, pairwise=pairwise)
+
+
+def reference_router_loss(q, c, mask, pos, teacher, in_batch=True, teacher_coef=0.0, tau=1.0):
+    """citadel_task.py:249-262 + backward on {"router_repr": q} / {"router_repr": c}.  Returns (loss, dq, dc, logged)."""
+    task = make_reference_citadel_task(in_batch, teacher_coef, tau)
+    tq = q.clone().requires_grad_(True)
+    tc = c.clone().requires_grad_(True)
+    loss = task.router_loss({"router_repr": tq}, {"router_repr": tc}, mask.clone(), pos.clone(), teacher.clone())
+    loss.backward()
+    return loss.detach(), tq.grad.detach(), tc.grad.detach(), dict(task.logged)
+
+
+def reference_distributed_gather(query_repr, context_repr, mask, pos, teacher, rank):
+    """citadel_task.py:97-135 on the calling gloo rank (an initialised process group is required)."""
+    task = make_reference_citadel_task(distributed=True, rank=rank)
+    return task.distributed_gather(query_repr, context_repr, mask, pos, teacher)

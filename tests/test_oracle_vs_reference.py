@@ -49,3 +49,21 @@ def test_reference_under_bf16_autocast_informational():
     print(f"autocast(bf16) vs fp32 reference: loss rel {e_loss:.2e}, dQ rel-to-max {e_dq:.2e}, dC rel-to-max {e_dc:.2e}")
     assert e_loss <= 2e-2 and e_dq <= 1e-1 and e_dc <= 1e-1   # bf16 logits: ~1e-3 .. 1e-2, an order above the HIP path's deviation
     assert e_loss > 0 or e_dq > 0  # it IS a different computation
+
+
+@pytest.mark.parametrize("in_batch,teacher_coef", [(True, 0.0), (False, 0.0), (True, 0.3), (False, 1.0)])
+def test_router_restatement_equals_the_live_citadel_task(in_batch, teacher_coef):
+    """oracle/router_oracle.py against /root/reference/dpr_scale/task/citadel_task.py run live."""
+    from oracle import router_oracle as R
+
+    q, c, mask, pos, teacher = R.synth_router(41, 6, 4, 1000)
+    t = torch.from_numpy
+    loss, dq, dc, logged = ref_shim.reference_router_loss(t(q), t(c), t(mask), t(pos), t(teacher), in_batch, teacher_coef, 2.0)
+    l2, dq2, dc2 = R.router_step(q, c, mask, pos, teacher, in_batch, teacher_coef, 2.0)
+    assert abs(l2 - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
+    assert rel(dq2, dq.numpy()) <= 2e-6 and rel(dc2, dc.numpy()) <= 2e-6
+    for pairwise in (False, True):
+        S = ref_shim.reference_citadel_sim_score(t(q), t(c), t(mask), pairwise).numpy()
+        So = R.sim_score(t(q).double(), t(c).double(), t(mask), pairwise).numpy()
+        fin = np.isfinite(S)
+        assert np.array_equal(fin, np.isfinite(So)) and rel(So[fin], S[fin]) <= 2e-6
