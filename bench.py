@@ -51,14 +51,33 @@ def parse():
     ap.add_argument("--negatives", type=int, default=7)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--temperature", type=float, default=1.0)
-    ap.add_argument("--driver", choices=["auto", "graph", "graph10", "eager"], default="auto")
+    ap.add_argument("--driver", choices=["auto", "graph", "graph10", "eager"], default="eager",
+                    help="issue mechanism behind `value`: eager (default) = one C-ABI call per step, what a binding and the Lightning "
+                         "task do; graph / graph10 = HIP graphs of 1 / 10 steps; auto = the fastest of the three.  The mechanisms not "
+                         "chosen are measured too and reported in other_driver")
+    ap.add_argument("--only", default="", help="comma list of the extra blocks to run (default: all): operator, torch_gpu, scale, rank, "
+                                               "router, grad_hook, cpu, e2e; `step` = none of them (the contract line alone)")
     ap.add_argument("--no-scale-roofline", action="store_true", help="skip the extra 8192x8192 per-kernel roofline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=31, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--e2e", action="store_true", help="(default on; kept for compatibility)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the short end-to-end (bert-base towers) block")
     ap.add_argument("--no-rank-roofline", action="store_true", help="skip the cfg3-per-rank (128 x 8256 x 768) block")
-    return ap.parse_args()
+    a = ap.parse_args()
+    blocks = {"operator", "torch_gpu", "scale", "rank", "router", "grad_hook", "cpu", "e2e"}
+    if a.only:
+        want = {x.strip() for x in a.only.split(",") if x.strip()}
+        unknown = want - blocks - {"step"}
+        if unknown:
+            ap.error(f"--only: unknown block(s) {sorted(unknown)}")
+        a.blocks = want & blocks
+    else:
+        a.blocks = set(blocks)
+    for flag, names in (("no_scale_roofline", ("scale",)), ("no_cpu_baseline", ("cpu",)), ("no_e2e", ("e2e",)),
+                        ("no_rank_roofline", ("rank", "router"))):
+        if getattr(a, flag):
+            a.blocks -= set(names)
+    return a
 
 
 def P(t):
@@ -288,7 +307,8 @@ def cpu_baseline(B, K, d, T, budget_s=10.0):
         n += 1
     el = time.perf_counter() - t0
     return {"value": B * n / el, "unit": "query-passage pairs/s", "cores": int(lib.oracle_num_threads()), "kind": "port",
-            "sample": f"{n} steps of the same B={B} K={K} d={d} workload in {el:.1f} s (oracle/inbatch_oracle.c, OpenMP)"}
+            "formulation": "plain-C restatement of the step (oracle/inbatch_oracle.c, OpenMP)",
+            "sample": f"{n} steps of the same B={B} K={K} d={d} workload in {el:.1f} s"}
 
 
 def cpu_baseline_reference(B, K, d, T, budget_s=6.0):
@@ -300,16 +320,180 @@ def cpu_baseline_reference(B, K, d, T, budget_s=6.0):
 
     q, c, y, m = synth_embeddings(1234, B, K, d, "U", False)
     best = None
-    for nth in sorted({min(8, torch.get_num_threads()), torch.get_num_threads()}):  # 8 threads; and the box default
+    for nth in (min(8, torch.get_num_threads()),):  # 8 host threads, stated in `cores`
         torch.set_num_threads(nth)
         med, n = time_reference_step(q, c, y, m, T, budget_s=budget_s / 2)
         if best is None or med < best[0]:
             best = (med, n, nth)
     med, n, nth = best
-    return {"value": B / med, "unit": "query-passage pairs/s", "cores": nth, "kind": "port",
-            "formulation": "reference ops in torch (CPU, fp32): matmul, masked fill, /T, CrossEntropyLoss, autograd backward",
+    return {"value": B / med, "unit": "query-passage pairs/s", "cores": nth, "kind": "reference-ops",
+            "formulation": "the reference's own ops in its own library (torch CPU, fp32), dpr_task.py:197-212 line by line: mask.repeat, "
+                           "matmul, masked fill, /T, CrossEntropyLoss, autograd backward (oracle/torch_steps.py, pinned to the reference's "
+                           "fixtures bit for bit; /root/reference itself does not exist on the GPU box)",
             "sample": f"median of {n} steps of the same B={B} K={K} d={d} workload ({med * 1e3:.3f} ms/step, torch {torch.__version__}, "
                       f"{nth} threads)"}
+
+
+def _event_us(run, iters):
+    """Average microseconds per call of `run`, HIP events on the current stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def _graph_of(fn, repeat):
+    """`repeat` calls of fn captured into one HIP graph through torch (allocations inside come from the graph's pool)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(repeat):
+            fn()
+    return g
+
+
+def _time_python_step(fn, reps=10, iters=30):
+    """(graph_us, eager_us) per call of a Python-level step: replayed from a HIP graph holding `reps` calls (device time, the host
+    out of the picture) and issued eagerly (what a training loop pays when nothing else hides the host)."""
+    for _ in range(5):
+        fn()
+    eager = _event_us(fn, iters * 4)
+    try:
+        g = _graph_of(fn, reps)
+        for _ in range(3):
+            g.replay()
+        graph = _event_us(g.replay, iters) / reps
+    except Exception as e:  # a step that cannot be captured is reported as such, never hidden
+        graph = None
+        sys.stderr.write(f"bench.py: graph capture failed: {e!r}\n")
+    return graph, eager
+
+
+def operator_block(dev, d=768):
+    """What TRAINING runs (dpr_task.py:153-214 under AMP): hotpath.inbatch_contrastive_loss forward + (loss * 1024).backward() --
+    the autograd operator with a non-unit grad_output -- next to the bare C-ABI step of the same shape, at cfg2 (B 32 x 256 contexts)
+    and at the cfg3-per-rank shape (B 128 x 8192 contexts).  HIP events; `graph` = ten steps per HIP graph (device time), `eager` =
+    one Python call per step (host-bound at these sizes)."""
+    from dpr_scale_amd import hotpath
+    from dpr_scale_amd.datamodule.synthetic import unit_logit_embeddings
+
+    out = {"what": "autograd operator forward + backward with grad_output = 1024 (as under AMP) vs the C-ABI step alone; us per step"}
+    for name, B, K in (("cfg2", 32, 8), ("cfg3_rank_shape", 128, 64)):
+        q, c, y, m = unit_logit_embeddings(1234, B, K, d)
+        tq = torch.from_numpy(q).to(dev).requires_grad_(True)
+        tc = torch.from_numpy(c).to(dev).requires_grad_(True)
+        ty, tm = torch.from_numpy(y).to(dev), torch.from_numpy(m).to(dev)
+        scale = torch.full((), 1024.0, device=dev)
+
+        def op_step():
+            tq.grad = None
+            tc.grad = None
+            loss = hotpath.inbatch_contrastive_loss(tq, tc, ty, tm, 1.0)
+            loss.backward(scale)
+
+        g_us, e_us = _time_python_step(op_step)
+        hp = HotPathStep(B, K, d, 1.0, 1, 0, dev)
+        abi = time_kernel(hp, hp.k_step, reps=10, iters=30)
+        out[name] = {"shape": f"B={B} x Nc={B * K} x d={d}", "operator_graph_us": None if g_us is None else round(g_us, 2),
+                     "operator_eager_us": round(e_us, 2), "c_abi_step_us": round(abi, 2),
+                     "operator_minus_c_abi_us": None if g_us is None else round(g_us - abi, 2),
+                     "operator_over_c_abi": None if g_us is None else round(g_us / abi, 3)}
+        del hp
+    torch.cuda.empty_cache()
+    return out
+
+
+def torch_gpu_block(dev, d=768):
+    """Context, never `value`: the reference's formulation of the hot path ALONE (dpr_task.py:197-212 + autograd backward) in torch
+    ops on this same MI355X -- fp32 as written, and under torch.autocast(bf16) as its AMP recipes run it -- at cfg2 and at
+    128 x 8192.  Same timing as operator_block."""
+    from dpr_scale_amd.datamodule.synthetic import unit_logit_embeddings
+
+    out = {"what": "reference ops (mask.repeat, matmul, masked fill, /T, CrossEntropyLoss, backward with grad_output = 1024) in torch on "
+                   "this GPU; us per step"}
+    for name, B, K in (("cfg2", 32, 8), ("cfg3_rank_shape", 128, 64)):
+        q, c, y, m = unit_logit_embeddings(1234, B, K, d)
+        tq = torch.from_numpy(q).to(dev).requires_grad_(True)
+        tc = torch.from_numpy(c).to(dev).requires_grad_(True)
+        ty, tm = torch.from_numpy(y).to(dev), torch.from_numpy(m).to(dev)
+        scale = torch.full((), 1024.0, device=dev)
+        loss_fn = torch.nn.CrossEntropyLoss()
+        res = {"shape": f"B={B} x Nc={B * K} x d={d}"}
+        for tag, amp in (("fp32", False), ("autocast_bf16", True)):
+            def ref_step():
+                tq.grad = None
+                tc.grad = None
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                    mask = tm.repeat(tq.size(0), 1)
+                    scores = torch.matmul(tq, torch.transpose(tc, 0, 1))
+                    scores[mask] = float("-inf")
+                    scores /= 1.0
+                    loss = loss_fn(scores, ty)
+                loss.backward(scale)
+
+            g_us, e_us = _time_python_step(ref_step)
+            res[tag] = {"graph_us": None if g_us is None else round(g_us, 2), "eager_us": round(e_us, 2)}
+        out[name] = res
+    torch.cuda.empty_cache()
+    return out
+
+
+def grad_hook_block(dev, n=110_000_000, W=8):
+    """the three local legs of the towers' gradient all-reduce (dpr_scale_amd/comm_hooks.py; reference hook
+    dpr_task.py:90-92) on one bert-base tower's gradients (110 M fp32 elements = one tower in one bucket), as rank 0 of an 8-rank
+    node would run them: pack (fp32 -> wire, x 1/W), sum of the W received shards (fp32 accumulation), unpack (wire -> fp32).  The
+    exchange itself needs W GPUs and is not timed here.  HBM roofline against 8 TB/s."""
+    from dpr_scale_amd import comm_hooks
+
+    legs = comm_hooks._HipLegs()
+    out = {"workload": f"{n} fp32 gradient elements, W = {W} (shard = n / W), legs on one GPU; exchange not included",
+           "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    buf = torch.randn(n, device=dev)
+    shard = ((n + W - 1) // W + 7) // 8 * 8
+    npad = shard * W
+    for wire in (torch.float16, torch.bfloat16):
+        send = torch.empty(npad, dtype=wire, device=dev)
+        recv = torch.empty(npad, dtype=wire, device=dev)
+        legs.pack(buf, 1.0 / W, send)
+        recv.copy_(send)
+        mine = torch.empty(shard, dtype=wire, device=dev)
+        full = torch.empty(npad, dtype=wire, device=dev)
+        es = wire.itemsize
+        rows = (("pack", lambda: legs.pack(buf, 1.0 / W, send), 4.0 * n + es * npad),
+                ("sum_shards", lambda: legs.sum_shards(recv, W, mine), es * npad + es * shard),
+                ("unpack", lambda: legs.unpack(full, buf), es * n + 4.0 * n))
+        res = {}
+        for name, fn, by in rows:
+            for _ in range(3):
+                fn()
+            us = _event_us(fn, 20)
+            res[name] = {"us": round(us, 1), "achieved": round(by / us * 1e-3, 1), "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 4)}
+        res["legs_total_us"] = round(sum(v["us"] for v in res.values()), 1)
+        # the torch formulation these kernels replaced (round 2's comm_hooks): buf / W -> .to(wire); view.float().sum(0).to(); copy back
+        def torch_legs():
+            s2 = (buf / W).to(wire)
+            m2 = recv.view(W, shard).float().sum(dim=0).to(wire)
+            buf.copy_(full[:n])
+            return s2, m2
+        for _ in range(2):
+            torch_legs()
+        res["torch_ops_total_us"] = round(_event_us(torch_legs, 5), 1)
+        out[str(wire).replace("torch.", "")] = res
+        del send, recv, mine, full
+    del buf
+    torch.cuda.empty_cache()
+    return out
+
 
 
 def roofline_router(dev, B=128, K=8, d=30528):
@@ -357,9 +541,14 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
            "algorithmic_bytes": algo, "achieved": round(algo / us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(algo / us * 1e-3 / HBM_PEAK_GBS, 4), "flops": 6 * bn * d,
            "mfma_frac": round(6 * bn * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
-    kfile = os.path.join(ROOT, "profiles", "r02_cfg3rank_kernel_stats.csv")
-    if os.path.isfile(kfile):
-        out["kernel_stats"] = "profiles/r02_cfg3rank_kernel_stats.csv (rocprofv3 --kernel-trace of this very call sequence)"
+    out["traffic"], out["traffic_source"] = None, None
+    tfile = os.path.join(ROOT, "profiles", "cfg3rank_traffic.json")
+    if (B, K, d, W) == (128, 8, 768, 8) and os.path.isfile(tfile):  # PMC bytes of this very call sequence (scripts/gpu_run.sh prof-rank)
+        tj = json.load(open(tfile))
+        out["traffic"] = tj.get("step_hbm_bytes")
+        out["traffic_source"] = f"profiles/cfg3rank_traffic.json ({tj.get('source')}); per kernel: " + ", ".join(
+            f"{k} {v['hbm_bytes_per_launch']}" for k, v in tj.get("kernels", {}).items())
+        out["traffic_over_algorithmic"] = None if not out["traffic"] else round(out["traffic"] / algo, 3)
     del hp
     torch.cuda.empty_cache()
     return out
@@ -547,13 +736,11 @@ def main():
         # training iteration gets, and the only one of the three whose pace does not depend on the host core the process landed on:
         # the eager loop is within 1 us of host-bound and flips between 9.9 and 11.5 us per step from run to run)
         runs = {"eager": (hp.c_step, 1)}  # (hp.step without its Python frames: no collectives at N = 1)
-        if driver in ("auto", "graph"):
-            runs["graph"] = (capture(hp, hp.step), 1)
-        if driver in ("auto", "graph10"):
-            runs["graph10"] = (capture(hp, hp.step, 10), 10)
-        # auto: every mechanism gets the full measurement (W warmup steps, R regions of exactly K steps); the one with the best
-        # median is the line's `value`, the others ride in `other_driver`.  (A short untimed probe mispredicted: the eager loop is
-        # bimodal from region to region.)
+        runs["graph"] = (capture(hp, hp.step), 1)
+        runs["graph10"] = (capture(hp, hp.step, 10), 10)
+        # every mechanism gets the full measurement (W warmup steps, R regions of exactly K steps).  `value` is the one --driver
+        # names: eager by default -- one C-ABI call per step is what a binding and the Lightning task do; the others ride in
+        # `other_driver` (auto = the best median of the three).
         measured = {name: measure(fn, per, hp.step) for name, (fn, per) in runs.items()}
         med = {name: sorted(v)[len(v) // 2] for name, v in measured.items()}
         if driver == "auto":
@@ -616,22 +803,34 @@ def main():
         if torch_coll is not None and comm is not None:  # the same step with torch.distributed's collectives, timed first
             out["torch_distributed_collectives"] = {"ms_per_step": round(torch_coll / a.steps * 1e3, 5),
                                                     "value": round(W * B * a.steps / torch_coll, 1)}
-        if not DM and not a.no_scale_roofline:
+        def extra(key, fn):  # extra information only: a failing block is reported, never fatal
+            try:
+                out[key] = fn()
+            except Exception as e:
+                out[key] = {"error": repr(e)}
+
+        if not DM and "operator" in a.blocks and d % 8 == 0:
+            extra("operator", lambda: operator_block(dev, d))
+        if not DM and "torch_gpu" in a.blocks:
+            extra("torch_gpu_hot_path", lambda: torch_gpu_block(dev, d))
+        if not DM and "grad_hook" in a.blocks:
+            extra("grad_hook", lambda: grad_hook_block(dev))
+        if not DM and "scale" in a.blocks:
             out["roofline_at_scale"] = roofline_at_scale(dev, d)
-        if not DM and not a.no_rank_roofline and d % 128 == 0:
+        if not DM and "rank" in a.blocks and d % 128 == 0:
             try:
                 out["roofline_cfg3_rank"] = roofline_cfg3_rank(dev, d)
             except Exception as e:  # extra info only
                 out["roofline_cfg3_rank"] = {"error": repr(e)}
-        if not DM and not a.no_rank_roofline:
+        if not DM and "router" in a.blocks:
             try:
                 out["router"] = roofline_router(dev)
             except Exception as e:  # extra info only
                 out["router"] = {"error": repr(e)}
-        if not a.no_cpu_baseline and not DM:
-            out["cpu_baseline"] = cpu_baseline(B, K, d, T)
-            out["cpu_baseline_reference"] = cpu_baseline_reference(B, K, d, T)
-    if not a.no_e2e and d == 768 and (W == 1 or backend == "nccl"):
+        if "cpu" in a.blocks and not DM:
+            out["cpu_baseline"] = cpu_baseline_reference(B, K, d, T)   # the faithful one: the reference's ops, 8 threads
+            out["cpu_baseline_port"] = cpu_baseline(B, K, d, T, budget_s=6.0)  # the C restatement on every host thread
+    if "e2e" in a.blocks and d == 768 and (W == 1 or backend == "nccl"):
         # the END-TO-END number of the north star (bert-base towers, seq_len 256): short, extra information, never `value`.
         # A watchdog prints the line without it if the leg does not come back (a rank lost in a collective must not cost
         # the measured line).

@@ -68,6 +68,16 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_pairwise_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dprhot_pairwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dprhot_train_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
+                                      c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_size_t, c_void_p]),
+    "dprhot_train_step_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float,
+                                             c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                             c_void_p, c_size_t, c_void_p]),
+    "dprhot_rescale_grads": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dprhot_grad_pack": (c_int, [c_void_p, c_size_t, c_float, c_int, c_void_p, c_size_t, c_void_p]),
+    "dprhot_grad_sum_shards": (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    "dprhot_grad_unpack": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dprhot_comm_unique_id": (c_int, [c_void_p]),
     "dprhot_comm_init": (c_int, [c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "dprhot_comm_destroy": (c_int, [c_void_p]),

@@ -22,8 +22,11 @@ DDP's own (``bucket_cap_mb`` of the wrapper; ``wrap_ddp`` below exposes it), red
 futures run on RCCL's stream underneath the remaining backward.
 
 ``mode="ring"`` is the reference's decomposition (one all-reduce in the wire dtype) for A/B runs.
-Nothing here is measured on more than one GPU in this round (one-GPU boxes): correctness is covered by the world-size-2
-gloo tests in tests/test_comm_hooks.py; DESIGN.md section 6 models the time on 7 links.
+The three local legs (pack, shard sum, unpack) are HIP kernels behind the C ABI (csrc/gradcomm.h): one pass over HBM each
+instead of torch's five or six elementwise passes.  Nothing here is measured on more than one GPU (one-GPU boxes):
+correctness is covered by the world-size-2 gloo tests in tests/test_comm_hooks.py (CPU buckets, and device buckets of two
+processes sharing the GPU) and a one-rank RCCL group on the GPU; bench.py's `grad_hook` block times the legs; DESIGN.md
+section 6 models the links.
 """
 import os
 
@@ -54,9 +57,72 @@ class GradCommState:
                    os.environ.get("DPRHOT_GRAD_RETURN"))
 
 
+_KIND = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}  # wire kinds of include/dprhot.h
+
+
 def _as_gloo_safe(t):
     """gloo has no bf16: ship the bit patterns in a 2-byte type it knows (exchange / gather only move bytes)."""
     return t.view(torch.float16) if t.dtype == torch.bfloat16 else t
+
+
+class _HipLegs:
+    """The three local legs of the hook on the HIP kernels behind the C ABI (dprhot_grad_pack / _sum_shards / _unpack):
+    one pass over HBM each, on the current stream.  Device buckets always take this path; there is no torch fallback."""
+
+    def __init__(self):
+        import ctypes
+
+        from . import _lib
+
+        self._lib, self._ct = _lib, ctypes
+
+    def _stream(self):
+        return self._ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def pack(self, buf, scale, send):
+        self._lib.check(self._lib.lib.dprhot_grad_pack(buf.data_ptr(), buf.numel(), float(scale), _KIND[send.dtype], send.data_ptr(),
+                                                       send.numel(), self._stream()), "dprhot_grad_pack")
+
+    def sum_shards(self, recv, W, out):
+        self._lib.check(self._lib.lib.dprhot_grad_sum_shards(recv.data_ptr(), int(W), out.numel(), _KIND[recv.dtype], _KIND[out.dtype],
+                                                             out.data_ptr(), self._stream()), "dprhot_grad_sum_shards")
+
+    def unpack(self, full, buf):
+        self._lib.check(self._lib.lib.dprhot_grad_unpack(full.data_ptr(), _KIND[full.dtype], buf.data_ptr(), buf.numel(), self._stream()),
+                        "dprhot_grad_unpack")
+
+
+class _TorchLegs:
+    """The same three legs in torch ops -- for CPU buckets only (the gloo tests); a device bucket never comes here."""
+
+    def pack(self, buf, scale, send):
+        n = buf.numel()
+        send[:n].copy_(buf * scale)  # ONE rounding of this rank's contribution (pre-divided in fp32)
+        send[n:].zero_()
+
+    def sum_shards(self, recv, W, out):
+        out.copy_(recv.view(W, -1).float().sum(dim=0))  # fp32 accumulation of the W shards
+
+    def unpack(self, full, buf):
+        buf.copy_(full[:buf.numel()])
+
+
+_HIP_LEGS = None
+
+
+def _legs(buf):
+    global _HIP_LEGS
+    if not buf.is_cuda:
+        return _TorchLegs()
+    if _HIP_LEGS is None:
+        _HIP_LEGS = _HipLegs()  # raises if libdprhot.so is missing: loudly, by design
+    return _HIP_LEGS
+
+
+def _done(value):
+    fut = torch.futures.Future()
+    fut.set_result(value)
+    return fut
 
 
 def compressed_allreduce_hook(state: GradCommState, bucket: dist.GradBucket) -> torch.futures.Future[torch.Tensor]:
@@ -68,37 +134,59 @@ def compressed_allreduce_hook(state: GradCommState, bucket: dist.GradBucket) -> 
     nccl = dist.get_backend(group) == "nccl"
     state.buckets += 1
 
-    if state.mode == "ring" or W == 1:
+    if state.mode == "ring":
         wire = (buf / W).to(state.wire_dtype)
         state.wire_bytes += 2 * (W - 1) * wire.numel() * wire.element_size() // max(W, 1)
         if wire.dtype == torch.bfloat16 and not nccl:
             # gloo cannot add bf16: emulate the ring's result (sum in bf16) through an fp32 all-reduce of the rounded values
             tmp = wire.float()
-            fut = dist.all_reduce(tmp, group=group, async_op=True).get_future()
-            return fut.then(lambda f: buf.copy_(f.value()[0].to(torch.bfloat16)))
+            dist.all_reduce(tmp, group=group)
+            return _done(buf.copy_(tmp.to(torch.bfloat16)))
+        if not nccl:  # callbacks of a gloo future run on gloo's worker threads: keep every collective on this thread
+            dist.all_reduce(wire, group=group)
+            return _done(buf.copy_(wire))
         fut = dist.all_reduce(wire, group=group, async_op=True).get_future()
         return fut.then(lambda f: buf.copy_(f.value()[0]))
 
-    shard = (n + W - 1) // W
+    legs = _legs(buf)
+    shard = ((n + W - 1) // W + 7) // 8 * 8  # 16-byte groups per shard
     npad = shard * W
-    send = torch.zeros(npad, dtype=state.wire_dtype, device=buf.device)
-    send[:n].copy_(buf / W)  # ONE rounding of this rank's contribution (pre-divided in fp32)
+    send = torch.empty(npad, dtype=state.wire_dtype, device=buf.device)
+    legs.pack(buf, 1.0 / W, send)
     recv = torch.empty_like(send)
     state.wire_bytes += (W - 1) * shard * (send.element_size() + torch.empty((), dtype=state.return_dtype).element_size())
-    fut = dist.all_to_all_single(_as_gloo_safe(recv) if not nccl else recv, _as_gloo_safe(send) if not nccl else send, group=group,
-                                 async_op=True).get_future()
 
-    def reduce_and_gather(_):
-        mine = recv.view(W, shard).float().sum(dim=0)  # fp32 accumulation of the W shards
-        out = mine.to(state.return_dtype)
+    def reduce_and_gather(wait2):
+        mine = torch.empty(shard, dtype=state.return_dtype, device=buf.device)
+        legs.sum_shards(recv, W, mine)
         full = torch.empty(npad, dtype=state.return_dtype, device=buf.device)
-        w2 = dist.all_gather_into_tensor(_as_gloo_safe(full) if not nccl else full, _as_gloo_safe(out) if not nccl else out, group=group,
-                                         async_op=True)
-        w2.wait()  # nccl: orders the current (hook) stream behind the collective, the host does not block
-        buf.copy_(full[:n])
+        w2 = dist.all_gather_into_tensor(full if nccl else _as_gloo_safe(full), mine if nccl else _as_gloo_safe(mine), group=group,
+                                         async_op=wait2)
+        if wait2:
+            w2.wait()  # nccl: orders the current (hook) stream behind the collective, the host does not block
+        legs.unpack(full, buf)
         return buf
 
-    return fut.then(reduce_and_gather)
+    if not nccl:
+        # gloo (CPU tests, or two processes sharing one device): a Future.then callback would run on one of gloo's worker threads
+        # and issue the second collective from there -- with several buckets in flight its order against the main thread's next
+        # all-to-all differs between ranks.  Both legs run here, in bucket order, and the future is already complete.
+        if buf.is_cuda:
+            r_cpu, s_cpu = torch.empty(npad, dtype=torch.float16 if send.element_size() == 2 else send.dtype), _as_gloo_safe(send).cpu()
+            dist.all_to_all_single(r_cpu, s_cpu, group=group)  # gloo moves host memory only
+            _as_gloo_safe(recv).copy_(r_cpu)
+            mine = torch.empty(shard, dtype=state.return_dtype, device=buf.device)
+            legs.sum_shards(recv, W, mine)
+            f_cpu = torch.empty(npad, dtype=_as_gloo_safe(mine).dtype)
+            dist.all_gather_into_tensor(f_cpu, _as_gloo_safe(mine).cpu(), group=group)
+            full = torch.empty(npad, dtype=state.return_dtype, device=buf.device)
+            _as_gloo_safe(full).copy_(f_cpu)
+            legs.unpack(full, buf)
+            return _done(buf)
+        dist.all_to_all_single(_as_gloo_safe(recv), _as_gloo_safe(send), group=group)
+        return _done(reduce_and_gather(False))
+    fut = dist.all_to_all_single(recv, send, group=group, async_op=True).get_future()
+    return fut.then(lambda _: reduce_and_gather(True))
 
 
 def register(ddp_model, state: GradCommState = None):

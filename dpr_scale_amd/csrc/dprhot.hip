@@ -26,6 +26,7 @@
 #include "rowwise.h"
 #include "step_small.h"
 #include "skinny.h"
+#include "gradcomm.h"
 
 using namespace dprhot;
 
@@ -72,6 +73,14 @@ E with_loss_stamp(E e) {
   }
   return e;
 }
+
+// loss_sum[0] = g_loss_scale * sum of the row losses, for every launch built on this thread while a LossScaleScope is alive
+// (dprhot_train_step_*: the mean of dpr_task.py:212 leaves the kernel ready, no separate division launch)
+thread_local float g_loss_scale = 1.0f;
+struct LossScaleScope {
+  explicit LossScaleScope(float s) { g_loss_scale = s; }
+  ~LossScaleScope() { g_loss_scale = 1.0f; }
+};
 
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
@@ -574,7 +583,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     static const int gp = []() { const char* e = getenv("DPRHOT_SK_GPARTS"); return e ? atoi(e) : 0; }();  // tuning aid
     int pp = gp > 0 ? gp : parts;
     while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
-    SkGArgs g{S, tile_lse, gold, nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp};
+    SkGArgs g{S, tile_lse, gold, nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp, g_loss_scale};
     hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp + 1)), dim3(SK_THREADS), 0, st, g);
     HIP_TRY(hipGetLastError());
   }
@@ -941,7 +950,7 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
     hipLaunchKernelGGL(g8_lse_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.part_m),
                        reinterpret_cast<const float*>(ws + wl.part_s), cdiv(Nc, G2_B) * 4, reinterpret_cast<const float*>(ws + wl.gold), B,
                        reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss, reinterpret_cast<float*>(ws + wl.rloss));
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, 1.0f, loss_sum);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum);
     HIP_TRY(hipGetLastError());
     return DPRHOT_OK;
   }
@@ -949,7 +958,7 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   if (fp.short_rows) {
     // S_in, when given, is where the caller wants the summed logits (the slabs always live in the workspace)
     GShortArgs g{reinterpret_cast<const float*>(ws + wl.logits), fp.splits, (size_t)B * Nc, B, Nc, y, y_offset, grad_scale,
-                 const_cast<float*>(S_in), row_loss, row_lse, G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum, fp.tpr};
+                 const_cast<float*>(S_in), row_loss, row_lse, G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum, fp.tpr, g_loss_scale};
     if (fp.blocks > 65535) return fail(DPRHOT_E_UNSUPPORTED, "softmax_finish: B=%d rows need %d workgroups (max 65535)", B, fp.blocks);
     if (fp.cpt == 1) hipLaunchKernelGGL(gfinal_short_kernel<1>, dim3(fp.blocks), dim3(fp.threads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(gfinal_short_kernel<2>, dim3(fp.blocks), dim3(fp.threads), 0, (hipStream_t)stream, g);
@@ -961,7 +970,7 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
   if (nt > kGfMaxPairs) return fail(DPRHOT_E_UNSUPPORTED, "Nc=%d too long for the statistics buffer (%d column tiles)", Nc, nt);
   GFinalArgs g{S, B, Nc, y, y_offset, grad_scale, reinterpret_cast<const float*>(ws + wl.part_m),
                reinterpret_cast<const float*>(ws + wl.part_s), nt, reinterpret_cast<const float*>(ws + wl.gold), row_loss, row_lse,
-               G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum};
+               G, reinterpret_cast<unsigned long long*>(ws + wl.header), loss_sum, g_loss_scale};
   const bool thin = (long)B * (Nc / 8) <= 1L << 18;  // latency-bound sizes: one chunk per thread, many small workgroups
   int rpb, xblocks;
   gfinal_geometry(Nc, thin ? 1 : 8, &rpb, &xblocks);
@@ -1174,7 +1183,7 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   char* ws = static_cast<char*>(workspace);
   StepSmallArgs a{reinterpret_cast<const float*>(ws + wl.logits), fp.splits, (size_t)B * Nc, B, Nc, d, y, y_offset, grad_scale,
                   Qb, Cb, h_scale, d_scale, dQ, dC_part, S_out, row_loss, row_lse, loss_sum, G,
-                  g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx};
+                  g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, g_loss_scale};
   // 16 columns of d per workgroup: every workgroup repeats the softmax, the narrow tile only shortens the GEMM / store tail
   constexpr int tw = 16;
   const size_t lds = step_small_lds(Nc, tw);
@@ -1234,6 +1243,95 @@ int dprhot_inbatch_step_packed_f32(const float* q, const dprhot_bf16* gathered, 
   return dprhot_inbatch_step_f32(q, nullptr, Qb, const_cast<dprhot_bf16*>(gathered), B, W * rows_c, d, y, (int64_t)rank * rows_c,
                                  nullptr, inv_T, grad_scale, h_scale, d_scale, nullptr, row_loss, row_lse, loss_sum, G, dQ, dC_part,
                                  workspace, workspace_bytes, stream);
+}
+
+// ---- gradient all-reduce of the towers (reference hook: dpr_task.py:90-92) -------------------------------
+static int gc_blocks(size_t groups) {
+  const size_t want = (groups + 255) / 256;
+  return (int)(want < 1 ? 1 : (want > (size_t)kNumCU * 8 ? (size_t)kNumCU * 8 : want));
+}
+
+// ---- the step as the autograd operator runs it ----------------------------------------------------------------------------------
+int dprhot_train_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
+                          int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float loss_scale, const float* d_scale,
+                          float* row_loss, float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (dc_kind != GC_FP32) return fail(DPRHOT_E_UNSUPPORTED, "train_step: dc_kind=%d (2 = fp32 dC_part) at B=%d Nc=%d d=%d", dc_kind, B, Nc, d);
+  LossScaleScope ls(loss_scale);
+  return dprhot_inbatch_step_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, 1.0f, d_scale, nullptr, row_loss, row_lse,
+                                 loss_out, G, dQ, static_cast<float*>(dC_part), workspace, workspace_bytes, stream);
+}
+
+int dprhot_train_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank, int n_ctx, int d,
+                                 const int64_t* y, float inv_T, float grad_scale, float loss_scale, const float* d_scale, float* row_loss,
+                                 float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (dc_kind != GC_FP32) return fail(DPRHOT_E_UNSUPPORTED, "train_step_packed: dc_kind=%d (2 = fp32 dC_part) at B=%d W=%d n_ctx=%d d=%d", dc_kind, B, W, n_ctx, d);
+  LossScaleScope ls(loss_scale);
+  return dprhot_inbatch_step_packed_f32(q, gathered, Qb, B, W, rank, n_ctx, d, y, inv_T, grad_scale, 1.0f, d_scale, row_loss, row_lse, loss_out,
+                                        G, dQ, static_cast<float*>(dC_part), workspace, workspace_bytes, stream);
+}
+
+int dprhot_rescale_grads(float* dQ, size_t n_dq, void* dC, size_t n_dc, int dc_kind, const float* go, const float* used, float* out2,
+                         void* stream) {
+  REQUIRE(go && used && out2, "NULL pointer");
+  REQUIRE(out2 != go && out2 != used && out2 + 1 != go && out2 + 1 != used, "out2 must not alias go / used");
+  REQUIRE((dQ != nullptr || n_dq == 0) && (dC != nullptr || n_dc == 0), "NULL gradient with a non-zero count");
+  REQUIRE(n_dq % 8 == 0 && n_dc % 8 == 0, "counts must be multiples of 8 (n_dq=%zu n_dc=%zu)", n_dq, n_dc);
+  REQUIRE(dc_kind == GC_FP32 || dc_kind == GC_BF16, "dc_kind=%d (2 fp32, 0 bf16)", dc_kind);
+  REQUIRE(aligned16(dQ) && aligned16(dC), "pointers must be 16-byte aligned");
+  const size_t groups = (n_dq + n_dc) / 8;
+  const dim3 grid(gc_blocks(groups / 4 + 1)), block(256);
+  if (dc_kind == GC_FP32) hipLaunchKernelGGL(rescale_grads_kernel<GC_FP32>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dC, n_dc / 8, go, used, out2);
+  else hipLaunchKernelGGL(rescale_grads_kernel<GC_BF16>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dC, n_dc / 8, go, used, out2);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_grad_pack(const float* bucket, size_t n, float scale, int wire, void* send, size_t n_padded, void* stream) {
+  REQUIRE(bucket && send, "NULL pointer");
+  REQUIRE(n > 0 && n_padded >= n && n_padded % 8 == 0, "bad sizes n=%zu n_padded=%zu (n_padded %% 8 == 0, >= n)", n, n_padded);
+  REQUIRE(wire >= GC_BF16 && wire <= GC_FP32, "wire=%d (0 bf16, 1 fp16, 2 fp32)", wire);
+  REQUIRE(aligned16(bucket) && aligned16(send), "pointers must be 16-byte aligned");
+  const dim3 grid(gc_blocks(n_padded / 8 / GC_U + 1)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (wire == GC_BF16) hipLaunchKernelGGL(grad_pack_kernel<GC_BF16>, grid, block, 0, st, bucket, n, scale, send, n_padded);
+  else if (wire == GC_FP16) hipLaunchKernelGGL(grad_pack_kernel<GC_FP16>, grid, block, 0, st, bucket, n, scale, send, n_padded);
+  else hipLaunchKernelGGL(grad_pack_kernel<GC_FP32>, grid, block, 0, st, bucket, n, scale, send, n_padded);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_grad_sum_shards(const void* recv, int W, size_t shard, int wire, int out_kind, void* out, void* stream) {
+  REQUIRE(recv && out, "NULL pointer");
+  REQUIRE(W > 0 && shard > 0 && shard % 8 == 0, "bad sizes W=%d shard=%zu (shard %% 8 == 0)", W, shard);
+  REQUIRE(wire >= GC_BF16 && wire <= GC_FP32 && (out_kind == wire || out_kind == GC_FP32), "wire=%d out_kind=%d (out = wire kind or fp32)", wire,
+          out_kind);
+  REQUIRE(aligned16(recv) && aligned16(out), "pointers must be 16-byte aligned");
+  const dim3 grid(gc_blocks(shard / 8)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define DPRHOT_GC_SUM(WK, OK) hipLaunchKernelGGL((grad_sum_shards_kernel<WK, OK>), grid, block, 0, st, recv, W, shard, out)
+  if (wire == GC_BF16 && out_kind == GC_BF16) DPRHOT_GC_SUM(GC_BF16, GC_BF16);
+  else if (wire == GC_BF16) DPRHOT_GC_SUM(GC_BF16, GC_FP32);
+  else if (wire == GC_FP16 && out_kind == GC_FP16) DPRHOT_GC_SUM(GC_FP16, GC_FP16);
+  else if (wire == GC_FP16) DPRHOT_GC_SUM(GC_FP16, GC_FP32);
+  else DPRHOT_GC_SUM(GC_FP32, GC_FP32);
+#undef DPRHOT_GC_SUM
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
+int dprhot_grad_unpack(const void* full, int kind, float* bucket, size_t n, void* stream) {
+  REQUIRE(full && bucket && n > 0, "bad argument");
+  REQUIRE(kind >= GC_BF16 && kind <= GC_FP32, "kind=%d (0 bf16, 1 fp16, 2 fp32)", kind);
+  REQUIRE(aligned16(full) && aligned16(bucket), "pointers must be 16-byte aligned");
+  const dim3 grid(gc_blocks(n / 8 / GC_U + 1)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == GC_BF16) hipLaunchKernelGGL(grad_unpack_kernel<GC_BF16>, grid, block, 0, st, full, bucket, n);
+  else if (kind == GC_FP16) hipLaunchKernelGGL(grad_unpack_kernel<GC_FP16>, grid, block, 0, st, full, bucket, n);
+  else hipLaunchKernelGGL(grad_unpack_kernel<GC_FP32>, grid, block, 0, st, full, bucket, n);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
 }
 
 }  // extern "C"

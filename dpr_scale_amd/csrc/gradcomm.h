@@ -1,0 +1,202 @@
+// gradcomm.h -- the three HBM streams of the towers' gradient all-reduce (the reference registers torch's
+// fp16_compress_hook, dpr_scale/task/dpr_task.py:90-92).  The all-pairs decomposition of dpr_scale_amd/comm_hooks.py moves a DDP
+// bucket as   pack -> all-to-all -> sum of the W received shards -> all-gather -> unpack ;   the three local legs are one pass each:
+//   grad_pack_kernel        send[i] = wire(bucket[i] * scale) for i < n, 0 up to n_pad          (4 B read, 2 B written per element)
+//   grad_sum_shards_kernel  out[i]  = sum_r recv[r][i], fp32 accumulation in rank order r = 0..W-1 (deterministic), one rounding
+//   grad_unpack_kernel      bucket[i] = float(full[i]) for i < n
+// Wire kinds: 0 = bf16 (RNE, v_cvt_pk_bf16_f32), 1 = fp16 (RNE; the reference's format), 2 = fp32.
+// Every global access is a 16-byte vector with consecutive lanes; each thread keeps U independent 16-byte groups in flight.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rowwise.h"
+
+namespace dprhot {
+
+constexpr int GC_BF16 = 0, GC_FP16 = 1, GC_FP32 = 2;
+
+__device__ __forceinline__ uint32_t gc_pk_f16(float a, float b) {
+  const __half2 h = __floats2half2_rn(a, b);
+  return __builtin_bit_cast(uint32_t, h);
+}
+template <int KIND>
+__device__ __forceinline__ uint32_t gc_pack2(float a, float b) {
+  if constexpr (KIND == GC_BF16) return pk_bf16(a, b);
+  else return gc_pk_f16(a, b);
+}
+template <int KIND>
+__device__ __forceinline__ void gc_unpack2(uint32_t w, float& a, float& b) {
+  if constexpr (KIND == GC_BF16) {
+    a = __uint_as_float(w << 16);
+    b = __uint_as_float(w & 0xffff0000u);
+  } else {
+    const float2 f = __half22float2(__builtin_bit_cast(__half2, w));
+    a = f.x;
+    b = f.y;
+  }
+}
+// 8 consecutive values of a 2-byte kind (one 16-byte load) or of fp32 (two)
+template <int KIND>
+__device__ __forceinline__ void gc_load8(const void* base, size_t c, float (&v)[8]) {
+  if constexpr (KIND == GC_FP32) {
+    const float4 a = reinterpret_cast<const float4*>(base)[2 * c], b = reinterpret_cast<const float4*>(base)[2 * c + 1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    const uint4 w = reinterpret_cast<const uint4*>(base)[c];
+    gc_unpack2<KIND>(w.x, v[0], v[1]);
+    gc_unpack2<KIND>(w.y, v[2], v[3]);
+    gc_unpack2<KIND>(w.z, v[4], v[5]);
+    gc_unpack2<KIND>(w.w, v[6], v[7]);
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void gc_store8(void* base, size_t c, const float (&v)[8]) {
+  if constexpr (KIND == GC_FP32) {
+    reinterpret_cast<float4*>(base)[2 * c] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(base)[2 * c + 1] = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    reinterpret_cast<uint4*>(base)[c] =
+        make_uint4(gc_pack2<KIND>(v[0], v[1]), gc_pack2<KIND>(v[2], v[3]), gc_pack2<KIND>(v[4], v[5]), gc_pack2<KIND>(v[6], v[7]));
+  }
+}
+template <int KIND>
+__device__ __forceinline__ void gc_store1(void* base, size_t i, float v) {
+  if constexpr (KIND == GC_FP32) reinterpret_cast<float*>(base)[i] = v;
+  else if constexpr (KIND == GC_BF16) reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)(pk_bf16(v, 0.f) & 0xffffu);
+  else reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)(gc_pk_f16(v, 0.f) & 0xffffu);
+}
+template <int KIND>
+__device__ __forceinline__ float gc_load1(const void* base, size_t i) {
+  if constexpr (KIND == GC_FP32) return reinterpret_cast<const float*>(base)[i];
+  else {
+    float a, b;
+    gc_unpack2<KIND>(reinterpret_cast<const uint16_t*>(base)[i], a, b);
+    return a;
+  }
+}
+
+constexpr int GC_U = 4;  // 16-byte groups per thread and trip (x2 loads each for fp32 sources)
+
+// send[0..n_pad) <- wire(bucket[0..n) * scale), zeros beyond n.  n8 = n / 8 whole groups, then a scalar tail, then zero groups.
+template <int WIRE>
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ bucket, size_t n, float scale, void* __restrict__ send,
+                                                        size_t n_pad) {
+  const size_t n8 = n / 8, p8 = n_pad / 8;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; c + (GC_U - 1) * stride < n8; c += GC_U * stride) {
+    float v[GC_U][8];
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) gc_load8<GC_FP32>(bucket, c + u * stride, v[u]);
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] *= scale;
+      gc_store8<WIRE>(send, c + u * stride, v[u]);
+    }
+  }
+  for (; c < p8; c += stride) {
+    float v[8];
+    if (c < n8) {
+      gc_load8<GC_FP32>(bucket, c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= scale;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const size_t i = c * 8 + e;
+        v[e] = i < n ? bucket[i] * scale : 0.f;
+      }
+    }
+    gc_store8<WIRE>(send, c, v);
+  }
+}
+
+// out[0..shard) <- sum over r of recv[r * shard + i]: fp32 accumulation in rank order, ONE rounding into OUT.  shard % 8 == 0.
+template <int WIRE, int OUT>
+__global__ __launch_bounds__(256) void grad_sum_shards_kernel(const void* __restrict__ recv, int W, size_t shard, void* __restrict__ out) {
+  const size_t s8 = shard / 8;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < s8; c += stride) {
+    float acc[8];
+    gc_load8<WIRE>(recv, c, acc);
+    int r = 1;
+    for (; r + 3 < W; r += 4) {  // four ranks' groups in flight
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gc_load8<WIRE>(recv, (size_t)(r + u) * s8 + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[u][e];
+    }
+    for (; r < W; ++r) {
+      float v[8];
+      gc_load8<WIRE>(recv, (size_t)r * s8 + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+    gc_store8<OUT>(out, c, acc);
+  }
+}
+
+// bucket[0..n) <- float(full[0..n))
+template <int KIND>
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const void* __restrict__ full, float* __restrict__ bucket, size_t n) {
+  const size_t n8 = n / 8;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; c + (GC_U - 1) * stride < n8; c += GC_U * stride) {
+    float v[GC_U][8];
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) gc_load8<KIND>(full, c + u * stride, v[u]);
+#pragma unroll
+    for (int u = 0; u < GC_U; ++u) gc_store8<GC_FP32>(bucket, c + u * stride, v[u]);
+  }
+  for (; c < n8; c += stride) {
+    float v[8];
+    gc_load8<KIND>(full, c, v);
+    gc_store8<GC_FP32>(bucket, c, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) bucket[n8 * 8 + threadIdx.x] = gc_load1<KIND>(full, n8 * 8 + threadIdx.x);
+}
+
+// ---- the autograd operator's grad_output fix-up ------------------------------------------------------------------------------------
+// The training step computes dQ / dC_part in the forward call, scaled by the grad_output it EXPECTS (`used`: the value the previous
+// backward saw -- AMP's loss scale changes once in thousands of steps, plain backward() is always 1).  backward() launches this
+// kernel: every workgroup reads the two scalars and leaves when they agree; only when the scale really changed are the gradients
+// multiplied by go / used.  The first thread also publishes out2[0] = go (what the gradients are now scaled by) and out2[1] = the
+// value the NEXT forward should expect (go when it is a finite, normal, non-zero number, else 1).  out2 is a fresh 2-float buffer,
+// never one of the inputs: no workgroup can read a value another one has already replaced.
+template <int DCK>
+__global__ __launch_bounds__(256) void rescale_grads_kernel(float* __restrict__ dQ, size_t nq8, void* __restrict__ dC, size_t nc8,
+                                                            const float* __restrict__ go, const float* __restrict__ used,
+                                                            float* __restrict__ out2) {
+  const float g = go[0], u = used[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out2[0] = g;
+    const float a = fabsf(g);
+    out2[1] = (a >= 1.17549435e-38f && a <= 3.0e38f) ? g : 1.0f;
+  }
+  if (g == u) return;
+  const float ratio = g / u;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nq8 + nc8; c += stride) {
+    float v[8];
+    if (c < nq8) {
+      gc_load8<GC_FP32>(dQ, c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= ratio;
+      gc_store8<GC_FP32>(dQ, c, v);
+    } else {
+      gc_load8<DCK>(dC, c - nq8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= ratio;
+      gc_store8<DCK>(dC, c - nq8, v);
+    }
+  }
+}
+
+}  // namespace dprhot

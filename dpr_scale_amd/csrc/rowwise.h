@@ -167,7 +167,8 @@ struct GFinalArgs {
   float* row_lse;
   uint16_t* G;
   unsigned long long* acc;  // [0] fixed-point loss sum, [1] arrival ticket (zeroed by the sim kernel)
-  float* loss_sum;          // out: sum_i row_loss[i]
+  float* loss_sum;          // out: loss_scale * sum_i row_loss[i]
+  float loss_scale = 1.0f;  // 1: the numerator; 1/Nq: the mean of dpr_task.py:212 leaves the kernel ready
 };
 
 constexpr double kLossFix = 1048576.0;   // 2^20: 48 bits of 2^-20 fixed point hold sums up to 2.7e8 at 1e-6 resolution
@@ -178,7 +179,7 @@ constexpr double kLossMaxBlock = 67108864.0;  // 2^26: a single workgroup's sum 
 // workgroup sum cannot travel in fixed point: it sets sticky bits in acc[1] (bit 0 NaN, bit 1 +inf, bit 2 -inf) BEFORE its
 // ticket, and the last arriver publishes NaN / inf exactly as nn.CrossEntropyLoss would (diverged embeddings, a masked gold
 // column) instead of a finite-looking number.  acc[0..1] are zeroed by the sim launch.
-__device__ __forceinline__ void loss_ticket_add(unsigned long long* acc, double tot, unsigned nblocks, float* loss_sum) {
+__device__ __forceinline__ void loss_ticket_add(unsigned long long* acc, double tot, unsigned nblocks, float* loss_sum, float loss_scale) {
   long long fx = 0;
   const bool nan = !(tot == tot), big = fabs(tot) >= kLossMaxBlock;  // inf counts as big
   if (nan || big) {
@@ -196,7 +197,7 @@ __device__ __forceinline__ void loss_ticket_add(unsigned long long* acc, double 
     else if ((flags & 6ull) == 6ull) out = NAN;  // +inf and -inf
     else if (flags & 2ull) out = INFINITY;
     else if (flags & 4ull) out = -INFINITY;
-    loss_sum[0] = out;
+    loss_sum[0] = out * loss_scale;
   }
 }
 constexpr int kGfMaxPairs = 2048;         // (max, sum) pairs one workgroup stages in LDS
@@ -329,9 +330,9 @@ __global__ __launch_bounds__(256) void gfinal_kernel(GFinalArgs p) {
     if (tid == 0) {
       const double tot = (double)s_part[0] + (double)s_part[1] + (double)s_part[2] + (double)s_part[3];
       if (small || gridDim.y == 1) {
-        p.loss_sum[0] = (float)tot;
+        p.loss_sum[0] = (float)tot * p.loss_scale;
       } else {
-        loss_ticket_add(p.acc, tot, gridDim.y, p.loss_sum);
+        loss_ticket_add(p.acc, tot, gridDim.y, p.loss_sum, p.loss_scale);
       }
     }
   }
@@ -361,6 +362,7 @@ struct GShortArgs {
   unsigned long long* acc;  // acc[0]: packed ticket|sum, zeroed by the sim kernel
   float* loss_sum;
   int tpr;
+  float loss_scale = 1.0f;
 };
 
 constexpr unsigned long long kTicketOne = 1ull << 48;
@@ -472,9 +474,9 @@ __global__ __launch_bounds__(1024) void gfinal_short_kernel(GShortArgs p) {
     double tot = 0.0;
     for (int r = 0; r < rpb; ++r) tot += (double)s_rl[r];
     if (gridDim.x == 1) {
-      p.loss_sum[0] = (float)tot;
+      p.loss_sum[0] = (float)tot * p.loss_scale;
     } else {
-      loss_ticket_add(p.acc, tot, gridDim.x, p.loss_sum);
+      loss_ticket_add(p.acc, tot, gridDim.x, p.loss_sum, p.loss_scale);
     }
   }
 }

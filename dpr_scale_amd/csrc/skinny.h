@@ -301,6 +301,7 @@ struct SkGArgs {
   float* row_lse;         // optional
   float* loss_sum;        // [1]
   int parts;              // workgroups per row
+  float loss_scale = 1.0f;
 };
 
 // logsumexp of one row from its tile values: 64 lanes of a wave, lane l takes groups l, l + 64 (nt <= 512)
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
     if (wave == 0) {
       float a = s_l[lane] + s_l[lane + 64];
       a = wave_sum(a);
-      if (lane == 0) p.loss_sum[0] = a;
+      if (lane == 0) p.loss_sum[0] = a * p.loss_scale;
     }
   }
 }

@@ -44,6 +44,7 @@ struct StepSmallArgs {
   float* loss_sum;     // [1]
   uint16_t* G;         // optional [B][Nc]
   int stamp_period, stamp_row;  // > 0: dC[m][0] = loss numerator for m % stamp_period == stamp_row (EpiScaleF32)
+  float loss_scale = 1.0f;
 };
 
 inline size_t step_small_lds(int Nc, int TW) {
@@ -238,8 +239,8 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   if (lead && tid == 0) {
     double tot = 0.0;
     for (int r = 0; r < p.B; ++r) tot += (double)s_rl[r];
-    p.loss_sum[0] = (float)tot;
-    s_rl[0] = (float)tot;  // (row losses are no longer needed) for the stamp below, read after the next barrier
+    p.loss_sum[0] = (float)tot * p.loss_scale;
+    s_rl[0] = (float)tot * p.loss_scale;  // (row losses are no longer needed) for the stamp below, read after the next barrier
   }
 
   const float sc = p.h_scale * dsc;

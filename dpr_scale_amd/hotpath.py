@@ -17,6 +17,26 @@ import torch
 from . import dist as D
 
 _BF16 = torch.bfloat16
+_KIND = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}  # storage kinds of include/dprhot.h
+
+
+class _ExpectedGradScale:
+    """Per device: the DEVICE scalar the next training step should scale its gradients by -- the grad_output the previous backward
+    saw (AMP's loss scale; 1 for a plain backward()).  Every backward publishes a FRESH one-float tensor (written once by
+    dprhot_rescale_grads, never modified afterwards), so a step that read an older one can still compare against it."""
+
+    _cur = {}
+
+    @classmethod
+    def get(cls, dev):
+        t = cls._cur.get(dev)
+        if t is None:
+            t = cls._cur[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+        return t
+
+    @classmethod
+    def publish(cls, dev, t):
+        cls._cur[dev] = t
 
 
 def _fp32_g_mode():
@@ -206,6 +226,71 @@ class HipKernels:
             self._stream()), "dprhot_inbatch_step_packed_f32")
         return row_loss, row_lse, loss_sum, G, dQ, dC
 
+    def train_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32):
+        """The operator's step (dprhot_train_step_f32): forward AND backward in one library call, the loss already multiplied by
+        loss_scale, the gradients scaled by the DEVICE scalar d_scale (the grad_output backward() is expected to deliver).
+        Returns (row_loss, row_lse, loss_out [2], G, dQ, dC_part); loss_out[0] is the loss."""
+        self._require_gpu(q, c, Qb, Cb, y, colmask, d_scale)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        dev = Qb.device
+        q = q.detach().contiguous()
+        c = c.detach().contiguous() if c is not None else None
+        assert q.dtype == torch.float32 and (c is None or (c.dtype == torch.float32 and c.shape[0] == Nc))
+        f32 = torch.float32
+        row_loss = torch.empty(B, dtype=f32, device=dev)
+        row_lse = torch.empty(B, dtype=f32, device=dev)
+        loss_out = torch.empty(2, dtype=f32, device=dev)
+        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        dQ = torch.empty((B, d), dtype=f32, device=dev)
+        dC = torch.empty((Nc, d), dtype=dc_dtype, device=dev)
+        ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_train_step_f32(
+            _ptr(q), _ptr(c), _ptr(Qb), _ptr(Cb), B, Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T), float(grad_scale),
+            float(loss_scale), _ptr(d_scale), _ptr(row_loss), _ptr(row_lse), _ptr(loss_out), _ptr(G), _ptr(dQ), _ptr(dC),
+            _KIND[dc_dtype], _ptr(ws), ws.numel(), self._stream()), "dprhot_train_step_f32")
+        return row_loss, row_lse, loss_out, G, dQ, dC
+
+    def train_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32):
+        """World size > 1 (dprhot_train_step_packed_f32): as train_step_f32 on the all-gathered packed buffer."""
+        self._require_gpu(q, gathered, Qb, y, d_scale)
+        B, d = Qb.shape
+        Nc = gathered.shape[0]
+        dev = Qb.device
+        q = q.detach().contiguous()
+        assert q.dtype == torch.float32 and gathered.dtype == _BF16 and Nc == W * self.packed_rows(n_ctx, d)
+        f32 = torch.float32
+        row_loss = torch.empty(B, dtype=f32, device=dev)
+        row_lse = torch.empty(B, dtype=f32, device=dev)
+        loss_out = torch.empty(2, dtype=f32, device=dev)
+        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        dQ = torch.empty((B, d), dtype=f32, device=dev)
+        dC = torch.empty((Nc, d), dtype=dc_dtype, device=dev)
+        ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_train_step_packed_f32(
+            _ptr(q), _ptr(gathered), _ptr(Qb), B, int(W), int(rank), int(n_ctx), d, _ptr(y), float(inv_T), float(grad_scale),
+            float(loss_scale), _ptr(d_scale), _ptr(row_loss), _ptr(row_lse), _ptr(loss_out), _ptr(G), _ptr(dQ), _ptr(dC),
+            _KIND[dc_dtype], _ptr(ws), ws.numel(), self._stream()), "dprhot_train_step_packed_f32")
+        return row_loss, row_lse, loss_out, G, dQ, dC
+
+    def rescale_grads(self, dQ, dC, go, used):
+        """backward() of the operator (dprhot_rescale_grads): the gradients were computed for grad_output = used; multiply by
+        go / used only if they differ (decided on the device).  Returns out2: [0] what the gradients are scaled by now, [1] the
+        scale the next forward should expect."""
+        self._require_gpu(dQ, dC, go, used)
+        out2 = torch.empty(2, dtype=torch.float32, device=go.device)
+        self._lib.check(self.lib.dprhot_rescale_grads(
+            _ptr(dQ), dQ.numel() if dQ is not None else 0, _ptr(dC), dC.numel() if dC is not None else 0,
+            _KIND[dC.dtype] if dC is not None else 2, _ptr(go), _ptr(used), _ptr(out2), self._stream()), "dprhot_rescale_grads")
+        return out2
+
+    def widen(self, src, dst):
+        """dst (fp32, contiguous) <- src (bf16 / fp16 / fp32, contiguous), one pass (dprhot_grad_unpack)."""
+        self._require_gpu(src, dst)
+        assert src.is_contiguous() and dst.is_contiguous() and dst.dtype == torch.float32 and src.numel() >= dst.numel()
+        self._lib.check(self.lib.dprhot_grad_unpack(_ptr(src), _KIND[src.dtype], _ptr(dst), dst.numel(), self._stream()), "dprhot_grad_unpack")
+        return dst
+
     def inbatch_bwd(self, G, Qb, Cb, h_scale, d_scale, need_dq=True, need_dc=True):
         self._require_gpu(G, Qb, Cb, d_scale)
         B, d = Qb.shape
@@ -379,6 +464,7 @@ class PendingGrad:
 
     def __init__(self):
         self.work = None
+        self.post = None  # run on the gradient after the wait (half-width wire: widen the received rows into it)
 
 
 class _DeferContextGrad(torch.autograd.Function):
@@ -397,6 +483,9 @@ class _DeferContextGrad(torch.autograd.Function):
         w, ctx.pending.work = ctx.pending.work, None
         if w is not None:
             w.wait()
+        post, ctx.pending.post = ctx.pending.post, None
+        if post is not None:
+            post(grad)
         return grad, None
 
 
@@ -429,14 +518,17 @@ class InBatchContrastive(torch.autograd.Function):
         q_f32 = q.dtype == torch.float32 and hasattr(kn, "inbatch_fwd_f32")
         Qb = kn.empty((B, d), _BF16, q)
 
+        wants_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         if W == 1:
             # columns = this rank's contexts (padded to a multiple of 8 with masked zero rows)
             rows_c = _pad_cols(n_ctx)
             Nc = rows_c
             Cb = kn.empty((Nc, d), _BF16, c)
-            colmask = kn.empty((Nc,), torch.uint8, c)
-            colmask[:n_ctx].copy_(m8)
-            if Nc != n_ctx:
+            if Nc == n_ctx:
+                colmask = m8 if m8.is_contiguous() else m8.contiguous()  # the batch's own bool mask, read in place
+            else:
+                colmask = kn.empty((Nc,), torch.uint8, c)
+                colmask[:n_ctx].copy_(m8)
                 Cb[n_ctx:].zero_()
                 colmask[n_ctx:].fill_(1)
             # fp32 encoder outputs are consumed as they are by the sim kernel (it rounds to bf16 while staging
@@ -460,8 +552,7 @@ class InBatchContrastive(torch.autograd.Function):
                 D.all_gather_rows(send, Cb, group)
             c_direct = False
             # with a backward to follow, the one-call step reads the mask straight from the gathered buffer: no unpack launch
-            packed_step = (q_f32 and hasattr(kn, "inbatch_step_packed_f32")
-                           and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+            packed_step = q_f32 and wants_grad and (hasattr(kn, "train_step_packed_f32") or hasattr(kn, "inbatch_step_packed_f32"))
             if not packed_step:
                 colmask = kn.empty((Nc,), torch.uint8, c)
                 kn.unpack_mask(Cb, W, n_ctx, colmask)
@@ -471,22 +562,40 @@ class InBatchContrastive(torch.autograd.Function):
         inv_T = 1.0 / float(temperature)
         grad_scale = inv_T / Nq  # d loss / d S of the global mean, before grad_output
         y_off = r * rows_c       # dpr_task.py:189-190 (label offset of this rank's columns)
-        eager = None  # gradients for grad_output = 1, when the whole step ran in the forward call
+        eager = None  # gradients computed in this call, scaled by ctx.used (a device scalar)
+        used = None
         S_dbg = None
-        if W == 1 and _fp32_g_mode() and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+        loss_is_mean = False  # the kernel already multiplied the numerator by 1 / Nq
+        dc_dtype = _dc_wire_dtype() if W > 1 else torch.float32
+        if W == 1 and _fp32_g_mode() and wants_grad:
             if q_f32:
                 row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
                                                                            inv_T, grad_scale, want_logits=True)
             else:
                 row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale, want_logits=True)
-        elif W > 1 and packed_step:
-            row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T,
-                                                                                     grad_scale)
-            # (dC_part's dead mask rows also carry the loss numerator; only bench.py's stream-ordered step uses that)
+        elif W > 1 and packed_step and hasattr(kn, "train_step_packed_f32"):
+            # forward and backward of this rank's rows in ONE library call; gradients scaled by the grad_output the last backward saw
+            used = _ExpectedGradScale.get(q.device)
+            try:
+                row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
+                                                                                       1.0 / Nq, used, dc_dtype)
+            except Exception as e:  # a plan without a bf16 dC epilogue: fp32 partials, rounded to the wire format in backward
+                if dc_dtype == torch.float32 or "dc_kind" not in str(e):
+                    raise
+                row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
+                                                                                       1.0 / Nq, used, torch.float32)
+            eager, loss_is_mean = (dQ, dC_part), True
+        elif W > 1 and packed_step:  # (stand-in kernels of the CPU tests)
+            row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale)
             eager = (dQ, dC_part)
-        elif q_f32 and hasattr(kn, "inbatch_step_f32") and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            # a backward will follow: forward and backward in ONE library call (two launches at the BASELINE shapes
-            # instead of three); backward() only applies grad_output and the reduce-scatter
+        elif q_f32 and wants_grad and hasattr(kn, "train_step_f32"):
+            # a backward will follow: forward and backward in ONE library call (two launches at the BASELINE shapes);
+            # backward() only checks the grad_output it was given against the one the gradients were scaled by
+            used = _ExpectedGradScale.get(q.device)
+            row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
+                                                                            inv_T, grad_scale, 1.0 / Nq, used)
+            eager, loss_is_mean = (dQ, dC_part), True
+        elif q_f32 and wants_grad and hasattr(kn, "inbatch_step_f32"):  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx,
                                                                               y_off, colmask, inv_T, grad_scale)
             eager = (dQ, dC_part)
@@ -495,14 +604,15 @@ class InBatchContrastive(torch.autograd.Function):
                                                                    colmask, inv_T, grad_scale)
         else:
             row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale)
+        loss_sum = loss_sum[:1]
         if W > 1:
-            D.all_reduce_sum(loss_sum, group)
-        loss = (loss_sum / Nq).reshape(())
+            D.all_reduce_sum(loss_sum, group)  # (of the means when loss_is_mean: the sum over ranks is the global mean)
+        loss = (loss_sum if loss_is_mean else loss_sum / Nq).reshape(())
 
         ctx.kn, ctx.group = kn, group
         ctx.dims = (W, r, B, d, n_ctx, rows_c)
         ctx.in_dtypes = (q.dtype, c.dtype)
-        ctx.eager = eager
+        ctx.eager, ctx.used, ctx.handed_out = eager, used, False
         ctx.pending = pending if W > 1 else None
         if eager is None:
             ctx.save_for_backward(Qb, Cb, G)
@@ -516,9 +626,21 @@ class InBatchContrastive(torch.autograd.Function):
         W, r, B, d, n_ctx, rows_c = ctx.dims
         need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         go = grad_out.detach().reshape(1).float().contiguous()  # device scalar: AMP loss scale, no host sync
-        if ctx.eager is not None:
-            dQ, dC_part = ctx.eager  # computed in forward for grad_output = 1; the scale is applied below (kept: a
-            #                          second backward with retain_graph=True must find them again)
+        if ctx.eager is not None and ctx.used is not None:
+            # computed in forward for grad_output = *ctx.used; ONE launch compares and only rescales when the scale really changed
+            dQ, dC_part = ctx.eager
+            if not ctx.handed_out:
+                out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
+                ctx.used = out2[0:1]  # what the gradients are scaled by from here on
+                ctx.handed_out = True
+                _ExpectedGradScale.publish(go.device, out2[1:2])
+                go = None
+            else:
+                # a second backward through a retained graph: autograd may have kept the tensors handed out the first time as
+                # .grad itself, so they are never touched again -- fresh tensors, scaled by go / used (rare: plain torch ops)
+                go = go / ctx.used
+        elif ctx.eager is not None:
+            dQ, dC_part = ctx.eager  # computed in forward for grad_output = 1 (stand-in kernels); the scale is applied below
         elif ctx.dbg is not None:
             # fp32-G debug mode: G = (exp(S - lse) - onehot) * scale recomputed in fp32, split into a bf16 pair, two GEMM passes
             Qb, Cb, _ = ctx.saved_tensors
@@ -549,15 +671,24 @@ class InBatchContrastive(torch.autograd.Function):
                 mine = kn.empty((rows_c, d), wire, dC_part)
                 if go is not None:
                     dC_part = dC_part * go  # scale before the collective: nothing is left to do after it
-                if wire != torch.float32:
+                if dC_part.dtype != wire:
                     dC_part = dC_part.to(wire)  # half the bytes on the links (and in RCCL's reduction)
-                if ctx.pending is not None and ctx.in_dtypes[1] == torch.float32 and wire == torch.float32:
-                    # reduce-scatter on RCCL's stream; whoever consumes dc (defer_context_grad, after the query-tower
-                    # backward has been enqueued) waits for it
+                widen = wire != ctx.in_dtypes[1] and ctx.in_dtypes[1] == torch.float32 and hasattr(kn, "widen")
+                if ctx.pending is not None and (wire == ctx.in_dtypes[1] or widen):
+                    # reduce-scatter on RCCL's stream; whoever consumes dc (defer_context_grad, after the query-tower backward has
+                    # been enqueued) waits for it -- and, on a half-width wire, widens the result into the fp32 gradient there
                     ctx.pending.work = D.reduce_scatter_rows(dC_part, mine, group, async_op=True)
+                    if widen:
+                        dc = kn.empty((n_ctx, d), torch.float32, mine)  # filled by pending.post, after the wait
+                        ctx.pending.post = lambda g, kn=kn, mine=mine: kn.widen(mine, g)
+                    else:
+                        dc = mine[:n_ctx]
                 else:
                     D.reduce_scatter_rows(dC_part, mine, group)  # sum over ranks of the partials of MY columns
-                dc = mine[:n_ctx].to(ctx.in_dtypes[1])
+                    if widen:
+                        dc = kn.widen(mine, kn.empty((n_ctx, d), torch.float32, mine))
+                    else:
+                        dc = mine[:n_ctx].to(ctx.in_dtypes[1])
         return dq, dc, None, None, None, None, None, None, None
 
 
@@ -675,7 +806,10 @@ def sim_score(q, c, colmask=None, inv_T=1.0, kernels=None):
     dummy-context mask (the row the reference broadcasts at :197).  Differentiable when an input requires grad."""
     kn = kernels if kernels is not None else default_kernels()
     q, c = _pad_hidden(q, c)
-    if torch.is_grad_enabled() and (q.requires_grad or c.requires_grad) and hasattr(kn, "dq"):
+    if torch.is_grad_enabled() and (q.requires_grad or c.requires_grad):
+        if not hasattr(kn, "dq"):
+            raise RuntimeError(f"sim_score: an input requires grad but the kernels object {getattr(kn, 'name', kn)!r} has no backward "
+                               "GEMMs (dq / dc); scores without a grad_fn would silently train nothing")
         return SimScore.apply(q, c, colmask, inv_T, kn)
     S, _, _, Nc = _sim_fwd(kn, q.detach(), c.detach(), colmask, inv_T)
     return S if S.shape[1] == Nc else S[:, :Nc]
@@ -733,6 +867,7 @@ def rank_and_loss(q, c, labels, colmask=None, inv_T=1.0, kernels=None):
     compute_rank_metrics + self.loss (dpr_task.py:235-246,:299) derive from the score matrix, here without ever storing it
     when the problem is large (validation over a whole epoch's embeddings: 8192 x 65536 logits would be 2 GiB)."""
     kn = kernels if kernels is not None else default_kernels()
+    q, c = _pad_hidden(q.detach(), c.detach())  # hidden sizes that are not a multiple of 8 (tiny encoders, projection heads)
     Nc = c.shape[0]
     Nc_pad = _pad_cols(Nc)
     Qb = kn.empty(tuple(q.shape), _BF16, q)

@@ -123,12 +123,13 @@ class DenseRetrieverTask(LightningModule):
         """Reference :90-92: `fp16_grads` registers torch's fp16_compress_hook (one half-precision ring all-reduce per
         bucket).  Here the same switch registers dpr_scale_amd.comm_hooks.compressed_allreduce_hook: half the bytes on the
         wire as well, but as an all-pairs exchange with fp32 accumulation (7 xGMI links per GPU instead of a one-link
-        ring); bf16 on the wire by default, DPRHOT_GRAD_WIRE=fp16 for the reference's format, DPRHOT_GRAD_MODE=ring for
-        its decomposition."""
+        ring).  The wire format is the reference's fp16 by default (same flag, same numbers on the wire; the sum itself
+        is fp32 here); DPRHOT_GRAD_WIRE=bf16 trades mantissa for fp32's exponent range, DPRHOT_GRAD_MODE=ring selects the
+        reference's decomposition."""
         if self.fp16_grads:
             from .. import comm_hooks
 
-            self.grad_comm_state = comm_hooks.register(self.trainer.strategy._model, comm_hooks.GradCommState.from_env())
+            self.grad_comm_state = comm_hooks.register(self.trainer.strategy._model, comm_hooks.GradCommState.from_env(default_wire="fp16"))
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, **kwargs):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 150 /* 0.1.50: + no-logits forward at large shapes (dprhot_dscores), dprhot_sim_rank */
+#define DPRHOT_VERSION 160 /* 0.1.60: + dprhot_grad_pack / _sum_shards / _unpack (gradient hook legs), dprhot_train_step_*, dprhot_rescale_grads */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -246,6 +246,45 @@ int dprhot_pairwise_fwd(const float* q, const float* c, const uint8_t* mask, int
 /* Its backward: dq[b] = sum_j g[b][j] c[b*M+j] and dc[b*M+j] = g[b][j] q[b]; g [B,M] fp32 with 0 at masked pairs.
  * dq / dc may each be NULL. */
 int dprhot_pairwise_bwd(const float* g, const float* q, const float* c, int B, int M, int d, float* dq, float* dc, void* stream);
+
+/* The step as the autograd operator of dpr_scale_amd/hotpath.py runs it (dpr_task.py:197-212 + its backward inside the forward call):
+ * dprhot_inbatch_step_f32 / _packed_f32 with
+ *   loss_scale   loss_out[0] = loss_scale * sum_i row_loss[i]: pass 1 / Nq_global and the mean of dpr_task.py:212 leaves the kernel
+ *                ready (and the stamp of the packed form carries that value)
+ *   d_scale      DEVICE scalar the gradients are scaled by (required): the grad_output the caller expects backward() to deliver
+ *   dC_part      fp32 (dc_kind = 2), or bf16 (dc_kind = 0: the wire format of the reduce-scatter written by the dC epilogue itself;
+ *                DPRHOT_E_UNSUPPORTED at shapes whose plan has no such epilogue -- the caller then asks for fp32)
+ * No S_out, no h_scale (= 1). */
+int dprhot_train_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
+                          int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float loss_scale, const float* d_scale,
+                          float* row_loss, float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int dprhot_train_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank, int n_ctx, int d,
+                                 const int64_t* y, float inv_T, float grad_scale, float loss_scale, const float* d_scale, float* row_loss,
+                                 float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* backward() of that operator: the gradients were computed for grad_output = *used; the autograd engine delivers *go.
+ *   if (*go != *used)  dQ[0..n_dq) and dC[0..n_dc) are multiplied by *go / *used   (AMP's loss scale changes once in thousands of
+ *                      steps; otherwise every workgroup reads two floats and leaves)
+ *   out2[0] = *go   (what the gradients are now scaled by: `used` of a second backward through the same graph)
+ *   out2[1] = *go if it is a finite, normal, non-zero number, else 1   (the d_scale the next forward should expect)
+ * out2 is a fresh 2-float buffer (never go / used).  dQ fp32, dC fp32 (dc_kind 2) or bf16 (0); either may be NULL with count 0;
+ * counts are multiples of 8. */
+int dprhot_rescale_grads(float* dQ, size_t n_dq, void* dC, size_t n_dc, int dc_kind, const float* go, const float* used, float* out2,
+                         void* stream);
+
+/* Gradient all-reduce of the encoder towers (reference: dpr_scale/task/dpr_task.py:90-92 registers torch's fp16_compress_hook on
+ * the DDP model: bucket -> fp16 -> ONE ring all-reduce -> fp32).  The hook of dpr_scale_amd/comm_hooks.py moves a bucket as
+ *   pack -> all-to-all (every pair of GPUs owns an xGMI link) -> sum of the W received shards in fp32 -> all-gather -> unpack;
+ * these are its three local legs, one pass over HBM each.  Wire kinds: 0 = bf16 (RNE), 1 = fp16 (RNE, the reference's), 2 = fp32.
+ *   dprhot_grad_pack        send[i] = wire(bucket[i] * scale) for i < n, 0 for n <= i < n_padded (n_padded % 8 == 0; = W * shard)
+ *   dprhot_grad_sum_shards  out[i] = sum_r recv[r * shard + i], fp32 accumulation in rank order r = 0 .. W-1 (deterministic), ONE
+ *                           rounding into out_kind (= wire kind, or 2 for an fp32 return leg); shard % 8 == 0
+ *   dprhot_grad_unpack      bucket[i] = float(full[i]) for i < n (kind of `full` = the return leg's) */
+int dprhot_grad_pack(const float* bucket, size_t n, float scale, int wire, void* send, size_t n_padded, void* stream);
+int dprhot_grad_sum_shards(const void* recv, int W, size_t shard, int wire, int out_kind, void* out, void* stream);
+int dprhot_grad_unpack(const void* full, int kind, float* bucket, size_t n, void* stream);
 
 /* Optional communicator: the collectives of the path (dpr_task.py:166-176 gathers; the autograd split of :192-195)
  * issued directly on the caller's stream through the RCCL library already present in the process (dlopen; no

@@ -68,6 +68,21 @@ def test_argument_validation_is_host_side():
     assert lib.dprhot_workspace_bytes(8192, 65536, 768, ctypes.byref(big)) == 0
     assert big.value < 8192 * 65536 * 4, "a no-logits shape must not reserve a logit buffer"
     assert lib.dprhot_workspace_bytes(1024, 8192, 768, ctypes.byref(small)) == 0 and small.value >= 1024 * 8192 * 4  # logits stored here
+    # round 3: the operator's step, the grad_output fix-up, the gradient-hook legs
+    assert lib.dprhot_train_step_f32(null, null, null, null, 4, 8, 64, null, 0, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
+                                     null, 2, null, 0, null) == -1
+    assert lib.dprhot_train_step_f32(null, null, null, null, 4, 8, 64, null, 0, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
+                                     null, 1, null, 0, null) == -3  # fp16 partials: no such epilogue
+    assert lib.dprhot_train_step_packed_f32(null, null, null, 4, 2, 5, 8, 64, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
+                                            null, 2, null, 0, null) == -1
+    assert lib.dprhot_rescale_grads(null, 8, null, 0, 2, null, null, null, null) == -1
+    assert lib.dprhot_grad_pack(null, 8, 1.0, 0, null, 8, null) == -1
+    buf = (ctypes.c_float * 16)()
+    assert lib.dprhot_grad_pack(buf, 9, 1.0, 0, buf, 12, null) == -1 and b"n_padded" in lib.dprhot_last_error()  # n_padded % 8
+    assert lib.dprhot_grad_pack(buf, 9, 1.0, 5, buf, 16, null) == -1  # wire kind
+    assert lib.dprhot_grad_sum_shards(buf, 2, 12, 0, 0, buf, null) == -1  # shard % 8
+    assert lib.dprhot_grad_sum_shards(buf, 2, 8, 0, 1, buf, null) == -1   # bf16 in, fp16 out
+    assert lib.dprhot_grad_unpack(null, 0, null, 8, null) == -1
     rows = ctypes.c_int(0)
     assert lib.dprhot_packed_rows(256, 768, ctypes.byref(rows)) == 0 and rows.value == 264  # 256 rows + 1 mask row -> 8-row multiple
     with pytest.raises(_lib.DprhotError):

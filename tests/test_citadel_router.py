@@ -94,7 +94,7 @@ def test_router_loss_hip_at_vocabulary_width(name):
     loss = task.router_loss({"router_repr": tq}, {"router_repr": tc}, t(mask), t(pos), t(teacher))
     loss.backward()
     assert abs(loss.item() - float(z["loss"])) <= 1e-3 * max(1.0, abs(float(z["loss"])))  # north_star: 1e-3 relative
-    tol = 1e-2 if (meta["in_batch"] and meta["teacher_coef"] < 1) else 1e-4   # bf16 dScores only on the dense path
+    tol = 1e-2 if meta["teacher_coef"] < 1 else 1e-4   # the cross-entropy's dScores are bf16 (2^-9); the teacher-only loss is fp32 throughout
     _check_grads(meta, z, tq.grad.cpu().numpy(), tc.grad.cpu().numpy(), tol)
     s0 = task.sim_score(tq.detach(), tc.detach(), t(mask), pairwise=False).cpu().numpy()
     fin = np.isfinite(z["S_dense"])

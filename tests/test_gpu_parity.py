@@ -847,6 +847,95 @@ def test_rank_and_loss_helper_matches_score_matrix_path(kn, dev):
     assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
 
 
+def test_operator_applies_any_grad_output_with_one_fixup_launch(dev):
+    """Under AMP backward() receives the loss scale, not 1.  The operator computes its gradients in the forward call for the
+    grad_output the PREVIOUS backward saw and fixes them up in backward (dprhot_rescale_grads) only when the scale changed: every
+    sequence of scales -- first step, unchanged, changed, zero, a second backward through a retained graph -- must give
+    grad_output x the reference's gradients."""
+    from dpr_scale_amd import hotpath
+
+    meta, g = load_golden("cfg2_Ur_T0.05")
+    q, c, y, m = rank_inputs(meta)[0]
+    ty, tm = t(y, dev), t(m, dev)
+
+    def step(scale, retain=False):
+        tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+        loss = hotpath.inbatch_contrastive_loss(tq, tc, ty, tm, meta["T"])
+        (loss * scale).backward(retain_graph=retain)
+        return loss, tq, tc
+
+    for scale in (1.0, 65536.0, 65536.0, 32768.0, 0.0, 3.0, 1.0):
+        loss, tq, tc = step(scale)
+        assert abs(loss.item() - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+        if scale == 0.0:
+            assert float(tq.grad.abs().max()) == 0.0 and float(tc.grad.abs().max()) == 0.0
+        else:
+            assert rel(tq.grad.cpu().numpy() / scale, g["dQ"]) <= GRAD_RTOL, scale
+            assert rel(tc.grad.cpu().numpy() / scale, g["dC"]) <= GRAD_RTOL, scale
+    # the expectation never becomes a value gradients cannot be rescaled from
+    exp = hotpath._ExpectedGradScale.get(dev)
+    assert float(exp.item()) == 1.0
+    # two backwards through one graph with different scales: gradients accumulate as 2 x + 5 x
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = hotpath.inbatch_contrastive_loss(tq, tc, ty, tm, meta["T"])
+    (loss * 2.0).backward(retain_graph=True)
+    (loss * 5.0).backward()
+    assert rel(tq.grad.cpu().numpy() / 7.0, g["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy() / 7.0, g["dC"]) <= GRAD_RTOL
+    # an overflowed loss scale (inf) propagates like the reference's autograd does (non-finite gradients), and is not remembered
+    loss, tq, tc = step(float("inf"))
+    assert not torch.isfinite(tq.grad).all()
+    assert float(hotpath._ExpectedGradScale.get(dev).item()) == 1.0
+    loss, tq, tc = step(4.0)
+    assert rel(tq.grad.cpu().numpy() / 4.0, g["dQ"]) <= GRAD_RTOL
+
+
+def test_operator_step_launches_only_library_kernels(dev):
+    """SURVEY.md section 8 b2 / VERDICT round 2: one training step through the autograd operator (forward + backward with a loss
+    scale, as under AMP) must not add torch elementwise passes to the hand-written step."""
+    from torch.profiler import ProfilerActivity, profile
+
+    from dpr_scale_amd import hotpath
+
+    meta, g = load_golden("cfg2_U_T1")
+    q, c, y, m = rank_inputs(meta)[0]
+    tq, tc, ty, tm = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True), t(y, dev), t(m, dev)
+    scale = torch.full((), 1024.0, device=dev)
+
+    def one():
+        tq.grad = tc.grad = None
+        loss = hotpath.inbatch_contrastive_loss(tq, tc, ty, tm, 1.0)
+        loss.backward(scale)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        one()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA and "Memcpy" not in e.name and "Memset" not in e.name]
+    if not names:
+        pytest.skip("the profiler recorded no device activity on this box")
+    foreign = [n for n in names if "dprhot" not in n]
+    assert not foreign, foreign
+    assert len(names) <= 3, names  # sim, softmax + backward, grad_output check
+
+
+def test_rank_and_loss_with_a_hidden_size_that_is_not_a_multiple_of_8(kn, dev):
+    """d = 100 (tiny encoders, projection heads): validation must pad like training does (it used to hit `n % 8 == 0`)."""
+    from dpr_scale_amd import hotpath
+
+    B, Nc, d = 24, 50, 100
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float()
+    c = (torch.randn(Nc, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float()
+    y = torch.randint(0, Nc, (B,), generator=gen)
+    ranks, loss = hotpath.rank_and_loss(q.to(dev), c.to(dev), y.to(dev), None, 1.0, kn)
+    S = O.sim_score(q.numpy(), c.numpy(), None)
+    assert np.array_equal(ranks.cpu().numpy(), O.rank_of_gold(S.astype(np.float32), y.numpy()))
+    ref = O.log_softmax_ce(S, y.numpy())[0]
+    assert abs(loss.item() - ref) <= LOSS_RTOL * max(1.0, abs(ref))
+
+
 def test_packed_multi_rank_step_at_a_no_logits_shape(kn, dev):
     """Large per-rank batch over several ranks, emulated on one GPU: dprhot_inbatch_step_packed_f32 then runs the no-logits forward
     with the column mask read from the gathered buffer's mask rows (Epi8Base::mask_byte, packed layout) and stamps the loss numerator

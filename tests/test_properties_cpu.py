@@ -149,3 +149,23 @@ def test_search_over_pickled_shards_follows_the_reference_flow(tmp_path):
         order = np.lexsort((ci, -cs), axis=1)[:, :7]
         assert np.array_equal(i.numpy(), np.take_along_axis(ci, order, 1))
         assert np.array_equal(v.numpy(), np.take_along_axis(cs, order, 1))
+
+
+def test_sim_score_refuses_to_return_detached_scores_to_a_training_caller():
+    """A kernels object without backward GEMMs must not hand scores without a grad_fn to a caller whose inputs require grad
+    (the encoders would silently receive no gradient)."""
+    import pytest
+    import torch
+
+    from _oracle_kernels import OracleKernels
+    from dpr_scale_amd import hotpath
+
+    class NoBackward(OracleKernels):
+        dq = property()  # hasattr(...) is False
+        dc = property()
+
+    q = torch.randn(4, 16, requires_grad=True)
+    c = torch.randn(8, 16)
+    with pytest.raises(RuntimeError, match="requires grad"):
+        hotpath.sim_score(q, c, None, 1.0, NoBackward())
+    assert hotpath.sim_score(q.detach(), c, None, 1.0, NoBackward()).shape == (4, 8)  # inference callers are unaffected
