@@ -229,28 +229,20 @@ class HotPathStep:
         self.c_step()
 
     def step(self):
-        # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first
+        # fp32 encoder outputs go straight into the sim kernel; only the rows that travel over xGMI are cast first.  The collectives
+        # are the product's own (dpr_scale_amd.dist): torch.distributed, or -- once dist.enable_direct_comm() has run, exactly as
+        # DenseRetrieverTask does before its first step -- the C ABI communicator on this very stream.
         if self.dist:
             self.k_pack()
-            if self.comm is not None:
-                self.comm.all_gather_rows(self.send, self.Cb)  # the one forward collective
-            else:
-                self.D.all_gather_rows(self.send, self.Cb, self.group)
+            self.D.all_gather_rows(self.send, self.Cb, self.group)  # the one forward collective
             if not self.packed_step:
                 self.k_unpack()
         self.k_step()  # forward + backward of the local rows: one call into the library
-        if self.dist and self.comm is not None:
-            self.comm.reduce_scatter_rows(self.dC, self.dc)  # the one backward collective; dc[n_ctx][0] = global loss numerator
+        if self.dist:
+            self.D.reduce_scatter_rows(self.dC, self.dc, self.group)  # the one backward collective; dc[n_ctx][0] = global loss numerator
             if not self.packed_step:
-                self.comm.all_reduce_sum(self.loss_sum)
-        elif self.dist:
-            self.D.reduce_scatter_rows(self.dC, self.dc, self.group)
-            if self.packed_step:
-                return
-            # the loss numerator (one float).  Plain call: it is enqueued behind the reduce-scatter on RCCL's stream and
-            # nothing on the host waits for it -- an async_op handle + wait() costs 3x the host time of the call itself
-            # (36 vs 11 us, scratch/dist_overhead.py)
-            self.D.all_reduce_sum(self.loss_sum, self.group)
+                # the loss numerator (one float).  Plain call: enqueued behind the reduce-scatter, nothing on the host waits for it
+                self.D.all_reduce_sum(self.loss_sum, self.group)
 
 
 def capture(hp, fn, repeat=1):
@@ -721,7 +713,7 @@ def main():
             wd0.daemon = True
             wd0.start()
             from dpr_scale_amd import dist as D
-            comm = D.try_direct_comm(dev)  # collective: all ranks get one, or all fall back to torch.distributed
+            comm = D.enable_direct_comm(dev)  # collective: all ranks get one, or all stay on torch.distributed (what the task calls)
             if comm is not None:
                 hp = HotPathStep(B, K, d, T, W, rank, dev, comm=comm, dist_mode=DM)
                 els = measure(hp.step)
@@ -860,7 +852,8 @@ def main():
     if DM:
         torch.cuda.synchronize()
         if comm is not None:
-            comm.close()
+            from dpr_scale_amd import dist as D2
+            D2.disable_direct_comm()
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     if DM:

@@ -1280,8 +1280,11 @@ int dprhot_rescale_grads(float* dQ, size_t n_dq, void* dC, size_t n_dc, int dc_k
   REQUIRE(n_dq % 8 == 0 && n_dc % 8 == 0, "counts must be multiples of 8 (n_dq=%zu n_dc=%zu)", n_dq, n_dc);
   REQUIRE(dc_kind == GC_FP32 || dc_kind == GC_BF16, "dc_kind=%d (2 fp32, 0 bf16)", dc_kind);
   REQUIRE(aligned16(dQ) && aligned16(dC), "pointers must be 16-byte aligned");
+  // the common case leaves after two scalar loads: as few workgroups as still stream at full rate when the scale did change
   const size_t groups = (n_dq + n_dc) / 8;
-  const dim3 grid(gc_blocks(groups / 4 + 1)), block(256);
+  int nb = gc_blocks(groups / 4 + 1);
+  if (nb > 2 * kNumCU) nb = 2 * kNumCU;
+  const dim3 grid(nb), block(256);
   if (dc_kind == GC_FP32) hipLaunchKernelGGL(rescale_grads_kernel<GC_FP32>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dC, n_dc / 8, go, used, out2);
   else hipLaunchKernelGGL(rescale_grads_kernel<GC_BF16>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dC, n_dc / 8, go, used, out2);
   HIP_TRY(hipGetLastError());
@@ -1354,7 +1357,7 @@ struct RcclApi {
   const char* (*GetErrorString)(int);
   bool ok;
 };
-constexpr int kRcclInt8 = 0, kRcclFloat32 = 7, kRcclSum = 0;
+constexpr int kRcclInt8 = 0, kRcclFloat16 = 6, kRcclFloat32 = 7, kRcclBfloat16 = 9, kRcclSum = 0;
 
 const RcclApi& rccl() {
   static const RcclApi api = []() {
@@ -1423,6 +1426,15 @@ int dprhot_reducescatter_dc(void* h, const float* send, float* recv, size_t coun
   REQUIRE(h && send && recv && count_per_rank > 0, "bad argument");
   DprhotComm* c = static_cast<DprhotComm*>(h);
   RCCL_TRY(rccl().ReduceScatter(send, recv, count_per_rank, kRcclFloat32, kRcclSum, c->comm, (hipStream_t)stream));
+  return DPRHOT_OK;
+}
+
+int dprhot_reducescatter_rows(void* h, const void* send, void* recv, size_t count_per_rank, int kind, void* stream) {
+  REQUIRE(h && send && recv && count_per_rank > 0, "bad argument");
+  REQUIRE(kind >= GC_BF16 && kind <= GC_FP32, "kind=%d (0 bf16, 1 fp16, 2 fp32)", kind);
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  const int dt = kind == GC_BF16 ? kRcclBfloat16 : (kind == GC_FP16 ? kRcclFloat16 : kRcclFloat32);
+  RCCL_TRY(rccl().ReduceScatter(send, recv, count_per_rank, dt, kRcclSum, c->comm, (hipStream_t)stream));
   return DPRHOT_OK;
 }
 

@@ -48,11 +48,76 @@ def _is_nccl(group):
     return dist.get_backend(group) == "nccl"
 
 
+# ---- the C ABI communicator as the path's transport (SURVEY.md section 8 b3 / e) ------------------------------------------------------
+_DIRECT = {}   # id(group) -> DirectComm, or False once its collective set-up has failed for that group
+_SIDE = {}     # device index -> the side HIP stream asynchronous collectives are issued on
+
+
+def _gkey(group):
+    return id(group) if group is not None else 0
+
+
+def direct_comm(group=None):
+    """The DirectComm registered for `group` by enable_direct_comm(), or None (lookup only: never collective)."""
+    c = _DIRECT.get(_gkey(group))
+    return c if c else None
+
+
+def enable_direct_comm(device, group=None):
+    """COLLECTIVE over `group`, once per group (DenseRetrieverTask calls it on every rank before the first training step): from then
+    on the path's all-gather, reduce-scatter and loss all-reduce are issued through the C ABI communicator -- synchronous ones on the
+    caller's stream (no hand-over to RCCL's stream and back), asynchronous ones on one side HIP stream with an event either way.
+    Returns the communicator, or None when any rank could not build it (every rank then keeps torch.distributed).
+    DPRHOT_DIRECT_RCCL=0 skips it."""
+    k = _gkey(group)
+    if k not in _DIRECT:
+        off = os.environ.get("DPRHOT_DIRECT_RCCL", "1") == "0"
+        _DIRECT[k] = (None if off else try_direct_comm(device, group)) or False
+    return direct_comm(group)
+
+
+def disable_direct_comm(group=None):
+    c = _DIRECT.pop(_gkey(group), None)
+    if c:
+        c.close()
+
+
+class _StreamWork:
+    """Handle of a collective issued on the side stream: wait() makes the CURRENT stream wait for it (the host never blocks)."""
+
+    def __init__(self, event, keep):
+        self.event, self.keep = event, keep
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        self.keep = None
+
+
+def _on_side_stream(fn, *tensors):
+    dev = tensors[0].device
+    side = _SIDE.get(dev.index)
+    if side is None:
+        side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))  # the operands were produced on the compute stream
+    with torch.cuda.stream(side):
+        fn()
+        ev = side.record_event()
+    for t in tensors:
+        t.record_stream(side)  # the caching allocator must not hand the memory out again before the side stream is done with it
+    return _StreamWork(ev, tensors)
+
+
 def all_gather_rows(send: torch.Tensor, out: torch.Tensor, group=None, async_op=False):
     """out[r*n:(r+1)*n] = send from rank r (equal n on every rank -- guaranteed upstream by
     ContiguousDistributedSampler padding, utils.py:48-60, and DPRTransform padding, dpr_transform.py:143-161)."""
     W, _ = world(group)
     assert out.shape[0] == W * send.shape[0], (out.shape, send.shape, W)
+    comm = direct_comm(group)
+    if comm is not None and send.is_cuda and not _allpairs():
+        if async_op:
+            return _on_side_stream(lambda: comm.all_gather_rows(send, out), send, out)
+        comm.all_gather_rows(send, out)
+        return None
     if _allpairs():
         s2, o2 = (send.view(torch.float16), out.view(torch.float16)) if (send.dtype == torch.bfloat16 and not _is_nccl(group)) else (send, out)
         if _is_nccl(group):  # grouped send/recv of the ONE send buffer to every peer: no staging copy
@@ -70,6 +135,12 @@ def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_
     W, r = world(group)
     n = out.shape[0]
     assert inp.shape[0] == W * n
+    comm = direct_comm(group)
+    if comm is not None and inp.is_cuda and not _allpairs() and inp.dtype == out.dtype and inp.dtype in comm.KINDS:
+        if async_op:
+            return _on_side_stream(lambda: comm.reduce_scatter_rows(inp, out), inp, out)
+        comm.reduce_scatter_rows(inp, out)
+        return None
     if _allpairs():
         tmp = torch.empty_like(inp)  # chunk k: what rank k computed for MY columns
         bytes_only = inp.dtype == torch.bfloat16 and not _is_nccl(group)
@@ -94,6 +165,10 @@ def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_
 
 
 def all_reduce_sum(t: torch.Tensor, group=None, async_op=False):
+    comm = direct_comm(group)
+    if comm is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and not async_op:
+        comm.all_reduce_sum(t)  # on the caller's stream: ordered behind the kernel that wrote it, in front of whoever reads it
+        return None
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
@@ -135,10 +210,13 @@ class DirectComm:
                                                            send.numel() * send.element_size(), self._stream()),
                         "dprhot_allgather_ctx")
 
+    KINDS = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
     def reduce_scatter_rows(self, inp, out):
-        assert inp.dtype == torch.float32 and out.dtype == torch.float32 and inp.numel() == self.W * out.numel()
-        self._lib.check(self._lib.lib.dprhot_reducescatter_dc(self.h, inp.data_ptr(), out.data_ptr(), out.numel(),
-                                                              self._stream()), "dprhot_reducescatter_dc")
+        assert inp.dtype == out.dtype and inp.dtype in self.KINDS and inp.numel() == self.W * out.numel()
+        assert inp.is_contiguous() and out.is_contiguous()
+        self._lib.check(self._lib.lib.dprhot_reducescatter_rows(self.h, inp.data_ptr(), out.data_ptr(), out.numel(), self.KINDS[inp.dtype],
+                                                                self._stream()), "dprhot_reducescatter_rows")
 
     def all_reduce_sum(self, t):
         assert t.dtype == torch.float32 and t.is_contiguous()

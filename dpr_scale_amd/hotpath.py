@@ -612,7 +612,8 @@ class InBatchContrastive(torch.autograd.Function):
         ctx.kn, ctx.group = kn, group
         ctx.dims = (W, r, B, d, n_ctx, rows_c)
         ctx.in_dtypes = (q.dtype, c.dtype)
-        ctx.eager, ctx.used, ctx.handed_out = eager, used, False
+        ctx.eager, ctx.used = eager, used
+        ctx.spare = (Qb, Cb, G) if (eager is not None and used is not None) else None
         ctx.pending = pending if W > 1 else None
         if eager is None:
             ctx.save_for_backward(Qb, Cb, G)
@@ -627,18 +628,21 @@ class InBatchContrastive(torch.autograd.Function):
         need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         go = grad_out.detach().reshape(1).float().contiguous()  # device scalar: AMP loss scale, no host sync
         if ctx.eager is not None and ctx.used is not None:
-            # computed in forward for grad_output = *ctx.used; ONE launch compares and only rescales when the scale really changed
+            # computed in forward for grad_output = *ctx.used; ONE launch compares and only rescales when the scale really changed.
+            # The tensors are handed to autograd and FORGOTTEN here: AccumulateGrad takes a gradient nobody else references as
+            # .grad itself, and clones it otherwise (one copy launch per step, 50 MB of traffic at cfg3 per rank).
             dQ, dC_part = ctx.eager
-            if not ctx.handed_out:
-                out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
-                ctx.used = out2[0:1]  # what the gradients are scaled by from here on
-                ctx.handed_out = True
-                _ExpectedGradScale.publish(go.device, out2[1:2])
-                go = None
-            else:
-                # a second backward through a retained graph: autograd may have kept the tensors handed out the first time as
-                # .grad itself, so they are never touched again -- fresh tensors, scaled by go / used (rare: plain torch ops)
-                go = go / ctx.used
+            ctx.eager = None
+            out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
+            ctx.used = None
+            _ExpectedGradScale.publish(go.device, out2[1:2])
+            go = None
+        elif ctx.spare is not None:
+            # a second backward through a retained graph: the first one gave its gradient tensors away; the backward GEMMs run
+            # again on the operands the step left behind (exact, rare)
+            Qb, Cb, G = ctx.spare
+            dQ, dC_part = kn.inbatch_bwd(G, Qb, Cb, 1.0, go, need_dq, need_dc)
+            go = None
         elif ctx.eager is not None:
             dQ, dC_part = ctx.eager  # computed in forward for grad_output = 1 (stand-in kernels); the scale is applied below
         elif ctx.dbg is not None:

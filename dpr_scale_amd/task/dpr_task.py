@@ -126,6 +126,15 @@ class DenseRetrieverTask(LightningModule):
         ring).  The wire format is the reference's fp16 by default (same flag, same numbers on the wire; the sum itself
         is fp32 here); DPRHOT_GRAD_WIRE=bf16 trades mantissa for fp32's exponent range, DPRHOT_GRAD_MODE=ring selects the
         reference's decomposition."""
+        if self._is_distributed() and hotpath.D.world(None)[0] > 1:
+            # the path's three collectives through the C ABI communicator (collective set-up with a self-check against
+            # torch.distributed; every rank keeps torch.distributed if any rank cannot build it)
+            try:
+                dev = next(self.parameters()).device
+            except StopIteration:
+                dev = None
+            if dev is not None and dev.type == "cuda":
+                hotpath.D.enable_direct_comm(dev)
         if self.fp16_grads:
             from .. import comm_hooks
 

@@ -293,6 +293,7 @@ int dprhot_grad_unpack(const void* full, int kind, float* bucket, size_t n, void
  *   dprhot_comm_init        COLLECTIVE over the W ranks, on the current HIP device; *h is the communicator handle
  *   dprhot_allgather_ctx    recv[r * bytes_per_rank ...] = rank r's send  (the packed context buffer of dprhot_pack_ctx)
  *   dprhot_reducescatter_dc recv[0 .. count_per_rank) = sum over ranks of send[rank * count_per_rank ...]  (fp32 dC partials)
+ *   dprhot_reducescatter_rows the same for dC partials of any storage kind (0 bf16, 1 fp16, 2 fp32: the wire formats of the backward)
  *   dprhot_allreduce_sum    in place, fp32 (the loss numerator)
  * One communicator per rank process, used from one thread; every rank issues the same calls in the same order. */
 int dprhot_comm_unique_id(void* id128);
@@ -300,6 +301,7 @@ int dprhot_comm_init(const void* id128, int W, int rank, void** h);
 int dprhot_comm_destroy(void* h);
 int dprhot_allgather_ctx(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 int dprhot_reducescatter_dc(void* h, const float* send, float* recv, size_t count_per_rank, void* stream);
+int dprhot_reducescatter_rows(void* h, const void* send, void* recv, size_t count_per_rank, int kind, void* stream);
 int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream);
 
 #ifdef __cplusplus

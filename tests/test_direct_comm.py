@@ -33,5 +33,29 @@ def test_direct_comm_one_rank_group_agrees_with_torch_distributed():
         torch.cuda.synchronize()
         assert torch.equal(out, send) and torch.equal(mine, part) and s.item() == 3.5
         comm.close()
+        # the product's transport: once enabled for the group, dist.all_gather_rows / reduce_scatter_rows / all_reduce_sum go through
+        # the communicator -- synchronously on the caller's stream, or on the side stream behind an event (async_op=True), for
+        # both wire formats of the backward
+        assert D.direct_comm() is None
+        assert D.enable_direct_comm(dev) is not None and D.direct_comm() is not None
+        for dt in (torch.float32, torch.bfloat16):
+            part = torch.randn(264, 768, device=dev).to(dt)
+            mine = torch.full_like(part, 7.0)
+            w = D.reduce_scatter_rows(part, mine, None, async_op=True)
+            assert isinstance(w, D._StreamWork)
+            w.wait()
+            out = torch.empty_like(send)
+            w2 = D.all_gather_rows(send, out, None, async_op=True)
+            w2.wait()
+            mine2 = torch.empty_like(part)
+            assert D.reduce_scatter_rows(part, mine2, None) is None
+            torch.cuda.synchronize()
+            assert torch.equal(mine, part) and torch.equal(mine2, part) and torch.equal(out, send)
+        s2 = torch.tensor([1.25], device=dev)
+        assert D.all_reduce_sum(s2) is None
+        torch.cuda.synchronize()
+        assert s2.item() == 1.25
+        D.disable_direct_comm()
+        assert D.direct_comm() is None
     finally:
         dist.destroy_process_group()

@@ -166,10 +166,11 @@ def test_task_training_step_overlapped_order_equals_plain_order():
         assert gmax > 0 and gdiff <= 1e-6 * gmax
 
 
-def _gpu_worker(rank, W, port, meta, q):
+def _gpu_worker(rank, W, port, meta, q, wire="fp32"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["DPRHOT_DC_WIRE"] = wire
     dist.init_process_group("gloo", rank=rank, world_size=W)
     from oracle.inbatch_oracle import synth_embeddings
     from dpr_scale_amd.hotpath import ContextGather, defer_context_grad, inbatch_contrastive_loss
@@ -192,14 +193,16 @@ def _gpu_worker(rank, W, port, meta, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_through_libdprhot_on_one_gpu_match_reference_ddp():
-    """The whole multi-rank operator -- pack kernel, early all-gather, mask unpack, one-call step (sim + softmax + both
-    backward GEMMs), scaled reduce-scatter, deferred context gradient -- with the real HIP kernels, two processes on
-    one device over gloo, against the reference's own 2-rank DDP fixture."""
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_two_ranks_through_libdprhot_on_one_gpu_match_reference_ddp(wire):
+    """The whole multi-rank operator -- pack kernel, early all-gather, one-call step (sim + softmax + both backward GEMMs, gradients
+    scaled for the expected grad_output and fixed up in backward), reduce-scatter in either wire format, deferred context gradient
+    (half-width wire: widened into the fp32 gradient after the wait) -- with the real HIP kernels, two processes on one device over
+    gloo, against the reference's own 2-rank DDP fixture."""
     meta, g = load_golden("w2_ddp")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, 29731, meta, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, 29731 if wire == "fp32" else 29733, meta, q, wire)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
