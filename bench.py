@@ -527,12 +527,42 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
     us = time_kernel(hp, hp.k_step, reps=20, iters=10)
     bn, bd, nd = float(B) * hp.Nc, float(B) * d, float(hp.Nc) * d
     algo = (4 * bd + 2 * nd + 4 * bn) + 6 * bn + (2 * bn + 2 * nd + 4 * bd) + (2 * bn + 2 * bd + 4 * nd)
+    # the same step as the autograd operator issues it under DDP: dprhot_train_step_packed_f32 (loss mean out of the kernel, dQ left
+    # as split-K slabs) + dprhot_rescale_grads (adds the slabs up, checks grad_output) -- with fp32 partials and with the bf16 wire of
+    # the reduce-scatter written by the dC epilogue (2 bytes instead of 4 per dC element: 53.8 MB of algorithmic traffic)
+    lib, _lib = hp.lib, hp._lib
+    nsl = _lib.train_dq_slabs(B, hp.Nc, d)
+    part = torch.empty((max(nsl, 1), B, d), dtype=torch.float32, device=dev)
+    out2 = torch.empty(2, dtype=torch.float32, device=dev)
+    op_us = {}
+    for wire, kind in (("fp32_wire", 2), ("bf16_wire", 0)):
+        dCw = hp.dC if kind == 2 else torch.empty((hp.Nc, d), dtype=torch.bfloat16, device=dev)
+
+        def train_step():
+            st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = lib.dprhot_train_step_packed_f32(P(hp.q), P(hp.Cb), P(hp.Qb), B, W, 0, hp.n_ctx, d, P(hp.y), hp.inv_T, hp.gscale, 1.0 / hp.Nq,
+                                                  P(hp.go), P(hp.row_loss), P(hp.row_lse), P(hp.loss_sum), P(hp.G), P(hp.dQ),
+                                                  P(part) if nsl > 0 else None, P(dCw), kind, P(hp.ws), hp.ws_bytes, st)
+            rc = rc or lib.dprhot_rescale_grads(P(hp.dQ), hp.dQ.numel(), P(part) if nsl > 0 else None, nsl, P(dCw), dCw.numel(), kind,
+                                                P(hp.go), P(hp.go), P(out2), st)
+            if rc:
+                _lib.check(rc, "train step")
+
+        try:
+            op_us[wire] = round(time_kernel(hp, train_step, reps=20, iters=10), 2)
+        except Exception as e:
+            op_us[wire] = repr(e)
     out = {"workload": f"cfg3 per rank: B={B} rows x Nc={hp.Nc} gathered columns (W={W} x {hp.rows_c} packed rows) x d={d}, "
                        "bf16 contexts resident, fp32 q in, fp32 dQ / dC_part out",
            "step_us": round(us, 2), "pairs_per_s_per_gpu": round(B / us * 1e6, 1), "bound": "hbm",
            "algorithmic_bytes": algo, "achieved": round(algo / us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(algo / us * 1e-3 / HBM_PEAK_GBS, 4), "flops": 6 * bn * d,
-           "mfma_frac": round(6 * bn * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+           "mfma_frac": round(6 * bn * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4),
+           "operator_path_step_us": op_us, "operator_path": "dprhot_train_step_packed_f32 (dQ slabs deferred) + dprhot_rescale_grads"}
+    if isinstance(op_us.get("fp32_wire"), float):
+        out["operator_path_frac_fp32_wire"] = round(algo / op_us["fp32_wire"] * 1e-3 / HBM_PEAK_GBS, 4)
+    if isinstance(op_us.get("bf16_wire"), float):
+        out["operator_path_frac_bf16_wire"] = round((algo - 2 * nd) / op_us["bf16_wire"] * 1e-3 / HBM_PEAK_GBS, 4)
     out["traffic"], out["traffic_source"] = None, None
     tfile = os.path.join(ROOT, "profiles", "cfg3rank_traffic.json")
     if (B, K, d, W) == (128, 8, 768, 8) and os.path.isfile(tfile):  # PMC bytes of this very call sequence (scripts/gpu_run.sh prof-rank)

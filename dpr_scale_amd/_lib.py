@@ -25,6 +25,8 @@ lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
 SIGNATURES = {
     "dprhot_version": (c_int, []),
     "dprhot_last_error": (c_char_p, []),
+    "dprhot_set_option": (c_int, [c_char_p, c_int]),
+    "dprhot_get_option": (c_int, [c_char_p, POINTER(c_int)]),
     "dprhot_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "dprhot_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_prep": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -68,13 +70,15 @@ SIGNATURES = {
                                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_pairwise_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dprhot_pairwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dprhot_train_dq_slabs": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
     "dprhot_train_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
-                                      c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                      c_void_p, c_size_t, c_void_p]),
+                                      c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_void_p, c_size_t, c_void_p]),
     "dprhot_train_step_packed_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_float,
-                                             c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                             c_void_p, c_size_t, c_void_p]),
-    "dprhot_rescale_grads": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                             c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                             c_int, c_void_p, c_size_t, c_void_p]),
+    "dprhot_rescale_grads": (c_int, [c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "dprhot_grad_pack": (c_int, [c_void_p, c_size_t, c_float, c_int, c_void_p, c_size_t, c_void_p]),
     "dprhot_grad_sum_shards": (c_int, [c_void_p, c_int, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     "dprhot_grad_unpack": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
@@ -109,6 +113,17 @@ def version() -> int:
     return lib.dprhot_version()
 
 
+def set_option(name: str, value: int):
+    """Process-wide test / A-B switch of the plans (include/dprhot.h); production never calls this."""
+    check(lib.dprhot_set_option(name.encode(), int(value)), f"dprhot_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    out = c_int(0)
+    check(lib.dprhot_get_option(name.encode(), ctypes.byref(out)), f"dprhot_get_option({name})")
+    return out.value
+
+
 def search_workspace_bytes(nq, chunk):
     out = c_size_t(0)
     check(lib.dprhot_search_workspace_bytes(int(nq), int(chunk), ctypes.byref(out)), "dprhot_search_workspace_bytes")
@@ -118,6 +133,12 @@ def search_workspace_bytes(nq, chunk):
 def packed_rows(n_ctx: int, d: int) -> int:
     out = c_int(0)
     check(lib.dprhot_packed_rows(n_ctx, d, ctypes.byref(out)), "dprhot_packed_rows")
+    return out.value
+
+
+def train_dq_slabs(B: int, Nc: int, d: int) -> int:
+    out = c_int(0)
+    check(lib.dprhot_train_dq_slabs(B, Nc, d, ctypes.byref(out)), "dprhot_train_dq_slabs")
     return out.value
 
 

@@ -82,6 +82,22 @@ struct LossScaleScope {
   ~LossScaleScope() { g_loss_scale = 1.0f; }
 };
 
+// dC_part as bf16 (the reduce-scatter's wire format written by the dC epilogue): set by dprhot_train_step_* for the plans that have
+// such an epilogue (the skinny step); every other plan refuses while it is set
+thread_local bool g_dc_bf16 = false;
+struct DcKindScope {
+  explicit DcKindScope(bool bf16) { g_dc_bf16 = bf16; }
+  ~DcKindScope() { g_dc_bf16 = false; }
+};
+
+// split-K partial sums of dQ left in a caller buffer (dprhot_train_step_*: the operator's backward launch adds them up): while set,
+// the skinny step writes its slabs there and skips its reduction launch
+thread_local float* g_dq_part = nullptr;
+struct DqPartScope {
+  explicit DqPartScope(float* p) { g_dq_part = p; }
+  ~DqPartScope() { g_dq_part = nullptr; }
+};
+
 #define HIP_TRY(expr)                                                                      \
   do {                                                                                     \
     hipError_t e_ = (expr);                                                                \
@@ -105,33 +121,37 @@ struct AttrOnce {
     if (!(cond)) return fail(DPRHOT_E_INVALID, __VA_ARGS__); \
   } while (0)
 
+// ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
+// the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
+enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_COUNT };
+struct OptDef { const char* name; int def; const char* what; };
+constexpr OptDef kOptDefs[OPT_COUNT] = {
+    {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
+    {"no_tr", 0, "1 swaps the LDS transpose read for plain 16-bit gathers (cross-check)"},
+    {"unfused_bwd", 0, "1 runs dC and dQ as two launches"},
+    {"big_min", 256, "fewest 256x256 tiles for which the large-shape kernels are chosen (0 = never; tests lower it)"},
+    {"no_nl", 0, "1 disables the no-logits forward"},
+    {"no_big_bwd", 0, "1 disables the 256x256 backward pair"},
+    {"no_skinny", 0, "1 disables the few-rows x many-contexts plan (skinny.h)"},
+    {"no_small_step", 0, "1 disables the fused softmax+backward kernel of the latency-bound shapes (step_small.h)"},
+    {"no_short", 0, "1 disables the short-row (K-split slab) forward"},
+    {"sk_cols", 0, "64 / 128 forces the sim unit width of the skinny plan, 0 = plan"},
+    {"search_unfused", 0, "1 materialises every chunk's scores in dprhot_search (no filter epilogue)"},
+    {"no_8pb", 0, "1 keeps the backward pair on gemm256.h instead of the phase-interleaved schedule"},
+};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0};
+inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-bool use_tr() {  // DPRHOT_NO_TR=1 swaps the LDS transpose read for plain 16-bit gathers (cross-check)
-  static const bool v = []() {
-    const char* e = getenv("DPRHOT_NO_TR");
-    return !(e && e[0] == '1');
-  }();
-  return v;
-}
+bool use_tr() { return opt(OPT_NO_TR) == 0; }
 
-int force_tile() {  // DPRHOT_TILE=0..5 pins the tile config of the single-GEMM launches (tuning / tests)
-  static const int v = []() {
-    const char* e = getenv("DPRHOT_TILE");
-    return e ? atoi(e) : -1;
-  }();
-  return v;
-}
+int force_tile() { return opt(OPT_TILE); }
 
-bool unfused_bwd() {  // DPRHOT_UNFUSED_BWD=1: dC and dQ as two launches (A/B of the horizontal fusion)
-  static const bool v = []() {
-    const char* e = getenv("DPRHOT_UNFUSED_BWD");
-    return e && e[0] == '1';
-  }();
-  return v;
-}
+bool unfused_bwd() { return opt(OPT_UNFUSED_BWD) != 0; }
 
 constexpr int kNumCU = 256;
 
@@ -142,13 +162,7 @@ constexpr int kBigTile = 6;
 constexpr TileSpec kTiles[kNumTiles] = {{128, 128, 64}, {64, 128, 64}, {64, 64, 64}, {32, 64, 64}, {32, 64, 256}, {32, 32, 256},
                                         {256, 256, 64}};
 
-int big_min_wgs() {  // DPRHOT_BIG_MIN: fewest 256x256 tiles for which the large-shape kernel is chosen (0 = never)
-  static const int v = []() {
-    const char* e = getenv("DPRHOT_BIG_MIN");
-    return e ? atoi(e) : 256;
-  }();
-  return v;
-}
+int big_min_wgs() { return opt(OPT_BIG_MIN); }
 bool big_ok(int M, int N, int K) {
   const long wgs = (long)((M + 255) / 256) * ((N + 255) / 256);
   return M > 128 && K % 64 == 0 && K >= 128 && big_min_wgs() > 0 && wgs >= big_min_wgs();
@@ -157,8 +171,7 @@ bool big_ok(int M, int N, int K) {
 // The phase-interleaved persistent 256x256 kernel (gemm8p.h) and the forward built on it that never stores the logits: same gate
 // as the 256x256 tile, plus an even number of K steps and operands addressable with 32-bit byte offsets.
 bool nl_ok(int M, int N, int K) {
-  static const bool off = getenv("DPRHOT_NO_NL") != nullptr;
-  return !off && force_tile() < 0 && big_ok(M, N, K) && K % 128 == 0 && (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
+  return !opt(OPT_NO_NL) && force_tile() < 0 && big_ok(M, N, K) && K % 128 == 0 && (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
 }
 
 // Tile for D[M,N] with contraction length K: the largest tile (BM capped by M) that still yields `want`
@@ -330,8 +343,7 @@ struct DqPlan { int tile, splits, kchunk; bool big; };
 // the 256x256 LDS-DMA backward pair (gemm256.h): both contraction lengths multiples of 64, enough 256-row blocks to
 // matter, operands addressable with 32-bit element offsets
 bool big_bwd_ok(int B, int Nc, int d) {
-  static const bool off = getenv("DPRHOT_NO_BIG_BWD") != nullptr;
-  if (off || force_tile() >= 0 || big_min_wgs() <= 0 || unfused_bwd()) return false;
+  if (opt(OPT_NO_BIG_BWD) || force_tile() >= 0 || big_min_wgs() <= 0 || unfused_bwd()) return false;
   if (B % 64 != 0 || Nc % 64 != 0) return false;
   if ((double)B * Nc >= 4.0e9 || (double)Nc * d >= 4.0e9) return false;
   const long units = (long)((Nc + 255) / 256 + (B + 255) / 256) * ((d + 255) / 256);
@@ -354,10 +366,6 @@ DqPlan dq_plan(int B, int Nc, int d) {
   if (B <= 32 && Nc >= 256) p.tile = 4;
   else if (B <= 256) p.tile = 2;
   else p.tile = 0;
-  {
-    static const int ft = []() { const char* e = getenv("DPRHOT_DQ_TILE"); return e ? atoi(e) : -1; }();
-    if (ft == 0 || ft == 2 || ft == 4) p.tile = ft;  // tuning aid
-  }
   const TileSpec ts = kTiles[p.tile];
   const int tiles = cdiv(B, ts.bm) * cdiv(d, ts.bn);
   const int ksteps = cdiv(Nc, ts.bk);
@@ -365,10 +373,6 @@ DqPlan dq_plan(int B, int Nc, int d) {
   const int min_steps = ts.bk >= 256 ? 1 : 2;
   if (splits > ksteps / min_steps) splits = ksteps / min_steps;
   if (splits > 16) splits = 16;  // bounds the fp32 slab traffic (splits * B * d * 4 bytes each way)
-  {
-    static const int forced = []() { const char* e = getenv("DPRHOT_DQ_SPLITS"); return e ? atoi(e) : 0; }();
-    if (forced > 0) splits = forced < ksteps ? forced : ksteps;  // tuning aid
-  }
   if (splits < 1) splits = 1;
   p.kchunk = cdiv(ksteps, splits) * ts.bk;
   p.splits = cdiv(Nc, p.kchunk);
@@ -382,9 +386,8 @@ int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >
 // (beyond that the per-unit recomputation of the row logsumexp from Nc / 128 tile values stops being cheap).
 struct SkPlan { bool ok; int nt, nts, scols, nrb, ksteps, nslices; };
 SkPlan sk_plan(int B, int Nc, int d) {
-  static const bool off = getenv("DPRHOT_NO_SKINNY") != nullptr;
-  static const int min_nc = []() { const char* e = getenv("DPRHOT_SKINNY_MIN_NC"); return e ? atoi(e) : 2048; }();
-  static const bool no_small = getenv("DPRHOT_NO_SMALL_STEP") != nullptr;  // tuning aid: lets the skinny plan take the small-step shapes
+  const bool off = opt(OPT_NO_SKINNY) != 0, no_small = opt(OPT_NO_SMALL_STEP) != 0;  // (no_small lets this plan take the small-step shapes)
+  constexpr int min_nc = 2048;
   SkPlan p{};
   p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
          Nc <= 16384 && (no_small || !(B <= SS_ROWS && Nc <= SS_MAXNC));
@@ -394,7 +397,7 @@ SkPlan sk_plan(int B, int Nc, int d) {
     // The narrow unit pays when the wide ones would leave most of the chip idle (B = 32 x Nc = 2112, cfg2 gathered over 8 ranks: 17
     // wide units, step 18.8 -> 17.6 us); with every CU busy it loses (cfg3 per rank, 260 wide units: sim 12.4 vs 11.0 us, and the G
     // launch then folds twice the tile statistics).  DPRHOT_SK_COLS=64 / 128 forces one.
-    static const int forced = []() { const char* e = getenv("DPRHOT_SK_COLS"); return e ? atoi(e) : 0; }();
+    const int forced = opt(OPT_SK_COLS);
     const bool few = cdiv(B, SK_ROWS) * cdiv(Nc, SK_COLS) < kNumCU / 2;
     const bool narrow = forced == 64 || (forced != 128 && few);
     p.scols = (narrow && cdiv(Nc, SK_SCOLS) <= 8 * SK_MAXG) ? SK_SCOLS : SK_COLS;
@@ -407,10 +410,6 @@ SkPlan sk_plan(int B, int Nc, int d) {
   if (ns < 1) ns = 1;         // units run next to the dC units, and fewer slices mean fewer partial sums to write and re-read
   if (ns > 64) ns = 64;   // bounds the fp32 partial traffic
   p.ksteps = cdiv(nk, ns);
-  {
-    static const int forced = []() { const char* e = getenv("DPRHOT_SK_KSTEPS"); return e ? atoi(e) : 0; }();  // tuning aid
-    if (forced > 0 && cdiv(nk, forced) <= 64) p.ksteps = forced;
-  }
   p.nslices = cdiv(nk, p.ksteps);
   return p;
 }
@@ -449,10 +448,7 @@ WsLayout ws_layout(int B, int Nc, int d) {
 // Forward plan, a pure function of the shape (both forward launches derive it independently).
 //  short rows (the BASELINE training shapes): sim split over K into `splits` slabs, softmax with the row in registers
 //  long rows: sim with per-tile statistics, then the streaming gfinal kernel
-bool no_short() {
-  static const bool v = []() { const char* e = getenv("DPRHOT_NO_SHORT"); return e && e[0] == '1'; }();
-  return v;
-}
+bool no_short() { return opt(OPT_NO_SHORT) != 0; }
 FwdPlan fwd_plan(int B, int Nc, int d) {
   FwdPlan p{};
   // wide: vocabulary-wide vectors (CITADEL router, d = 30522): the contraction is long and the logit matrix small -- the
@@ -467,10 +463,7 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
     return p;
   }
   p.tile = B <= 32 ? (d >= 256 ? 5 : 3) : 2;
-  if (wide && B >= 128) {  // tuning aid: tile of the vocabulary-wide sim (0 = 128x128, 1 = 64x128, 2 = 64x64)
-    static const int wt = getenv("DPRHOT_WIDE_TILE") ? atoi(getenv("DPRHOT_WIDE_TILE")) : 2;
-    if (wt >= 0 && wt <= 2) p.tile = wt;
-  }
+  if (wide && B >= 128) p.tile = 2;  // 64 x 64 (128 x 128 with twice the slabs measured within 5 %: the fp32 ingest is the limiter)
   const int bk = kTiles[p.tile].bk, ksteps = cdiv(d, bk);
   int splits = ksteps < 4 ? ksteps : 4;
   if (wide) {  // >= 2 workgroups per CU, at least 4 K steps each, at most 32 slabs of partial logits
@@ -557,8 +550,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   float* tile_lse = reinterpret_cast<float*>(ws + wl.part_m);
   float* gold = reinterpret_cast<float*>(ws + wl.gold);
   // packed layout whose ranks hold a whole number of sim tiles: only the real rows are multiplied (SkSimArgs::tiles_per_rank)
-  static const bool no_remap = getenv("DPRHOT_SK_NO_REMAP") != nullptr;  // A/B
-  const bool remap = !no_remap && g_packed.base != nullptr && g_packed.rows_c > g_packed.n_ctx && g_packed.n_ctx % sk.scols == 0 &&
+  const bool remap = g_packed.base != nullptr && g_packed.rows_c > g_packed.n_ctx && g_packed.n_ctx % sk.scols == 0 &&
                      Nc % g_packed.rows_c == 0;
   const int tpr = remap ? g_packed.n_ctx / sk.scols : 0;
   const int nts = remap ? (Nc / g_packed.rows_c) * tpr : sk.nts;
@@ -578,20 +570,20 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     default: return fail(DPRHOT_E_UNSUPPORTED, "skinny step: d=%d", d);
   }
   if (rc) return rc;
+  float* rl = row_loss ? row_loss : reinterpret_cast<float*>(ws + wl.rloss);  // the backward launch forms the loss from the row losses
   {
     const int parts = B >= 128 ? 2 : (B >= 64 ? 4 : 8);  // >= 256 workgroups; a part is at most 4 x 256 chunks of 8 columns
-    static const int gp = []() { const char* e = getenv("DPRHOT_SK_GPARTS"); return e ? atoi(e) : 0; }();  // tuning aid
-    int pp = gp > 0 ? gp : parts;
+    int pp = parts;
     while (cdiv(Nc / 8, pp) > 4 * SK_THREADS) pp *= 2;
-    SkGArgs g{S, tile_lse, gold, nts, B, Nc, y, y_offset, grad_scale, G, row_loss, row_lse, loss_sum, pp, g_loss_scale};
-    hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp + 1)), dim3(SK_THREADS), 0, st, g);
+    SkGArgs g{S, tile_lse, gold, nts, B, Nc, y, y_offset, grad_scale, G, rl, row_lse, pp};
+    hipLaunchKernelGGL(sk_g_kernel, dim3((unsigned)(B * pp)), dim3(SK_THREADS), 0, st, g);
     HIP_TRY(hipGetLastError());
   }
   {
-    float* part = reinterpret_cast<float*>(ws + wl.dq_part);
+    float* part = g_dq_part != nullptr ? g_dq_part : reinterpret_cast<float*>(ws + wl.dq_part);
     const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = sk.nt * (d / SK_DN);
-    SkBwdArgs b{G, Qb, Cb, B, Nc, d, h_scale, d_scale, dC_part, loss_sum, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0,
-                g_packed.n_ctx, sk.ksteps, sk.nslices, part, ndq_pad};
+    SkBwdArgs b{G, Qb, Cb, B, Nc, d, h_scale, d_scale, dC_part, rl, loss_sum, g_loss_scale, g_dc_bf16 ? 1 : 0,
+                g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, sk.ksteps, sk.nslices, part, ndq_pad};
     const size_t lds = sk_bwd_lds();
     static AttrOnce attr_done;
     if (!attr_done) {
@@ -600,9 +592,11 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     }
     hipLaunchKernelGGL(sk_bwd_kernel, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
     HIP_TRY(hipGetLastError());
-    const size_t n4 = (size_t)B * d / 4;
-    hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
-    HIP_TRY(hipGetLastError());
+    if (g_dq_part == nullptr) {  // (else the caller's finishing launch forms dQ from the slabs: dprhot_rescale_grads)
+      const size_t n4 = (size_t)B * d / 4;
+      hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
+      HIP_TRY(hipGetLastError());
+    }
   }
   return DPRHOT_OK;
 }
@@ -613,6 +607,26 @@ extern "C" {
 
 int dprhot_version(void) { return DPRHOT_VERSION; }
 const char* dprhot_last_error(void) { return g_err; }
+
+int dprhot_set_option(const char* name, int value) {
+  REQUIRE(name != nullptr, "NULL name");
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOptDefs[i].name) == 0) {
+      __atomic_store_n(&g_opt[i], value, __ATOMIC_RELAXED);
+      return DPRHOT_OK;
+    }
+  return fail(DPRHOT_E_INVALID, "unknown option '%s'", name);
+}
+
+int dprhot_get_option(const char* name, int* h_value) {
+  REQUIRE(name != nullptr && h_value != nullptr, "NULL pointer");
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOptDefs[i].name) == 0) {
+      *h_value = opt((OptId)i);
+      return DPRHOT_OK;
+    }
+  return fail(DPRHOT_E_INVALID, "unknown option '%s'", name);
+}
 
 int dprhot_workspace_bytes(int B, int Nc, int d, size_t* h_out) {
   REQUIRE(h_out != nullptr, "h_out is NULL");
@@ -817,7 +831,7 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
   float* S = static_cast<float*>(workspace);
   int* cand_j = reinterpret_cast<int*>(static_cast<char*>(workspace) + (size_t)nq * chunk * 4);
   int* cnt = reinterpret_cast<int*>(static_cast<char*>(workspace) + (size_t)nq * chunk * 8);
-  static const bool unfused = getenv("DPRHOT_SEARCH_UNFUSED") != nullptr;
+  const bool unfused = opt(OPT_SEARCH_UNFUSED) != 0;
   HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nq * sizeof(int), st));
   for (int64_t j0 = 0; j0 < n_ctx; j0 += chunk) {
     const int cols = (int)((n_ctx - j0 < chunk) ? (n_ctx - j0) : chunk);
@@ -1112,7 +1126,7 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     const int nbx1 = cdiv(d, G2_B), nby1 = cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
     a1.kchunk = B;  // dC: one K range (B % 64 == 0)
     const int grid = nbx1 * nby1 + nbx2 * nby2 * p.splits;
-    static const bool no8 = getenv("DPRHOT_NO_8PB") != nullptr;
+    const bool no8 = opt(OPT_NO_8PB) != 0;
     if (!no8 && B % 128 == 0 && Nc % 128 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9) {
       // the phase-interleaved schedule (gemm8pb.h): an even number of K steps per unit, byte offsets in 32 bits
       auto k8 = gemm8p_bwd_kernel<Epi8Scale>;
@@ -1142,9 +1156,8 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
 // launches: the sim GEMM (partial-logit slabs) and one kernel that does softmax-CE, dScores and both backward GEMMs;
 // every other shape runs the three launches of dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd.
 static bool small_step_ok(int B, int Nc, int d) {
-  static const bool off = getenv("DPRHOT_NO_SMALL_STEP") != nullptr;
   const FwdPlan fp = fwd_plan(B, Nc, d);
-  return !off && B <= SS_ROWS && Nc <= SS_MAXNC && d % 16 == 0 && fp.short_rows && fp.splits <= 4 && !unfused_bwd();
+  return !opt(OPT_NO_SMALL_STEP) && B <= SS_ROWS && Nc <= SS_MAXNC && d % 16 == 0 && fp.short_rows && fp.splits <= 4 && !unfused_bwd();
 }
 
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
@@ -1252,41 +1265,81 @@ static int gc_blocks(size_t groups) {
 }
 
 // ---- the step as the autograd operator runs it ----------------------------------------------------------------------------------
+static int train_dc_kind_ok(int dc_kind, int B, int Nc, int d) {
+  if (dc_kind == GC_FP32) return DPRHOT_OK;
+  if (dc_kind == GC_BF16 && sk_plan(B, Nc, d).ok) return DPRHOT_OK;  // the skinny step's dC units have a bf16 epilogue
+  return fail(DPRHOT_E_UNSUPPORTED, "train_step: dc_kind=%d at B=%d Nc=%d d=%d: this shape's plan writes fp32 dC_part only (ask for dc_kind = 2)", dc_kind,
+              B, Nc, d);
+}
+
+int dprhot_train_dq_slabs(int B, int Nc, int d, int* h_nslabs) {
+  REQUIRE(h_nslabs != nullptr, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  const SkPlan sk = sk_plan(B, Nc, d);
+  *h_nslabs = sk.ok ? sk.nslices : 0;  // the other plans either do not split dQ or combine it inside their last launch's shadow
+  return DPRHOT_OK;
+}
+
+static int train_dq_part_ok(const float* dq_part, int B, int Nc, int d) {
+  if (dq_part == nullptr) return DPRHOT_OK;
+  REQUIRE(aligned16(dq_part), "dq_part must be 16-byte aligned");
+  if (!sk_plan(B, Nc, d).ok) return fail(DPRHOT_E_INVALID, "train_step: dq_part given but B=%d Nc=%d d=%d leaves no slabs (dprhot_train_dq_slabs = 0)", B, Nc, d);
+  return DPRHOT_OK;
+}
+
 int dprhot_train_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
                           int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float loss_scale, const float* d_scale,
-                          float* row_loss, float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  if (dc_kind != GC_FP32) return fail(DPRHOT_E_UNSUPPORTED, "train_step: dc_kind=%d (2 = fp32 dC_part) at B=%d Nc=%d d=%d", dc_kind, B, Nc, d);
+                          float* row_loss, float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, float* dq_part, void* dC_part,
+                          int dc_kind, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  if (int rc = train_dc_kind_ok(dc_kind, B, Nc, d)) return rc;
+  if (int rc = train_dq_part_ok(dq_part, B, Nc, d)) return rc;
   LossScaleScope ls(loss_scale);
+  DcKindScope dk(dc_kind == GC_BF16);
+  DqPartScope dp(dq_part);
   return dprhot_inbatch_step_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, 1.0f, d_scale, nullptr, row_loss, row_lse,
                                  loss_out, G, dQ, static_cast<float*>(dC_part), workspace, workspace_bytes, stream);
 }
 
 int dprhot_train_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank, int n_ctx, int d,
                                  const int64_t* y, float inv_T, float grad_scale, float loss_scale, const float* d_scale, float* row_loss,
-                                 float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind, void* workspace,
-                                 size_t workspace_bytes, void* stream) {
-  if (dc_kind != GC_FP32) return fail(DPRHOT_E_UNSUPPORTED, "train_step_packed: dc_kind=%d (2 = fp32 dC_part) at B=%d W=%d n_ctx=%d d=%d", dc_kind, B, W, n_ctx, d);
+                                 float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, float* dq_part, void* dC_part, int dc_kind,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(W > 0 && n_ctx > 0 && d > 0 && d % 8 == 0, "bad argument W=%d n_ctx=%d d=%d", W, n_ctx, d);
+  int rows_c = 0;
+  if (int rc = dprhot_packed_rows(n_ctx, d, &rows_c)) return rc;
+  if (int rc = train_dc_kind_ok(dc_kind, B, W * rows_c, d)) return rc;
+  if (int rc = train_dq_part_ok(dq_part, B, W * rows_c, d)) return rc;
   LossScaleScope ls(loss_scale);
+  DcKindScope dk(dc_kind == GC_BF16);
+  DqPartScope dp(dq_part);
   return dprhot_inbatch_step_packed_f32(q, gathered, Qb, B, W, rank, n_ctx, d, y, inv_T, grad_scale, 1.0f, d_scale, row_loss, row_lse, loss_out,
                                         G, dQ, static_cast<float*>(dC_part), workspace, workspace_bytes, stream);
 }
 
-int dprhot_rescale_grads(float* dQ, size_t n_dq, void* dC, size_t n_dc, int dc_kind, const float* go, const float* used, float* out2,
-                         void* stream) {
+int dprhot_rescale_grads(float* dQ, size_t n_dq, const float* dq_part, int nslabs, void* dC, size_t n_dc, int dc_kind, const float* go,
+                         const float* used, float* out2, void* stream) {
   REQUIRE(go && used && out2, "NULL pointer");
   REQUIRE(out2 != go && out2 != used && out2 + 1 != go && out2 + 1 != used, "out2 must not alias go / used");
   REQUIRE((dQ != nullptr || n_dq == 0) && (dC != nullptr || n_dc == 0), "NULL gradient with a non-zero count");
   REQUIRE(n_dq % 8 == 0 && n_dc % 8 == 0, "counts must be multiples of 8 (n_dq=%zu n_dc=%zu)", n_dq, n_dc);
   REQUIRE(dc_kind == GC_FP32 || dc_kind == GC_BF16, "dc_kind=%d (2 fp32, 0 bf16)", dc_kind);
-  REQUIRE(aligned16(dQ) && aligned16(dC), "pointers must be 16-byte aligned");
+  REQUIRE(nslabs >= 0 && (nslabs == 0 || (dq_part != nullptr && n_dq > 0)), "nslabs=%d needs dq_part and dQ", nslabs);
+  REQUIRE(aligned16(dQ) && aligned16(dC) && aligned16(dq_part), "pointers must be 16-byte aligned");
   // the common case leaves after two scalar loads: as few workgroups as still stream at full rate when the scale did change
   const size_t groups = (n_dq + n_dc) / 8;
   int nb = gc_blocks(groups / 4 + 1);
   if (nb > 2 * kNumCU) nb = 2 * kNumCU;
+  int nqb = 0;
+  if (nslabs > 0) {  // one 16-byte group of dQ per thread: the slab loads of a group are the latency chain
+    nqb = (int)((n_dq / 8 + 255) / 256);
+    nb += nqb;
+  }
   const dim3 grid(nb), block(256);
-  if (dc_kind == GC_FP32) hipLaunchKernelGGL(rescale_grads_kernel<GC_FP32>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dC, n_dc / 8, go, used, out2);
-  else hipLaunchKernelGGL(rescale_grads_kernel<GC_BF16>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dC, n_dc / 8, go, used, out2);
+  if (dc_kind == GC_FP32)
+    hipLaunchKernelGGL(rescale_grads_kernel<GC_FP32>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dq_part, nslabs, nqb, dC, n_dc / 8, go, used, out2);
+  else
+    hipLaunchKernelGGL(rescale_grads_kernel<GC_BF16>, grid, block, 0, (hipStream_t)stream, dQ, n_dq / 8, dq_part, nslabs, nqb, dC, n_dc / 8, go, used, out2);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
 }

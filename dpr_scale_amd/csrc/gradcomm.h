@@ -170,20 +170,51 @@ __global__ __launch_bounds__(256) void grad_unpack_kernel(const void* __restrict
 // multiplied by go / used.  The first thread also publishes out2[0] = go (what the gradients are now scaled by) and out2[1] = the
 // value the NEXT forward should expect (go when it is a finite, normal, non-zero number, else 1).  out2 is a fresh 2-float buffer,
 // never one of the inputs: no workgroup can read a value another one has already replaced.
+// With nslabs > 0 the step left dQ as split-K partial slabs (dprhot_train_dq_slabs): workgroups [0, nqb) form dQ = go * sum of the
+// slabs in slab order (bit-reproducible) -- the reduction launch of the step rides in this one -- and the rest treat dC as above.
 template <int DCK>
-__global__ __launch_bounds__(256) void rescale_grads_kernel(float* __restrict__ dQ, size_t nq8, void* __restrict__ dC, size_t nc8,
-                                                            const float* __restrict__ go, const float* __restrict__ used,
-                                                            float* __restrict__ out2) {
+__global__ __launch_bounds__(256) void rescale_grads_kernel(float* __restrict__ dQ, size_t nq8, const float* __restrict__ dq_part, int nslabs,
+                                                            int nqb, void* __restrict__ dC, size_t nc8, const float* __restrict__ go,
+                                                            const float* __restrict__ used, float* __restrict__ out2) {
   const float g = go[0], u = used[0];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     out2[0] = g;
     const float a = fabsf(g);
     out2[1] = (a >= 1.17549435e-38f && a <= 3.0e38f) ? g : 1.0f;
   }
+  if (nslabs > 0 && (int)blockIdx.x < nqb) {
+    const size_t stride = (size_t)nqb * blockDim.x;
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nq8; c += stride) {
+      float acc[8];
+      gc_load8<GC_FP32>(dq_part, c, acc);
+      int z = 1;
+      for (; z + 3 < nslabs; z += 4) {  // four slabs' groups in flight
+        float v[4][8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) gc_load8<GC_FP32>(dq_part, (size_t)(z + w) * nq8 + c, v[w]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += v[w][e];
+      }
+      for (; z < nslabs; ++z) {
+        float v[8];
+        gc_load8<GC_FP32>(dq_part, (size_t)z * nq8 + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= g;
+      gc_store8<GC_FP32>(dQ, c, acc);
+    }
+    return;
+  }
   if (g == u) return;
   const float ratio = g / u;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < nq8 + nc8; c += stride) {
+  const int b0 = nslabs > 0 ? nqb : 0;
+  const size_t first = nslabs > 0 ? nq8 : 0;  // dQ is already exact when it came from the slabs
+  const size_t stride = (size_t)(gridDim.x - b0) * blockDim.x;
+  for (size_t c = first + (blockIdx.x - b0) * (size_t)blockDim.x + threadIdx.x; c < nq8 + nc8; c += stride) {
     float v[8];
     if (c < nq8) {
       gc_load8<GC_FP32>(dQ, c, v);

@@ -683,8 +683,10 @@ __global__ __launch_bounds__(256) void pairwise_bwd_kernel(const float* __restri
       c0 = c[row + k0];
       if (two) c1 = c[row + k0 + 1];
     }
-    a0 = fmaf(gj, c0, a0);
-    a1 = fmaf(gj, c1, a1);
+    if (gj != 0.f) {  // a masked pair takes no part at all: inf / NaN in a masked (dummy) context row must not reach dq as 0 * inf
+      a0 = fmaf(gj, c0, a0);
+      a1 = fmaf(gj, c1, a1);
+    }
     if (dc != nullptr) {
       if (vec) *reinterpret_cast<float2*>(dc + row + k0) = make_float2(gj * q0, gj * q1);
       else { dc[row + k0] = gj * q0; if (two) dc[row + k0 + 1] = gj * q1; }
@@ -913,7 +915,7 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
       int* hist = reinterpret_cast<int*>(si);  // 256 bins + 3 control words (the state is empty: its slots are free)
       auto key_of = [](float x) -> unsigned {
         if (x == 0.f) return 0x80000000u;
-        if (x != x) return 0u;  // NaN ranks last
+        if (x != x) return 0u;  // (NaN never reaches a histogram or the collecting pass: it never qualifies, as in the streaming scheme)
         const unsigned u = __float_as_uint(x);
         return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
       };
@@ -945,8 +947,10 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
       bool ok = false;
       for (int pass = 0; pass < 4; ++pass, shift -= 8) {
         hist[tid] = 0;
+        if (tid == 0) hist[256] = -1;
         __syncthreads();
         for_each([&](float x, int) {
+          if (x != x) return;  // NaN never qualifies
           const unsigned key = key_of(x);
           if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
         });
@@ -956,6 +960,7 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
         const int mine = hist[tid];
         if (above < need && need <= above + mine) { hist[256] = tid; hist[257] = need - above; hist[258] = mine; }
         __syncthreads();
+        if (hist[256] < 0) break;  // fewer than k values that are not NaN: the streaming scheme leaves the rest of the state empty
         prefix = (prefix << 8) | (unsigned)hist[256];
         need = hist[257];
         total = (k - need) + hist[258];  // strictly ahead of the bin + the bin itself
@@ -966,7 +971,7 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
         if (tid == 0) s_cnt = 0;
         __syncthreads();
         for_each([&](float x, int j) {
-          if ((key_of(x) >> shift) >= prefix) {
+          if (x == x && (key_of(x) >> shift) >= prefix) {
             const int pos = atomicAdd(&s_cnt, 1);
             sv[pos] = x;
             si[pos] = p.col_offset + j;

@@ -428,6 +428,12 @@ static void search_case(int nq, int n, int d, int k, int chunk, bool quantise, b
 int main(int argc, char** argv) {
   const bool timing = argc > 1 && strstr(argv[1], "time");
   const bool big = argc > 1 && strstr(argv[1], "big");
+  // this binary (not the library) reads the environment: DPRHOT_TILE / DPRHOT_NO_TR / DPRHOT_BIG_MIN -> dprhot_set_option
+  {
+    const char* const env_opt[3][2] = {{"DPRHOT_TILE", "tile"}, {"DPRHOT_NO_TR", "no_tr"}, {"DPRHOT_BIG_MIN", "big_min"}};
+    for (int i = 0; i < 3; ++i)
+      if (const char* e = getenv(env_opt[i][0])) dprhot_set_option(env_opt[i][1], atoi(e));
+  }
   printf("libdprhot version %d  DPRHOT_TILE=%s DPRHOT_NO_TR=%s\n", dprhot_version(), getenv("DPRHOT_TILE") ? getenv("DPRHOT_TILE") : "-",
          getenv("DPRHOT_NO_TR") ? getenv("DPRHOT_NO_TR") : "-");
   {

@@ -297,11 +297,9 @@ struct SkGArgs {
   int64_t y_offset;
   float grad_scale;
   uint16_t* G;            // [B][Nc] bf16
-  float* row_loss;        // optional
+  float* row_loss;        // [B] (required: the backward launch forms the loss from it)
   float* row_lse;         // optional
-  float* loss_sum;        // [1]
   int parts;              // workgroups per row
-  float loss_scale = 1.0f;
 };
 
 // logsumexp of one row from its tile values: 64 lanes of a wave, lane l takes groups l, l + 64 (nt <= 512)
@@ -333,12 +331,12 @@ __device__ __forceinline__ float sk_row_lse(const float* tile_lse, int nt, int B
   return mx + logf(sm);  // every lane holds the same bits (butterfly reductions)
 }
 
-// grid = B * parts + 1 workgroups: workgroup (row, part) turns its share of the row's logits into G.  Every wave derives the
-// row logsumexp itself (<= 2 KB of tile values); the last workgroup writes row_lse / row_loss / loss_sum for all rows.
+// grid = B * parts workgroups: workgroup (row, part) turns its share of the row's logits into G.  Every wave derives the row
+// logsumexp itself (<= 2 KB of tile values); part 0 publishes the row's logsumexp and loss.  The loss SUM over the rows is formed
+// by the backward launch (sk_bwd_kernel: 512 bytes of row losses, fixed order) -- the extra workgroup that used to fold all
+// B x nt tile values a second time was this launch's tail.
 __global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool loss_wg = (int)blockIdx.x == p.B * p.parts;  // the ONE extra workgroup: row_lse / row_loss / loss_sum of all rows, next to
-  if (!loss_wg) {                                         // (not after) the G workgroups -- as workgroup 0's second job it was the tail
+  const int tid = threadIdx.x, lane = tid & 63;
   const int row = blockIdx.x / p.parts, part = blockIdx.x - row * p.parts;
   const int cpr = p.Nc >> 3;                       // 8-column chunks per row
   const int per = (cpr + p.parts - 1) / p.parts;   // chunks of this part
@@ -354,7 +352,12 @@ __global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
     vb[k] = *reinterpret_cast<const float4*>(src + 4);
   }
   const int yi = reinterpret_cast<const int*>(p.y)[2 * row] + (int)p.y_offset;
+  const float gold = p.gold[row];
   const float lse = sk_row_lse(p.tile_lse, p.nt, p.B, row, lane);
+  if (part == 0 && tid == 0) {
+    p.row_loss[row] = lse - gold;  // (always a real buffer: the caller's or the workspace's -- the backward launch sums it)
+    if (p.row_lse) p.row_lse[row] = lse;
+  }
 #pragma unroll
   for (int k = 0; k < CPT; ++k) {
     const int ch = c_lo + tid + k * SK_THREADS;
@@ -371,56 +374,12 @@ __global__ __launch_bounds__(SK_THREADS) void sk_g_kernel(SkGArgs p) {
       *reinterpret_cast<uint4*>(p.G + (size_t)row * p.Nc + j) = make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
     }
   }
-  return;
-  }
-  {
-    // the loss of ALL rows: thread (row = tid & 127, half = tid >> 7) folds the tile groups half, half + 2, ... of its row
-    // (lanes = rows: coalesced 16-byte loads, all of them in flight at once); the halves meet in LDS; fixed-order sum
-    __shared__ float s_m[SK_MAXB], s_s[SK_MAXB], s_l[SK_MAXB];
-    const int lrow = tid & (SK_MAXB - 1), half = tid >> 7;
-    const bool row_ok = lrow < p.B;
-    const int ng = (p.nt + 3) >> 2;
-    float4 tv[SK_MAXG];
-#pragma unroll
-    for (int u = 0; u < SK_MAXG; ++u) {  // groups beyond ng re-read group 0 (dropped below by the t < nt tests): no branches
-      const int gq = half + 2 * u;
-      tv[u] = *reinterpret_cast<const float4*>(p.tile_lse + ((size_t)(gq < ng ? gq : 0) * p.B + (row_ok ? lrow : 0)) * 4);
-    }
-    const float gold = p.gold[row_ok ? lrow : 0];
-    float mx = -INFINITY, sm = 0.f;
-#pragma unroll
-    for (int u = 0; u < SK_MAXG; ++u) {
-      const int t = (half + 2 * u) * 4;
-      const float a = t + 0 < p.nt ? tv[u].x : -INFINITY, b = t + 1 < p.nt ? tv[u].y : -INFINITY;
-      const float c = t + 2 < p.nt ? tv[u].z : -INFINITY, e = t + 3 < p.nt ? tv[u].w : -INFINITY;
-      tv[u] = make_float4(a, b, c, e);
-      mx = fmaxf(mx, fmaxf(fmaxf(a, b), fmaxf(c, e)));
-    }
-    if (mx != -INFINITY) {
-#pragma unroll
-      for (int u = 0; u < SK_MAXG; ++u) sm += __expf(tv[u].x - mx) + __expf(tv[u].y - mx) + __expf(tv[u].z - mx) + __expf(tv[u].w - mx);
-    }
-    if (half == 1) { s_m[lrow] = mx; s_s[lrow] = sm; }
-    __syncthreads();
-    if (half == 0) {
-      const float m2 = s_m[lrow], s2 = s_s[lrow];
-      const float M = fmaxf(mx, m2);
-      float tot = 0.f;
-      if (M != -INFINITY) tot = sm * __expf(mx - M) + s2 * __expf(m2 - M);
-      const float ls = M + logf(tot);
-      s_l[lrow] = row_ok ? ls - gold : 0.f;
-      if (row_ok) {
-        if (p.row_lse) p.row_lse[lrow] = ls;
-        if (p.row_loss) p.row_loss[lrow] = ls - gold;
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      float a = s_l[lane] + s_l[lane + 64];
-      a = wave_sum(a);
-      if (lane == 0) p.loss_sum[0] = a * p.loss_scale;
-    }
-  }
+}
+
+// loss numerator = sum of the B <= 128 row losses in a fixed order (every wave that needs it computes the same bits)
+__device__ __forceinline__ float sk_loss_sum(const float* row_loss, int B, int lane) {
+  const float a = (lane < B ? row_loss[lane] : 0.f) + (lane + 64 < B ? row_loss[lane + 64] : 0.f);
+  return wave_sum(a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -433,9 +392,12 @@ struct SkBwdArgs {
   int B, Nc, d;
   float h_scale;
   const float* d_scale;
-  float* dC;              // [Nc][d]
-  const float* loss_sum;  // [1] (sk_g_kernel), read for the stamp
-  int stamp_period, stamp_row;  // > 0: dC[m][0] = loss numerator where m % stamp_period == stamp_row (EpiScaleF32)
+  void* dC;               // [Nc][d] fp32, or bf16 when dc_bf16 (the wire format of the reduce-scatter, written here)
+  const float* row_loss;  // [B] (sk_g_kernel)
+  float* loss_sum;        // [1] out: loss_scale * sum of the row losses (written by dC unit 0)
+  float loss_scale;
+  int dc_bf16;
+  int stamp_period, stamp_row;  // > 0 (fp32 dC only): dC[m][0] = loss_sum where m % stamp_period == stamp_row (EpiScaleF32)
   int ksteps;             // 64-context steps per dQ slice
   int nslices;
   float* part;            // [nslices][B][d] dQ partial sums
@@ -447,8 +409,10 @@ constexpr int SK_QA = SK_MAXB * 64;  // elements of the G part of a dQ slot  [12
 constexpr int SK_QB = 64 * SK_QN;    // elements of the C part of a dQ slot  [64 k][64 n]
 inline size_t sk_bwd_lds() {
   const size_t dc = (size_t)SK_COLS * SK_DC_TS * sizeof(float);  // dC: epilogue tile (>= G image + Q image)
-  const size_t dq = (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2;
-  return dc > dq ? dc : dq;
+  const size_t dq = (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2;      // ring; its epilogue tile [128][SK_QN + 4] fp32 is the dC one's size
+  const size_t dqe = (size_t)SK_MAXB * (SK_QN + 4) * sizeof(float);
+  const size_t m = dc > dq ? dc : dq;
+  return m > dqe ? m : dqe;
 }
 
 // dC unit = 128 contexts x 128 columns of d: dC[ct*128.., dt*128..] = G^T x Q over the B rows (B % 32 == 0).
@@ -478,8 +442,12 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
     }
   }
   const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
-  const bool stamp = dt == 0 && p.stamp_period > 0;
-  const float lsum = stamp ? p.loss_sum[0] : 0.f;
+  const bool stamp = dt == 0 && p.stamp_period > 0 && !p.dc_bf16;
+  float lsum = 0.f;
+  if (stamp || unit == 0) {
+    lsum = sk_loss_sum(p.row_loss, p.B, lane) * p.loss_scale;
+    if (unit == 0 && tid == 0) p.loss_sum[0] = lsum;
+  }
   DPRHOT_TMB(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -515,19 +483,37 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
       for (int r = 0; r < 4; ++r) T[(wm * 64 + a * 16 + g4 * 4 + r) * SK_DC_TS + wn * 64 + b * 16 + i16] = acc[a][b][r] * sc;
   __syncthreads();
   DPRHOT_TMB(1, 4);
+  if (p.dc_bf16) {  // 8 values per lane: whole 256-byte rows of bf16
+    uint16_t* const out = static_cast<uint16_t*>(p.dC);
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int e = tid + it * SK_THREADS, row = e >> 5, cq = e & 31;
-    const int m = n0 + row;
-    if (m < p.Nc) {
-      float4 v = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + cq * 4);
-      if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
-      *reinterpret_cast<float4*>(p.dC + (size_t)m * p.d + c0 + cq * 4) = v;
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + it * SK_THREADS, row = e >> 4, c8 = e & 15;
+      const int m = n0 + row;
+      if (m < p.Nc) {
+        const float4 a = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + c8 * 8 + 4);
+        *reinterpret_cast<uint4*>(out + (size_t)m * p.d + c0 + c8 * 8) = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
+      }
+    }
+  } else {
+    float* const out = static_cast<float*>(p.dC);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = tid + it * SK_THREADS, row = e >> 5, cq = e & 31;
+      const int m = n0 + row;
+      if (m < p.Nc) {
+        float4 v = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + cq * 4);
+        if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+        *reinterpret_cast<float4*>(out + (size_t)m * p.d + c0 + cq * 4) = v;
+      }
     }
   }
   DPRHOT_TMB(1, 5);
 }
 
+// (Round 3 measured the alternative -- 128 columns of d per unit, two 32 KiB ring slots, twice the slices: per-workgroup stamps
+//  K loop 7 steps x 0.9 us (only ONE step's DMA in flight behind the one being multiplied: a step waits a whole DMA latency),
+//  epilogue 2.7 us (64 KiB of partial sums leave one CU at ~24 GB/s), launch 14.3 us against 13.4 for this form.)
 // 64-wide mn-major image [k][64]: two k rows share a 256-byte bank row; the 32 lanes of a transpose read served together
 // touch rows k0..k0+3 and k0+8..k0+11 of one 32-byte column group, so group cg of row k sits at slot cg ^ sk_swz64(k)
 __device__ __forceinline__ int sk_swz64(int k) { return ((k >> 1) & 1) | (((k >> 3) & 1) << 1); }

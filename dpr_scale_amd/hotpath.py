@@ -68,6 +68,7 @@ class HipKernels:
         self._lib = _lib
         self.lib = _lib.lib
         self._ws = {}
+        self._nslabs = {}
 
     # -- plumbing --------------------------------------------------------------------------------------
     @staticmethod
@@ -226,10 +227,20 @@ class HipKernels:
             self._stream()), "dprhot_inbatch_step_packed_f32")
         return row_loss, row_lse, loss_sum, G, dQ, dC
 
-    def train_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32):
+    def _dq_slabs(self, B, Nc, d, dev):
+        """Caller-owned buffer for the split-K partial sums of dQ, or None when this shape's plan leaves none."""
+        key = (B, Nc, d)
+        n = self._nslabs.get(key)
+        if n is None:
+            n = self._nslabs[key] = self._lib.train_dq_slabs(B, Nc, d)
+        return torch.empty((n, B, d), dtype=torch.float32, device=dev) if n > 0 else None
+
+    def train_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32,
+                       defer_dq=False):
         """The operator's step (dprhot_train_step_f32): forward AND backward in one library call, the loss already multiplied by
         loss_scale, the gradients scaled by the DEVICE scalar d_scale (the grad_output backward() is expected to deliver).
-        Returns (row_loss, row_lse, loss_out [2], G, dQ, dC_part); loss_out[0] is the loss."""
+        Returns (row_loss, row_lse, loss_out [2], G, dQ, dC_part); loss_out[0] is the loss.  defer_dq: where the plan splits dQ over
+        the contexts, dQ comes back as (dQ buffer, slabs) and rescale_grads() adds the slabs up (one launch less in the step)."""
         self._require_gpu(q, c, Qb, Cb, y, colmask, d_scale)
         B, d = Qb.shape
         Nc = Cb.shape[0]
@@ -244,14 +255,16 @@ class HipKernels:
         G = torch.empty((B, Nc), dtype=_BF16, device=dev)
         dQ = torch.empty((B, d), dtype=f32, device=dev)
         dC = torch.empty((Nc, d), dtype=dc_dtype, device=dev)
+        part = self._dq_slabs(B, Nc, d, dev) if defer_dq else None
         ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
         self._lib.check(self.lib.dprhot_train_step_f32(
             _ptr(q), _ptr(c), _ptr(Qb), _ptr(Cb), B, Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T), float(grad_scale),
-            float(loss_scale), _ptr(d_scale), _ptr(row_loss), _ptr(row_lse), _ptr(loss_out), _ptr(G), _ptr(dQ), _ptr(dC),
+            float(loss_scale), _ptr(d_scale), _ptr(row_loss), _ptr(row_lse), _ptr(loss_out), _ptr(G), _ptr(dQ), _ptr(part), _ptr(dC),
             _KIND[dc_dtype], _ptr(ws), ws.numel(), self._stream()), "dprhot_train_step_f32")
-        return row_loss, row_lse, loss_out, G, dQ, dC
+        return row_loss, row_lse, loss_out, G, (dQ if part is None else (dQ, part)), dC
 
-    def train_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32):
+    def train_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32,
+                              defer_dq=False):
         """World size > 1 (dprhot_train_step_packed_f32): as train_step_f32 on the all-gathered packed buffer."""
         self._require_gpu(q, gathered, Qb, y, d_scale)
         B, d = Qb.shape
@@ -266,22 +279,27 @@ class HipKernels:
         G = torch.empty((B, Nc), dtype=_BF16, device=dev)
         dQ = torch.empty((B, d), dtype=f32, device=dev)
         dC = torch.empty((Nc, d), dtype=dc_dtype, device=dev)
+        part = self._dq_slabs(B, Nc, d, dev) if defer_dq else None
         ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
         self._lib.check(self.lib.dprhot_train_step_packed_f32(
             _ptr(q), _ptr(gathered), _ptr(Qb), B, int(W), int(rank), int(n_ctx), d, _ptr(y), float(inv_T), float(grad_scale),
-            float(loss_scale), _ptr(d_scale), _ptr(row_loss), _ptr(row_lse), _ptr(loss_out), _ptr(G), _ptr(dQ), _ptr(dC),
+            float(loss_scale), _ptr(d_scale), _ptr(row_loss), _ptr(row_lse), _ptr(loss_out), _ptr(G), _ptr(dQ), _ptr(part), _ptr(dC),
             _KIND[dc_dtype], _ptr(ws), ws.numel(), self._stream()), "dprhot_train_step_packed_f32")
-        return row_loss, row_lse, loss_out, G, dQ, dC
+        return row_loss, row_lse, loss_out, G, (dQ if part is None else (dQ, part)), dC
 
     def rescale_grads(self, dQ, dC, go, used):
         """backward() of the operator (dprhot_rescale_grads): the gradients were computed for grad_output = used; multiply by
         go / used only if they differ (decided on the device).  Returns out2: [0] what the gradients are scaled by now, [1] the
         scale the next forward should expect."""
-        self._require_gpu(dQ, dC, go, used)
+        part = None
+        if isinstance(dQ, tuple):  # (dQ buffer, split-K slabs left by a train step with defer_dq): summed here, scaled by go
+            dQ, part = dQ
+        self._require_gpu(dQ, part, dC, go, used)
         out2 = torch.empty(2, dtype=torch.float32, device=go.device)
         self._lib.check(self.lib.dprhot_rescale_grads(
-            _ptr(dQ), dQ.numel() if dQ is not None else 0, _ptr(dC), dC.numel() if dC is not None else 0,
-            _KIND[dC.dtype] if dC is not None else 2, _ptr(go), _ptr(used), _ptr(out2), self._stream()), "dprhot_rescale_grads")
+            _ptr(dQ), dQ.numel() if dQ is not None else 0, _ptr(part), part.shape[0] if part is not None else 0, _ptr(dC),
+            dC.numel() if dC is not None else 0, _KIND[dC.dtype] if dC is not None else 2, _ptr(go), _ptr(used), _ptr(out2),
+            self._stream()), "dprhot_rescale_grads")
         return out2
 
     def widen(self, src, dst):
@@ -578,12 +596,12 @@ class InBatchContrastive(torch.autograd.Function):
             used = _ExpectedGradScale.get(q.device)
             try:
                 row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
-                                                                                       1.0 / Nq, used, dc_dtype)
+                                                                                       1.0 / Nq, used, dc_dtype, defer_dq=True)
             except Exception as e:  # a plan without a bf16 dC epilogue: fp32 partials, rounded to the wire format in backward
                 if dc_dtype == torch.float32 or "dc_kind" not in str(e):
                     raise
                 row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
-                                                                                       1.0 / Nq, used, torch.float32)
+                                                                                       1.0 / Nq, used, torch.float32, defer_dq=True)
             eager, loss_is_mean = (dQ, dC_part), True
         elif W > 1 and packed_step:  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale)
@@ -593,7 +611,7 @@ class InBatchContrastive(torch.autograd.Function):
             # backward() only checks the grad_output it was given against the one the gradients were scaled by
             used = _ExpectedGradScale.get(q.device)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
-                                                                            inv_T, grad_scale, 1.0 / Nq, used)
+                                                                            inv_T, grad_scale, 1.0 / Nq, used, defer_dq=True)
             eager, loss_is_mean = (dQ, dC_part), True
         elif q_f32 and wants_grad and hasattr(kn, "inbatch_step_f32"):  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx,
@@ -634,6 +652,8 @@ class InBatchContrastive(torch.autograd.Function):
             dQ, dC_part = ctx.eager
             ctx.eager = None
             out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
+            if isinstance(dQ, tuple):
+                dQ = dQ[0]  # (the slabs have been added up into it)
             ctx.used = None
             _ExpectedGradScale.publish(go.device, out2[1:2])
             go = None

@@ -19,7 +19,8 @@
  *     asynchronously; no entry point synchronises with the host.
  *   - bf16 values travel as uint16_t bit patterns (round-to-nearest-even from fp32).
  *   - Return value: 0 = OK, <0 = error (DPRHOT_E_*); dprhot_last_error() returns a thread-local message.
- *     Functions are re-entrant; there is no global mutable state.
+ *     Functions are re-entrant; the only process-wide state is the explicit option table below (test / A-B switches that
+ *     production never touches) -- the library reads no environment variable.
  *   - Shapes: B = rows (queries) held by this rank, Nc = all columns (contexts) after the gather,
  *     d = hidden size.
  */
@@ -45,6 +46,14 @@ typedef uint16_t dprhot_bf16;
 
 int dprhot_version(void);
 const char* dprhot_last_error(void);
+
+/* Process-wide test / A-B switches of the shape plans (all default to "plan decides"; production never calls this).  Names:
+ *   tile (-1 | 0..5)   no_tr   unfused_bwd   big_min (256)   no_nl   no_big_bwd   no_skinny   no_small_step   no_short
+ *   sk_cols (0 | 64 | 128)   search_unfused   no_8pb
+ * Setting one changes the plans of every later call on every thread (workspace sizes included: query them after setting).
+ * DPRHOT_E_INVALID for an unknown name. */
+int dprhot_set_option(const char* name, int value);
+int dprhot_get_option(const char* name, int* h_value);
 
 /* Bytes of scratch the fused entry points (dprhot_inbatch_fwd/_bwd, dprhot_dq) need for this shape. */
 int dprhot_workspace_bytes(int B, int Nc, int d, size_t* h_out);
@@ -252,27 +261,32 @@ int dprhot_pairwise_bwd(const float* g, const float* q, const float* c, int B, i
  *   loss_scale   loss_out[0] = loss_scale * sum_i row_loss[i]: pass 1 / Nq_global and the mean of dpr_task.py:212 leaves the kernel
  *                ready (and the stamp of the packed form carries that value)
  *   d_scale      DEVICE scalar the gradients are scaled by (required): the grad_output the caller expects backward() to deliver
- *   dC_part      fp32 (dc_kind = 2), or bf16 (dc_kind = 0: the wire format of the reduce-scatter written by the dC epilogue itself;
- *                DPRHOT_E_UNSUPPORTED at shapes whose plan has no such epilogue -- the caller then asks for fp32)
+ *   dq_part      NULL, or -- when dprhot_train_dq_slabs(B, Nc, d) = n > 0 -- a caller buffer [n][B][d] fp32: the step then leaves
+ *                dQ as n unscaled split-K partial slabs there (dQ itself untouched) and skips its own reduction launch; the
+ *                caller's dprhot_rescale_grads forms dQ from them (the operator's backward launches that anyway)
+ *   dC_part      fp32 (dc_kind = 2), or bf16 (dc_kind = 0: the wire format of the reduce-scatter written by the dC epilogue itself,
+ *                no loss stamp; DPRHOT_E_UNSUPPORTED at shapes whose plan has no such epilogue -- the caller then asks for fp32)
  * No S_out, no h_scale (= 1). */
+int dprhot_train_dq_slabs(int B, int Nc, int d, int* h_nslabs);
 int dprhot_train_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
                           int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float loss_scale, const float* d_scale,
-                          float* row_loss, float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          float* row_loss, float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, float* dq_part, void* dC_part,
+                          int dc_kind, void* workspace, size_t workspace_bytes, void* stream);
 int dprhot_train_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank, int n_ctx, int d,
                                  const int64_t* y, float inv_T, float grad_scale, float loss_scale, const float* d_scale, float* row_loss,
-                                 float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, void* dC_part, int dc_kind, void* workspace,
-                                 size_t workspace_bytes, void* stream);
+                                 float* row_lse, float* loss_out, dprhot_bf16* G, float* dQ, float* dq_part, void* dC_part, int dc_kind,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* backward() of that operator: the gradients were computed for grad_output = *used; the autograd engine delivers *go.
- *   if (*go != *used)  dQ[0..n_dq) and dC[0..n_dc) are multiplied by *go / *used   (AMP's loss scale changes once in thousands of
- *                      steps; otherwise every workgroup reads two floats and leaves)
- *   out2[0] = *go   (what the gradients are now scaled by: `used` of a second backward through the same graph)
+ *   nslabs > 0         dQ[0..n_dq) = *go * sum of the nslabs slabs of dq_part, in slab order (bit-reproducible)
+ *   if (*go != *used)  dQ (nslabs == 0) and dC[0..n_dc) are multiplied by *go / *used   (AMP's loss scale changes once in thousands
+ *                      of steps; otherwise their workgroups read two floats and leave)
+ *   out2[0] = *go   (what the gradients are now scaled by)
  *   out2[1] = *go if it is a finite, normal, non-zero number, else 1   (the d_scale the next forward should expect)
  * out2 is a fresh 2-float buffer (never go / used).  dQ fp32, dC fp32 (dc_kind 2) or bf16 (0); either may be NULL with count 0;
  * counts are multiples of 8. */
-int dprhot_rescale_grads(float* dQ, size_t n_dq, void* dC, size_t n_dc, int dc_kind, const float* go, const float* used, float* out2,
-                         void* stream);
+int dprhot_rescale_grads(float* dQ, size_t n_dq, const float* dq_part, int nslabs, void* dC, size_t n_dc, int dc_kind, const float* go,
+                         const float* used, float* out2, void* stream);
 
 /* Gradient all-reduce of the encoder towers (reference: dpr_scale/task/dpr_task.py:90-92 registers torch's fp16_compress_hook on
  * the DDP model: bucket -> fp16 -> ONE ring all-reduce -> fp32).  The hook of dpr_scale_amd/comm_hooks.py moves a bucket as

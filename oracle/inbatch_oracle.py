@@ -207,3 +207,14 @@ def synth_embeddings(seed, B, K, d, dist="U", ragged_mask=False):
         mask = rng.random(B * K) < 0.05
         mask[pos_idx] = False
     return bf16_round(q), bf16_round(c), pos_idx, mask
+
+
+def synth_search(seed, nq, n, d):
+    """Retrieval inputs whose inner products are EXACT in fp16, in bf16-input MFMA arithmetic and in fp32 alike (entries in
+    {-1, -0.5, 0, 0.5, 1}: every score is a multiple of 0.25 below 2^6), so the reference's fp16 scores
+    (run_retrieval_pytorch.py:149) and the fp32 scores of the MI355X path are the same numbers, and only the order inside a tie
+    class is left to the implementation (torch.topk documents none; the frozen rule here is lower id first)."""
+    rng = np.random.default_rng(seed)
+    q = rng.integers(-2, 3, (nq, d)).astype(np.float32) / 2
+    c = rng.integers(-2, 3, (n, d)).astype(np.float32) / 2
+    return q, c

@@ -18,6 +18,7 @@ Cases (SURVEY.md section 8 notation, BASELINE.json configs):
   ties / nib / topk           rank metrics with ties, in_batch_negatives=False branch, top-k
   router_*                    CITADEL router loss (citadel_task.py:137-153, :240-262) at d = 30522, both sim_score modes
   router_gather_w2            citadel_task.py:97-135 distributed_gather on 2 real gloo ranks, ragged token lengths
+  search_ref                  run_retrieval_pytorch.py:141-176 search_index (fp16 einsum + topk, the batched loop and its tail)
 """
 import json
 import os
@@ -33,7 +34,7 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
 from oracle import ref_shim  # noqa: E402
-from oracle.inbatch_oracle import synth_embeddings  # noqa: E402
+from oracle.inbatch_oracle import synth_embeddings, synth_search  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 SEED0 = 1234
@@ -177,9 +178,24 @@ def router_fixtures():
                                              "shim); inputs = oracle.router_oracle.synth_gather_rank(seed, rank)"), **arrays)
 
 
+def search_fixture():
+    """f2: /root/reference/dpr_scale/run_retrieval_pytorch.py search_index, unmodified (oracle/ref_shim.py), on a 20 000-passage index:
+    the batched loop (3 full batches of 16 queries) and its tail (5 queries)."""
+    if not wanted("search_ref"):
+        return
+    nq, n, d, k, batch, seed = 53, 20000, 64, 100, 16, SEED0 + 700
+    q, c = synth_search(seed, nq, n, d)
+    scores, ids = ref_shim.reference_search_index(torch.from_numpy(q), torch.from_numpy(c).to(torch.float16), batch, k)
+    save("search_ref", dict(case="search_ref", nq=nq, n=n, d=d, k=k, batch=batch, seed=seed,
+                            source="reference run_retrieval_pytorch.py search_index (fp16 einsum + torch.topk on the CPU through the "
+                                   "shim); inputs = oracle.inbatch_oracle.synth_search(seed, nq, n, d)"),
+         scores=scores.numpy().astype(np.float32), ids=ids.numpy().astype(np.int64))
+
+
 def main():
     assert ref_shim.reference_available(), "needs /root/reference"
     router_fixtures()
+    search_fixture()
     torch.manual_seed(0)
     torch.set_num_threads(8)
 

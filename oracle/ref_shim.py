@@ -189,3 +189,49 @@ def reference_distributed_gather(query_repr, context_repr, mask, pos, teacher, r
     """citadel_task.py:97-135 on the calling gloo rank (an initialised process group is required)."""
     task = make_reference_citadel_task(distributed=True, rank=rank)
     return task.distributed_gather(query_repr, context_repr, mask, pos, teacher)
+
+
+# ---- SURVEY.md section 8 f2: brute-force retrieval, from the reference's own run_retrieval_pytorch.py -------------------------------
+def load_reference_search_index():
+    """Import search_index (run_retrieval_pytorch.py:141-176) from the reference tree, unmodified.  The module pulls in the data
+    modules (hydra, ujson, pytorch_lightning ...) at import time although search_index needs none of them: `ujson` is aliased to
+    json and `dpr_scale.datamodule.dpr` is replaced by a stub with the three dataset names the script imports.  The function sends
+    its operands to `.cuda(0)`; on this GPU-less container torch.Tensor.cuda is patched to the identity for the duration of a call
+    (fp16 einsum + topk then run on the CPU: same ops, same dtypes)."""
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    _install_stubs()
+    import json as _json
+
+    sys.modules.setdefault("ujson", _json)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    stub = types.ModuleType("dpr_scale.datamodule.dpr")
+    stub.CSVDataset = stub.QueryCSVDataset = stub.QueryTSVDataset = type("_Unused", (), {})
+    import dpr_scale.datamodule  # noqa: F401  (the reference's package)
+
+    saved = sys.modules.get("dpr_scale.datamodule.dpr")
+    sys.modules["dpr_scale.datamodule.dpr"] = stub
+    try:
+        import importlib
+
+        mod = importlib.import_module("dpr_scale.run_retrieval_pytorch")
+    finally:
+        if saved is not None:
+            sys.modules["dpr_scale.datamodule.dpr"] = saved
+        else:
+            sys.modules.pop("dpr_scale.datamodule.dpr", None)
+    assert os.path.realpath(mod.__file__).startswith(os.path.realpath(REFERENCE_ROOT))
+    return mod.search_index
+
+
+def reference_search_index(query_embs, corpus_embs, batch, topk):
+    """(scores, ids) exactly as the reference's search_index returns them (corpus_embs fp16, as build_index leaves the index)."""
+    fn = load_reference_search_index()
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        scores, ids = fn(query_embs, corpus_embs, batch, topk)
+    finally:
+        torch.Tensor.cuda = real_cuda
+    return torch.as_tensor(scores), torch.as_tensor(ids)

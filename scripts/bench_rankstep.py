@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from bench import HotPathStep, time_kernel  # noqa: E402
+from dpr_scale_amd import _lib  # noqa: E402
 
 
 def main():
@@ -19,7 +20,11 @@ def main():
     ap.add_argument("--shapes", default="128:8:768:8,64:2:1024:8,32:8:768:8")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--opt", action="append", default=[], help="name=value: dprhot_set_option before anything runs (A/B of the plans)")
     a = ap.parse_args()
+    for kv in a.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     for sh in a.shapes.split(","):
@@ -34,7 +39,7 @@ def main():
         algo = (4 * bd + 2 * nd + 4 * bn) + 6 * bn + (2 * bn + 2 * nd + 4 * bd) + (2 * bn + 2 * bd + 4 * nd)  # SURVEY 8(d), 3-kernel design
         print(json.dumps({"B": B, "K": K, "d": d, "W": W, "Nc": hp.Nc, "step_us": round(us, 2), "loss_sum": float(hp.loss_sum.item()),
                           "algorithmic_MB": round(algo / 1e6, 2), "hbm_frac": round(algo / us * 1e-3 / 8000.0, 4),
-                          "skinny": os.environ.get("DPRHOT_NO_SKINNY") is None}), flush=True)
+                          "skinny": not _lib.get_option("no_skinny")}), flush=True)
         del hp
         torch.cuda.empty_cache()
 

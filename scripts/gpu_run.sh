@@ -36,7 +36,7 @@ for task in "$@"; do
   arg=""; case "$task" in *:*) arg="${task#*:}"; arg="${arg//+/ }"; task="${task%%:*}";; esac
   echo "=== $task $arg"
   case "$task" in
-    tests)  ( timeout 2400 python -m pytest tests -m gpu -x -q ${arg:+-k "$arg"} ) > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -n 15 $OUT/pytest_gpu.txt ;;
+    tests)  ( timeout 1500 python -m pytest tests -m gpu -x -q --timeout 420 ${arg:+-k "$arg"} ) > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -n 15 $OUT/pytest_gpu.txt ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 3 ;;
     bench)  ( timeout 1500 python bench.py $arg ) > $OUT/bench_n1.log 2>&1; echo "bench rc=$?"; tail -n 1 $OUT/bench_n1.log > $OUT/bench_n1.json; cut -c1-1500 $OUT/bench_n1.json ;;
     prof-bench) three_passes bench r03_bench_cfg2 python $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --repeats 3 --only step --driver eager ;;

@@ -70,12 +70,24 @@ def test_argument_validation_is_host_side():
     assert lib.dprhot_workspace_bytes(1024, 8192, 768, ctypes.byref(small)) == 0 and small.value >= 1024 * 8192 * 4  # logits stored here
     # round 3: the operator's step, the grad_output fix-up, the gradient-hook legs
     assert lib.dprhot_train_step_f32(null, null, null, null, 4, 8, 64, null, 0, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
-                                     null, 2, null, 0, null) == -1
+                                     null, null, 2, null, 0, null) == -1
     assert lib.dprhot_train_step_f32(null, null, null, null, 4, 8, 64, null, 0, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
-                                     null, 1, null, 0, null) == -3  # fp16 partials: no such epilogue
+                                     null, null, 1, null, 0, null) == -3  # fp16 partials: no such epilogue
+    assert lib.dprhot_train_step_f32(null, null, null, null, 4, 8, 64, null, 0, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
+                                     null, null, 0, null, 0, null) == -3  # bf16 partials: only the skinny plan writes them
     assert lib.dprhot_train_step_packed_f32(null, null, null, 4, 2, 5, 8, 64, null, 1.0, 1.0, 1.0, null, null, null, null, null, null,
-                                            null, 2, null, 0, null) == -1
-    assert lib.dprhot_rescale_grads(null, 8, null, 0, 2, null, null, null, null) == -1
+                                            null, null, 2, null, 0, null) == -1
+    assert lib.dprhot_rescale_grads(null, 8, null, 0, null, 0, 2, null, null, null, null) == -1
+    n = ctypes.c_int(-1)
+    assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and 1 <= n.value <= 64  # cfg3 per rank: split-K slabs
+    assert lib.dprhot_train_dq_slabs(32, 256, 768, ctypes.byref(n)) == 0 and n.value == 0          # cfg2: dQ comes out whole
+    # explicit option table instead of environment variables
+    assert lib.dprhot_set_option(b"no_skinny", 1) == 0
+    assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and n.value == 0
+    assert lib.dprhot_get_option(b"no_skinny", ctypes.byref(n)) == 0 and n.value == 1
+    assert lib.dprhot_set_option(b"no_skinny", 0) == 0
+    assert lib.dprhot_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.dprhot_last_error()
+    assert b"getenv" not in open(_lib.LIB_PATH, "rb").read()  # the library reads no environment variable
     assert lib.dprhot_grad_pack(null, 8, 1.0, 0, null, 8, null) == -1
     buf = (ctypes.c_float * 16)()
     assert lib.dprhot_grad_pack(buf, 9, 1.0, 0, buf, 12, null) == -1 and b"n_padded" in lib.dprhot_last_error()  # n_padded % 8

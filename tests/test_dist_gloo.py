@@ -255,7 +255,7 @@ def test_eight_ranks_cfg3_operator_on_one_gpu_match_reference():
     procs = [ctx.Process(target=_gpu_worker_cfg3, args=(r, W, 29741, meta, q)) for r in range(W)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(W)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=240) for _ in range(W)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
     colsum = np.zeros(meta["d"], np.float64)

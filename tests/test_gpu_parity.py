@@ -314,6 +314,49 @@ def test_production_packed_step_every_rank_full_size(name, kn, dev):
     assert np.array_equal(ranks, g["ranks"][own * B:(own + 1) * B])
 
 
+@pytest.mark.parametrize("wire", ["fp32", "bf16"])
+def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
+    """dprhot_train_step_packed_f32 -- what the autograd operator runs under DDP -- for EVERY rank of cfg3 against the
+    reference's global step: the loss leaves the kernel as the mean (loss_scale = 1 / Nq), the gradients are scaled by a
+    DEVICE grad_output (here 8), and dC_part is written as fp32 or, for the bf16 wire of the reduce-scatter, as bf16 by the
+    dC epilogue itself (each partial rounded once; summed here in fp64 like the all-pairs reduce-scatter sums in fp32)."""
+    meta, g = load_golden("cfg3_Ur_T1")
+    W, B, K, d, T = meta["W"], meta["B"], meta["K"], meta["d"], meta["T"]
+    own, n_ctx = meta["own_rank"], B * K
+    parts, rows_c, Cb = _packed_world(meta, kn, dev)
+    inv_T, go = 1.0 / T, 8.0
+    dt = torch.float32 if wire == "fp32" else torch.bfloat16
+    d_scale = torch.full((1,), go, device=dev)
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
+    loss, dq_own = 0.0, None
+    for r in range(W):
+        rl, lse, lo, G, dq, dcp = kn.train_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), inv_T,
+                                                           inv_T / (W * B), 1.0 / (W * B), d_scale, dt)
+        assert dcp.dtype == dt
+        dC += dcp.double()
+        loss += lo[0].item()  # the all-reduce of the per-rank means
+        assert abs(lo[0].item() * W * B - rl.double().sum().item()) <= 1e-5 * max(1.0, rl.double().sum().item())
+        if r == own:
+            dq_own = dq.cpu().numpy() / go
+            # the same step with dQ left as split-K slabs, finished by the operator's backward launch (here with a grad_output that
+            # differs from the expected one: dQ = go2 * sum of the slabs, dC rescaled by go2 / go)
+            go2 = torch.full((1,), 2.0, device=dev)
+            _, _, _, _, dq_def, dcp2 = kn.train_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), inv_T,
+                                                                inv_T / (W * B), 1.0 / (W * B), d_scale, dt, defer_dq=True)
+            assert isinstance(dq_def, tuple) and dq_def[1].shape[0] == kn._lib.train_dq_slabs(B, W * rows_c, d) >= 1
+            out2 = kn.rescale_grads(dq_def, dcp2, go2, d_scale)
+            assert out2.tolist() == [2.0, 2.0]
+            assert rel(dq_def[0].cpu().numpy() / 2.0, dq_own) <= 1e-5
+            assert rel(dcp2.float().cpu().numpy() / 2.0, dcp.float().cpu().numpy() / go) <= (1e-6 if wire == "fp32" else 8e-3)
+    assert abs(loss - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+    assert rel(dq_own, g["dq_own"]) <= GRAD_RTOL
+    chunk = dC.cpu().numpy().reshape(W, rows_c, d)[own] / go
+    assert rel(chunk[:64], g["dc_own_head"]) <= GRAD_RTOL
+    assert rel(chunk[:n_ctx].sum(1), g["dc_own_rowsum"]) <= GRAD_RTOL
+    assert rel(chunk[:n_ctx].sum(0), g["dc_own_colsum"]) <= GRAD_RTOL
+
+
 def test_selftest_big_passes():
     """The stand-alone C ABI self-test (csrc/selftest.hip) including its cfg3-per-rank (128 x 8192 x 768) and 1M-passage
     search cases, executed as the binary a C caller would link."""

@@ -1,0 +1,56 @@
+"""SURVEY.md section 8 f2 pinned to the reference: tests/golden/search_ref.npz holds what /root/reference/dpr_scale/
+run_retrieval_pytorch.py::search_index (:141-176, fp16 einsum + torch.topk; run unmodified through oracle/ref_shim.py) returns
+for a 20 000-passage index whose inner products are exact in every arithmetic involved.  Scores must agree bit for bit; ids must
+agree wherever the reference's order is defined (strictly different scores), and inside a tie class -- where torch.topk promises
+nothing -- the path's frozen rule (lower id first) is checked against a full recomputation."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import inbatch_oracle as O
+
+
+def _check(values, indices, q, c, z, k):
+    values, indices = np.asarray(values, np.float64), np.asarray(indices, np.int64)
+    ref_s, ref_i = z["scores"].astype(np.float64), z["ids"]
+    assert values.shape == ref_s.shape == (q.shape[0], k)
+    assert np.array_equal(values, ref_s)  # same numbers, same order (descending)
+    S = q.astype(np.float64) @ c.astype(np.float64).T  # exact
+    for r in range(q.shape[0]):
+        assert np.array_equal(S[r, indices[r]], values[r])            # every id really has its score
+        assert np.array_equal(S[r, ref_i[r]], ref_s[r])               # (and so does the reference's)
+        kth = values[r, -1]
+        above = values[r] > kth
+        assert set(indices[r, above]) == set(ref_i[r, ref_s[r] > kth])  # everything strictly above the k-th score: same passages
+        # frozen tie rule: stable descending order = score desc, id asc
+        order = np.lexsort((np.arange(S.shape[1]), -S[r]))[:k]
+        assert np.array_equal(indices[r], order)
+
+
+def test_search_over_shards_with_the_standin_kernels_equals_the_reference():
+    from _oracle_kernels import OracleKernels
+    from dpr_scale_amd.hotpath import CorpusSearch
+
+    meta, z = load_golden("search_ref")
+    q, c = O.synth_search(meta["seed"], meta["nq"], meta["n"], meta["d"])
+    s = CorpusSearch(torch.from_numpy(q), meta["k"], chunk=4096, kernels=OracleKernels())
+    for lo in range(0, meta["n"], 7001):  # ragged shards
+        s.add(torch.from_numpy(c[lo:lo + 7001]), lo)
+    v, i = s.result()
+    _check(v.numpy(), i.numpy(), q, c, z, meta["k"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk,shard", [(4096, 7001), (8192, 20000), (1024, 5000)])
+def test_search_on_the_hip_path_equals_the_reference(chunk, shard):
+    from dpr_scale_amd.hotpath import CorpusSearch
+
+    dev = torch.device("cuda:0")
+    meta, z = load_golden("search_ref")
+    q, c = O.synth_search(meta["seed"], meta["nq"], meta["n"], meta["d"])
+    s = CorpusSearch(torch.from_numpy(q).to(dev), meta["k"], chunk=chunk)
+    for lo in range(0, meta["n"], shard):
+        s.add(torch.from_numpy(c[lo:lo + shard]).to(dev), lo)
+    v, i = s.result()
+    _check(v.cpu().numpy(), i.cpu().numpy(), q, c, z, meta["k"])
