@@ -186,7 +186,9 @@ __device__ __forceinline__ void g2_tile_once(const GemmArgs& p, const Epi& epi, 
   const int kbeg = bz * p.kchunk;
   const int kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg) / G2_BK;
-  float* const scratch = reinterpret_cast<float*>(smem + 4 * G2_TILE);
+  // one workgroup per tile: when finish() runs (behind the barrier that ends the K loop) the operand images are dead, and the whole
+  // tile memory is the epilogue's scratch (EpiScaleF32 stages 8 waves x 16 x 68 floats there)
+  float* const scratch = reinterpret_cast<float*>(smem);
 
   f32x4 acc[TM][TN];
 #pragma unroll

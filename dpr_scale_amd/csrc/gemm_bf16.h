@@ -691,25 +691,44 @@ struct EpiScaleF32 {
   __device__ __forceinline__ float settle(const TileCtx&, float ds) const {
     return h_scale * ds;
   }
+  // Through LDS, one 16-row block of the wave's tile at a time (the tile memory is free by now; each wave has its own 16 x (WN_COLS + 4)
+  // fp32 patch, so no barrier is needed): the MFMA layout gives a lane one column of four rows -- stored as it is, that is a 4-byte
+  // store per value in 64-byte runs (6x the time per byte of a 16-byte store, MI355X_MICROARCH.md; the router-width backward, 141 MB of
+  // fp32 gradients, spent 67 us there) -- the patch is read back as float4: 16 lanes cover 256 contiguous bytes of one row.
   template <int BM, int BN, int WM, int WN, int TM, int TN>
   __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, float s) const {
+    constexpr int WC = TN * 16, TS = WC + 4;  // columns of the wave's tile, patch row stride
     const int i = c.lane & 15, g = c.lane >> 4;
     float* o = out + (size_t)c.bz * M * N;
+    float* const T = c.scratch + (c.wm * WN + c.wn) * (16 * TS);
+    const int nw0 = c.n0 + c.wn * (BN / WN);
+    const float stamp = stamp_src != nullptr ? *stamp_src : 0.f;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a) {
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int m = c.m0 + c.wm * (BM / WM) + a * 16 + g * 4;
-        const int n = c.n0 + c.wn * (BN / WN) + b * 16 + i;
-        if (n >= N) continue;
+      for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (m + r < M) {
-            float v = acc[a][b][r] * s;
-            if (n == 0 && stamp_src != nullptr && (m + r) % stamp_period == stamp_row) v = *stamp_src;
-            o[(size_t)(m + r) * N + n] = v;
+        for (int r = 0; r < 4; ++r) T[(g * 4 + r) * TS + b * 16 + i] = acc[a][b][r] * s;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      const int mb = c.m0 + c.wm * (BM / WM) + a * 16;
+#pragma unroll
+      for (int it = 0; it < TN; ++it) {  // 16 rows x WC / 4 float4 = 64 lanes x TN
+        const int e = c.lane + it * 64, row = e / (WC / 4), cq = e % (WC / 4);
+        const int m = mb + row, n = nw0 + cq * 4;
+        float4 v = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
+        if (m < M && n < N) {
+          if (n == 0 && stamp_src != nullptr && m % stamp_period == stamp_row) v.x = stamp;
+          if (n + 3 < N) {
+            *reinterpret_cast<float4*>(o + (size_t)m * N + n) = v;
+          } else {  // ragged N (not a multiple of 4): never for dQ / dC (N = d, a multiple of 8)
+            o[(size_t)m * N + n] = v.x;
+            if (n + 1 < N) o[(size_t)m * N + n + 1] = v.y;
+            if (n + 2 < N) o[(size_t)m * N + n + 2] = v.z;
           }
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // the patch is rewritten by the next block only after these reads
+    }
   }
 };
 

@@ -444,6 +444,32 @@ def test_streaming_topk_adversarial_orders(pattern, k, kn, dev):
     assert torch.equal(i2, order) and torch.equal(v2, v)
 
 
+@pytest.mark.parametrize("k", [64, 300, 1000])
+def test_topk_never_selects_nan_whatever_the_start_up_path(k, kn, dev):
+    """A NaN score never qualifies: with fewer than k other values in a row the remaining slots stay empty (-inf / -1) -- the same
+    answer from the counting start (k <= 256), the radix-select start (k > 256, >= 4096 columns) and the streaming update."""
+    rows, cols = 6, 8192
+    gen = torch.Generator(device="cpu").manual_seed(k)
+    S = torch.randn(rows, cols, generator=gen)
+    keep = [k + 40, k, k - 1, 5, 0, cols]  # finite values per row
+    for r, n in enumerate(keep):
+        idx = torch.randperm(cols, generator=gen)[n:]
+        S[r, idx] = float("nan")
+    v, i = kn.topk(S.to(dev), k)
+    v, i = v.cpu(), i.cpu()
+    vv, ii = torch.empty((rows, k), device=dev), torch.empty((rows, k), dtype=torch.int64, device=dev)
+    Sd = S.to(dev).contiguous()
+    kn.topk_update(Sd[:, :4096].contiguous(), 4096, 0, vv, ii, True)   # the same row folded in two pieces
+    kn.topk_update(Sd[:, 4096:].contiguous(), 4096, 4096, vv, ii, False)
+    for r, n in enumerate(keep):
+        fin = torch.nan_to_num(S[r], nan=float("-inf"))
+        order = torch.sort(fin, descending=True, stable=True).indices[:min(n, k)]
+        m = order.numel()
+        assert torch.equal(i[r, :m], order) and torch.equal(v[r, :m], S[r, order]), (k, r)
+        assert torch.all(i[r, m:] == -1) and torch.all(v[r, m:] == float("-inf")), (k, r)
+        assert torch.equal(ii[r].cpu(), i[r]) and torch.equal(vv[r].cpu(), v[r]), (k, r)
+
+
 def test_topk_state_with_fewer_columns_than_k(kn, dev):
     S = torch.tensor([[1.0, 3.0, 2.0, 3.0]], device=dev)
     v = torch.empty((1, 6), device=dev)
