@@ -926,18 +926,47 @@ class CorpusSearch:
     The [nq, n] score matrix never exists: each `chunk` of passages is scored on the bf16 MFMA path and folded
     into the running top-k on the device (dprhot_search)."""
 
+    KMAX = 1024  # largest k of the streaming top-k kernels (include/dprhot.h); run_retrieval_pytorch.py:149 accepts any --topk
+
     def __init__(self, query_embs, k, chunk=None, kernels=None):
         self.kn = kernels if kernels is not None else default_kernels()
         nq, d = query_embs.shape
         self.Qb = self.kn.empty((nq, d), _BF16, query_embs)
         self.kn.cast_bf16(query_embs, self.Qb)
+        self.k = int(k)
+        self.wide_k = self.k > self.KMAX
         if chunk is None:  # keep the score chunk around 256 MiB
             chunk = max(1024, min(65536, (1 << 26) // max(nq, 1) // 8 * 8))
         self.chunk = int(chunk) // 8 * 8
-        self.values = torch.empty((nq, k), dtype=torch.float32, device=query_embs.device)
-        self.indices = torch.empty((nq, k), dtype=torch.int64, device=query_embs.device)
-        self.ws = self.kn.search_workspace(nq, self.chunk, query_embs)
+        self.values = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=query_embs.device)
+        self.indices = torch.full((nq, k), -1, dtype=torch.int64, device=query_embs.device)
+        self.ws = None if self.wide_k else self.kn.search_workspace(nq, self.chunk, query_embs)
         self.first = True
+
+    def _add_wide(self, Cb, first_id):
+        """k beyond the kernels' 1024: the scores still come from the MFMA path chunk by chunk (dprhot_sim_fwd), the selection is
+        torch's: the chunk's own top-k, then state + chunk sorted in the same total order (score desc, id asc) -- two stable sorts,
+        ids first -- so that the result equals dprhot_topk of the whole matrix for any k.  Exact and rarely used (the reference's
+        recipes stop at --topk 1000); not a hand-written kernel."""
+        n, d = Cb.shape
+        for j0 in range(0, n, self.chunk):
+            cols = min(self.chunk, n - j0)
+            pad = (-cols) % 8
+            blk = Cb[j0:j0 + cols]
+            if pad:
+                blk = torch.cat([blk, torch.zeros((pad, d), dtype=_BF16, device=Cb.device)], 0)
+            S = self.kn.sim(self.Qb, blk.contiguous(), None, 1.0)[:, :cols]
+            kk = min(self.k, cols)
+            order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :kk]  # ties: lower column first
+            v = torch.gather(S, 1, order)
+            ids = order + (first_id + j0)
+            allv, alli = torch.cat([self.values, v], 1), torch.cat([self.indices, ids], 1)
+            alli_key = torch.where(alli < 0, torch.full_like(alli, torch.iinfo(torch.int64).max), alli)  # empty slots last
+            o1 = torch.sort(alli_key, dim=1, stable=True).indices
+            allv, alli = torch.gather(allv, 1, o1), torch.gather(alli, 1, o1)
+            o2 = torch.sort(allv, dim=1, descending=True, stable=True).indices[:, :self.k]
+            self.values, self.indices = torch.gather(allv, 1, o2).contiguous(), torch.gather(alli, 1, o2).contiguous()
+        self.first = False
 
     def add(self, corpus_embs, first_id=0):
         n, d = corpus_embs.shape
@@ -946,6 +975,8 @@ class CorpusSearch:
         else:
             Cb = self.kn.empty((n, d), _BF16, corpus_embs)
             self.kn.cast_bf16(corpus_embs, Cb)
+        if self.wide_k:
+            return self._add_wide(Cb, first_id)
         n8 = n // 8 * 8
         if n8:
             self.kn.search(self.Qb, Cb[:n8], first_id, self.values, self.indices, self.first, self.chunk, self.ws)

@@ -309,12 +309,11 @@ class DenseRetrieverTask(LightningModule):
             self._eval_epoch_end(test_outputs, "test")
 
     def to_torchscript(self, file_path=None, method="script", example_inputs=None, **kwargs):
-        """TorchScript export of the encoders (reference :325-368) is encoder packaging, outside the hot path
-        (SURVEY.md section 2 #8); it is delegated to the reference's own ScriptEncoder when that is installed."""
-        try:
-            from dpr_scale.utils.utils import ScriptEncoder  # the reference package, if present
-        except ImportError as e:
-            raise NotImplementedError("to_torchscript needs dpr_scale.utils.utils.ScriptEncoder (reference package)") from e
+        """TorchScript export of the encoders (reference :325-368): {"ctx_encoder", "ctx_encoder_qt"[, "q_encoder", "q_encoder_qt"]},
+        the context encoder saved to file_path.  Encoder packaging, outside the hot path: plain PyTorch
+        through dpr_scale_amd.utils.script_encoder.ScriptEncoder (same contract as the reference's; no reference package needed)."""
+        from ..utils.script_encoder import ScriptEncoder
+
         if method != "script":
             raise ValueError(f"The 'method' parameter only supports 'script', but value given was: {method}")
         transform = instantiate(self.transform_conf)

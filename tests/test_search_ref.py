@@ -54,3 +54,30 @@ def test_search_on_the_hip_path_equals_the_reference(chunk, shard):
         s.add(torch.from_numpy(c[lo:lo + shard]).to(dev), lo)
     v, i = s.result()
     _check(v.cpu().numpy(), i.cpu().numpy(), q, c, z, meta["k"])
+
+
+def _wide_k_check(kernels, dev):
+    from dpr_scale_amd.hotpath import CorpusSearch
+
+    q, c = O.synth_search(7, 9, 3000, 32)
+    k = 1500
+    s = CorpusSearch(torch.from_numpy(q).to(dev), k, chunk=1024, kernels=kernels)
+    for lo in range(0, 3000, 1301):
+        s.add(torch.from_numpy(c[lo:lo + 1301]).to(dev), lo)
+    v, i = s.result()
+    S = q.astype(np.float64) @ c.astype(np.float64).T
+    for r in range(q.shape[0]):
+        order = np.lexsort((np.arange(S.shape[1]), -S[r]))[:k]
+        assert np.array_equal(i[r].cpu().numpy(), order) and np.array_equal(v[r].cpu().numpy().astype(np.float64), S[r, order])
+
+
+def test_topk_beyond_the_kernel_limit_with_the_standin_kernels():
+    """run_retrieval_pytorch.py:149 takes any --topk: k = 1500 > 1024 goes through scoring + two stable sorts, same total order."""
+    from _oracle_kernels import OracleKernels
+
+    _wide_k_check(OracleKernels(), torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_topk_beyond_the_kernel_limit_on_the_hip_path():
+    _wide_k_check(None, torch.device("cuda:0"))

@@ -228,3 +228,28 @@ def test_sim_score_then_loss_is_differentiable_like_the_reference():
     # the [Nq, Nc] mask form the reference passes (:197) works too
     s2 = task.sim_score(tq.detach(), tc.detach(), torch.from_numpy(m).repeat(6, 1))
     assert torch.equal(torch.isinf(s2), torch.from_numpy(m).repeat(6, 1))
+
+
+def test_to_torchscript_packages_the_encoders_without_the_reference_package(tmp_path):
+    """dpr_task.py:325-368 (a SURVEY.md 8-b1 hook): scripted modules texts -> embeddings for the context encoder (plain and int8
+    dynamic-quantised) and, with separate towers, the query encoder; the context encoder is saved to file_path."""
+    import torch
+
+    from dpr_scale_amd.task.dpr_task import DenseRetrieverTask
+
+    task = DenseRetrieverTask({"_target_": "_script_toys.ToyTransform"}, {"_target_": "_script_toys.ToyEncoder"}, None, None,
+                              shared_model=False)
+    task.setup("fit")
+    path = str(tmp_path / "ctx.pt")
+    out = task.to_torchscript(path)
+    assert sorted(out) == ["ctx_encoder", "ctx_encoder_qt", "q_encoder", "q_encoder_qt"]
+    texts = ["hello", "hi", ""]
+    want = task.context_encoder(out["ctx_encoder"].transform(texts)["token_ids"])
+    assert torch.allclose(out["ctx_encoder"](texts), want, atol=1e-6)
+    assert torch.allclose(torch.jit.load(path)(texts), want, atol=1e-6)
+    assert (out["ctx_encoder_qt"](texts) - want).abs().max() < 0.1  # int8 weights
+    assert not torch.allclose(out["q_encoder"](texts), want)        # separate towers
+    import pytest
+
+    with pytest.raises(ValueError):
+        task.to_torchscript(method="trace")
