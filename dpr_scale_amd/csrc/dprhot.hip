@@ -27,6 +27,7 @@
 #include "step_small.h"
 #include "skinny.h"
 #include "gradcomm.h"
+#include "wide.h"
 
 using namespace dprhot;
 
@@ -124,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -139,8 +140,10 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_cols", 0, "64 / 128 forces the sim unit width of the skinny plan, 0 = plan"},
     {"search_unfused", 0, "1 materialises every chunk's scores in dprhot_search (no filter epilogue)"},
     {"no_8pb", 0, "1 keeps the backward pair on gemm256.h instead of the phase-interleaved schedule"},
+    {"no_wide", 0, "1 keeps vocabulary-wide fp32 operands on the register-staged sim kernel (wide.h off)"},
+    {"wide_nocopy", 0, "TIMING EXPERIMENT ONLY: 1 drops the bf16 copy-out of wide.h (the backward then reads garbage)"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -466,9 +469,10 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
   if (wide && B >= 128) p.tile = 2;  // 64 x 64 (128 x 128 with twice the slabs measured within 5 %: the fp32 ingest is the limiter)
   const int bk = kTiles[p.tile].bk, ksteps = cdiv(d, bk);
   int splits = ksteps < 4 ? ksteps : 4;
-  if (wide) {  // >= 2 workgroups per CU, at least 4 K steps each, at most 32 slabs of partial logits
-    const int per_split = cdiv(B, kTiles[p.tile].bm) * cdiv(Nc, kTiles[p.tile].bn);
-    splits = cdiv(2 * kNumCU, per_split);
+  if (wide) {  // one 128 x 128 tile per CU (wide.h; the register-staged kernel then gets more, thinner workgroups), at least 4 K steps
+               // each, at most 32 slabs of partial logits
+    const int per_split = cdiv(B, WD_B) * cdiv(Nc, WD_B);
+    splits = cdiv(kNumCU, per_split);
     if (splits > ksteps / 4) splits = ksteps / 4;
     if (splits > 32) splits = 32;
     if (splits < 4) splits = 4;
@@ -489,6 +493,13 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
   p.threads = rpb * tpr;
   p.blocks = cdiv(B, rpb);
   return p;
+}
+
+// the LDS-DMA fp32 sim (wide.h): vocabulary-wide short-row shapes whose K chunks are whole 32-float steps and whose operands are
+// addressable with 32-bit byte offsets
+bool wide_sim_ok(int B, int Nc, int d, const FwdPlan& fp) {
+  return !opt(OPT_NO_WIDE) && d >= 4096 && Nc <= 4096 && B <= 256 && fp.short_rows && d % WD_KS == 0 && fp.kchunk % WD_KS == 0 &&
+         (double)Nc * d * 4 < 4.0e9 && (double)B * d * 4 < 4.0e9;
 }
 
 int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
@@ -931,6 +942,19 @@ int dprhot_sim_stats_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot
   a.Acopy = Qb;
   a.Bcopy = c ? Cb : nullptr;
   if (fp.short_rows) {
+    if (c != nullptr && wide_sim_ok(B, Nc, d, fp) && g_packed.base == nullptr) {
+      // vocabulary-wide fp32 operands: LDS-DMA ring of fp32 tiles, bf16 rounding on the fragment read (wide.h)
+      WideSimArgs wa{q, c, Qb, Cb, B, Nc, d, colmask, inv_T, reinterpret_cast<float*>(ws + wl.logits), (size_t)B * Nc, fp.kchunk,
+                     reinterpret_cast<unsigned long long*>(ws + wl.header), 2, opt(OPT_WIDE_NOCOPY), cdiv(Nc, WD_B), cdiv(B, WD_B)};
+      static AttrOnce attr_done;
+      if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wide_sim_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wd_lds_bytes));
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(wide_sim_kernel, dim3((unsigned)(wa.nbx * wa.nby * fp.splits)), dim3(WD_THREADS), wd_lds_bytes, (hipStream_t)stream, wa);
+      HIP_TRY(hipGetLastError());
+      return DPRHOT_OK;
+    }
     EpiSim epi{reinterpret_cast<float*>(ws + wl.logits), colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr,
                reinterpret_cast<unsigned long long*>(ws + wl.header), 2, (size_t)B * Nc};
     epi = with_packed_mask(epi);

@@ -47,14 +47,30 @@ class RouterScoring:
             scores = scores.masked_fill(full, float("-inf"))
         return scores
 
+    def _stock_scoring(self):
+        """True when neither sim_score nor the loss has been replaced by a subclass / the user: only then may router_loss skip the
+        materialised score matrix."""
+        from .dpr_task import HotCrossEntropyLoss
+
+        return type(self).sim_score is RouterScoring.sim_score and isinstance(getattr(self, "loss", None),
+                                                                              (HotCrossEntropyLoss, torch.nn.CrossEntropyLoss))
+
     def router_loss(self, query_repr, context_repr, mask, pos_ctx_indices, teacher_scores):
         """citadel_task.py:249-262."""
         router_loss = 0.0
         if 1 - self.teacher_coef > 0:
-            router_scores = self.sim_score(query_repr["router_repr"], context_repr["router_repr"], mask, pairwise=not self.in_batch)
-            if not self.in_batch:
-                pos_ctx_indices = torch.zeros(len(router_scores), dtype=torch.int64, device=router_scores.device)
-            router_loss = self.loss(router_scores, pos_ctx_indices)
+            q, c = query_repr["router_repr"], context_repr["router_repr"]
+            if self.in_batch and self._stock_scoring() and q.is_cuda and (mask is None or mask.dim() == 1):
+                # CrossEntropyLoss(sim_score(q, c, mask), labels) on already-gathered vectors IS the in-batch contrastive step
+                # (dpr_task.py:197-212 at T = 1 without a gather): one fused operator -- fp32 vectors read once, no [Nq, Nc] logits
+                # in HBM, both backward GEMMs in the forward call -- instead of casts + sim + cross-entropy + two backward launches
+                m = mask if mask is not None else torch.zeros(c.shape[0], dtype=torch.bool, device=c.device)
+                router_loss = hotpath.inbatch_contrastive_loss(q, c, pos_ctx_indices, m, 1.0, False, getattr(self, "kernels", None))
+            else:
+                router_scores = self.sim_score(q, c, mask, pairwise=not self.in_batch)
+                if not self.in_batch:
+                    pos_ctx_indices = torch.zeros(len(router_scores), dtype=torch.int64, device=router_scores.device)
+                router_loss = self.loss(router_scores, pos_ctx_indices)
         if self.teacher_coef > 0:
             pairwise_router_scores = self.sim_score(query_repr["router_repr"], context_repr["router_repr"], mask, pairwise=True)
             router_loss = (1 - self.teacher_coef) * router_loss + self.teacher_coef * distilled_loss(

@@ -357,6 +357,42 @@ def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
     assert rel(chunk[:n_ctx].sum(0), g["dc_own_colsum"]) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("B,K,d,ragged", [(128, 8, 4128, True), (40, 6, 8192, False), (16, 4, 30528, True), (200, 2, 4096, True)])
+def test_vocabulary_wide_fp32_operands_through_the_lds_dma_sim(B, K, d, ragged, kn, dev):
+    """csrc/wide.h: fp32 operands with a contraction thousands long (the CITADEL router shape class) go global -> LDS by DMA and are
+    rounded to bf16 on the fragment read; split-K slabs, bf16 copy-out for the backward.  Loss / gradients against the fp64 oracle,
+    the bf16 images against RNE rounding, and the register-staged kernel (option no_wide) as a second opinion on the logits."""
+    from dpr_scale_amd import _lib, hotpath
+
+    q, c, y, m = O.synth_embeddings(4000 + B, B, K, d, "U", ragged)
+    ref = O.training_step_global(q, c, y, m, 1.0)
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = hotpath.inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), 1.0)
+    loss.backward()
+    assert abs(loss.item() - ref["loss"]) <= LOSS_RTOL * max(1.0, abs(ref["loss"]))
+    assert rel(tq.grad.cpu().numpy(), ref["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy(), ref["dC"]) <= GRAD_RTOL
+    # the forward alone, both kernels: logits bit-comparable up to the summation order of the slabs
+    Nc = B * K
+    if Nc % 8 == 0:
+        outs = []
+        for no_wide in (0, 1):
+            _lib.set_option("no_wide", no_wide)
+            try:
+                Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+                Cb = torch.empty((Nc, d), dtype=torch.bfloat16, device=dev)
+                rl, lse, ls, G, S = kn.inbatch_fwd_f32(t(q, dev), t(c, dev), Qb, Cb, t(y, dev), 0, t(m.astype(np.uint8), dev), 1.0, 1.0 / B,
+                                                       want_logits=True)
+                outs.append((S.cpu().numpy(), Qb.float().cpu().numpy(), Cb.float().cpu().numpy(), ls.item()))
+            finally:
+                _lib.set_option("no_wide", 0)
+        (S1, Q1, C1, l1), (S0, Q0, C0, l0) = outs
+        assert np.array_equal(Q1, O.bf16_round(q)) and np.array_equal(C1, O.bf16_round(c))  # (inputs are bf16-representable: identity)
+        assert np.array_equal(Q0, Q1) and np.array_equal(C0, C1)
+        fin = np.isfinite(ref["S"])
+        assert np.array_equal(fin, np.isfinite(S1)) and rel(S1[fin], ref["S"][fin]) <= LOGIT_RTOL and rel(S0[fin], S1[fin]) <= 1e-5
+        assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
+
+
 def test_selftest_big_passes():
     """The stand-alone C ABI self-test (csrc/selftest.hip) including its cfg3-per-rank (128 x 8192 x 768) and 1M-passage
     search cases, executed as the binary a C caller would link."""
