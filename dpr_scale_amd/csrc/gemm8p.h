@@ -690,28 +690,51 @@ struct Epi8Filter {
         any |= mx[a][b] >= tv[a];
       }
     }
-    if (!any) return;
+    if (__ballot(any) == 0ull) return;  // wave-uniform: the lanes of a row trade counts below
+    // Append path.  Round 2 took one RETURNING global atomic per candidate inside a divergent walk -- serialised round trips to L2:
+    // a k = 1000 search leaves ~60 candidates per 128 x 64 wave tile in its second chunk and that chunk's GEMM took 471 us instead
+    // of 98.  Now per 32-row block: every lane counts its qualifiers (a bit per value: no memory), the two lanes of a row add their
+    // counts with one v_permlane32_swap, ONE atomic per row reserves the run (all rows of the block in the same instruction), and
+    // the values are written behind each other from a running offset.
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int m = t.m0 + t.wm * 128 + a * 32 + i;
-      if (m >= M) continue;
+      unsigned mask = 0u;  // bit b * 16 + r
+      if (m < M) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if (!(mx[a][b] >= tv[a])) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
+            const float v = acc.v[a][b][r];
+            if (!(n < N && v >= tv[a])) continue;
+            bool take = v > tv[a];
+            if (!take) {  // exact tie with the k-th best -> lower passage id wins (-1: slot unfilled)
+              const long long ti = kth_idx[(size_t)m * k + k - 1];
+              take = ti < 0 || col_offset + n < ti;
+            }
+            if (take) mask |= 1u << (b * 16 + r);
+          }
+        }
+      }
+      const int mine = __builtin_popcount(mask);
+      const auto cc = __builtin_amdgcn_permlane32_swap((unsigned)mine, (unsigned)mine, false, false);  // (count of lane i, of lane i + 32)
+      const int total = (int)(cc[0] + cc[1]);
+      int base = 0;
+      if (h == 0 && total > 0) base = atomicAdd(&cnt[m], total);
+      const auto bb = __builtin_amdgcn_permlane32_swap((unsigned)base, (unsigned)base, false, false);
+      int pos = (int)bb[0] + (h != 0 ? (int)cc[0] : 0);
+      if (mask == 0u) continue;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        if (!(mx[a][b] >= tv[a])) continue;
+        if (((mask >> (b * 16)) & 0xffffu) == 0u) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int n = t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
-          const float v = acc.v[a][b][r];
-          if (!(n < N && v >= tv[a])) continue;
-          bool take = v > tv[a];
-          if (!take) {  // exact tie with the k-th best -> lower passage id wins (-1: slot unfilled)
-            const long long ti = kth_idx[(size_t)m * k + k - 1];
-            take = ti < 0 || col_offset + n < ti;
-          }
-          if (take) {
-            const int pos = atomicAdd(&cnt[m], 1);
-            cand_v[(size_t)m * N + pos] = v;
-            cand_j[(size_t)m * N + pos] = n;
+          if ((mask >> (b * 16 + r)) & 1u) {
+            cand_v[(size_t)m * N + pos] = acc.v[a][b][r];
+            cand_j[(size_t)m * N + pos] = t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
+            ++pos;
           }
         }
       }

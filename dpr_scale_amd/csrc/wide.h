@@ -18,7 +18,8 @@
 
 namespace dprhot {
 
-constexpr int WD_B = 128;      // tile rows and columns
+constexpr int WD_B = 128;      // tile rows and columns (64 x 64 tiles with 256-byte runs -- 64 fp32 of k per slot, 8 slabs -- were measured and
+                               // lost: 69 us alone against 45, q then crosses the L2 -> CU path sixteen times)
 constexpr int WD_KS = 32;      // fp32 k values per ring slot and operand row (128 bytes)
 constexpr int WD_SLOTS = 4;
 constexpr int WD_THREADS = 512;  // waves 0-3 fetch and multiply, waves 4-7 write the bf16 images
