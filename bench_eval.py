@@ -36,7 +36,7 @@ def bench_search(nq, n, d, k, chunk, iters):
     kn = default_kernels()
 
     def ours():
-        s = CorpusSearch(q, k, chunk=chunk, kernels=kn)
+        s = CorpusSearch(q, k, chunk=chunk or None, kernels=kn)
         s.add(C, 0)
         return s.result()
 
@@ -52,7 +52,7 @@ def bench_search(nq, n, d, k, chunk, iters):
     inter = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(i[:64].cpu(), ri[:64].cpu())) / (64.0 * k)
     S = torch.sort(q[:8].to(torch.bfloat16).float() @ C.float().T, dim=1, descending=True, stable=True)
     exact = bool(torch.equal(S.indices[:, :10], i[:8, :10]))  # top-10 of fp32 torch scores (top-k deep ties may reorder)
-    return {"what": "search", "workload": f"nq={nq} corpus={n} d={d} k={k} chunk={chunk} bf16 resident",
+    return {"what": "search", "workload": f"nq={nq} corpus={n} d={d} k={k} chunk={chunk or 'default (head 65536, then up to 262144)'} bf16 resident",
             "ms": round(t_ours * 1e3, 3), "queries_per_s": round(nq / t_ours, 1),
             "tflops_scoring": round(2.0 * nq * n * d / t_ours * 1e-12, 1),
             "torch_fp16_einsum_topk_ms": round(t_ref * 1e3, 3), "speedup_vs_torch": round(t_ref / t_ours, 2),
@@ -108,7 +108,7 @@ if __name__ == "__main__":
     ap.add_argument("--corpus", type=int, default=1 << 21)
     ap.add_argument("--d", type=int, default=768)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--chunk", type=int, default=65536)
+    ap.add_argument("--chunk", type=int, default=0, help="0 = CorpusSearch default")
     ap.add_argument("--nc", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()

@@ -935,8 +935,8 @@ class CorpusSearch:
         self.kn.cast_bf16(query_embs, self.Qb)
         self.k = int(k)
         self.wide_k = self.k > self.KMAX
-        if chunk is None:  # keep the score chunk around 256 MiB
-            chunk = max(1024, min(65536, (1 << 26) // max(nq, 1) // 8 * 8))
+        if chunk is None:  # filtered chunks of up to 262144 passages (2 GiB of candidate workspace at 1024 queries); the library starts
+            chunk = max(1024, min(262144, (1 << 28) // max(nq, 1) // 8 * 8))  # an empty state from a 65536-passage head on its own
         self.chunk = int(chunk) // 8 * 8
         self.values = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=query_embs.device)
         self.indices = torch.full((nq, k), -1, dtype=torch.int64, device=query_embs.device)

@@ -239,7 +239,7 @@ int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t c
  * (fp32 scores; the reference scores in fp16), chunk columns at a time, each chunk folded into the running
  * top-k -- the [nq, n_ctx] score matrix never exists.  Q [nq,d], C [n_ctx,d] bf16; passage ids are
  * id_offset + row.  n_ctx and chunk multiples of 8 (a ragged tail goes through sim_fwd + topk_update with
- * cols < ld).  first as in dprhot_topk_update.  The first chunk of an empty state is scored into the workspace
+ * cols < ld).  first as in dprhot_topk_update.  The first chunk of an empty state (at most 65536 passages of it) is scored into the workspace
  * and selected from; for every later chunk the GEMM epilogue compares each score with the row's current k-th best
  * and only appends the few that beat it to a candidate list, which a merge kernel folds into the state.
  * workspace: dprhot_search_workspace_bytes(nq, chunk). */
