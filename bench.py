@@ -597,6 +597,16 @@ def roofline_at_scale(dev, d, B=8192, Nc=8192):
         rows = (("sim_gemm", hp.k_sim, 2 * (bd + nd) + 4 * bn, 2 * bn * d, "mfma"),
                 ("softmax_dscores", hp.k_softmax, 6 * bn, 0.0, "hbm"),
                 ("backward_gemms", hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d, "mfma"))
+    # sim_score with the logits wanted (validation through a subclass's own metrics, the head chunk of a retrieval): dprhot_sim_fwd
+    S_full = torch.empty((B, Nc), dtype=torch.float32, device=dev)
+
+    def k_simfwd():
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = hp.lib.dprhot_sim_fwd(P(hp.Qb), B, P(hp.Cb), Nc, d, P(hp.mask_all), hp.inv_T, P(S_full), st)
+        if rc:
+            hp._lib.check(rc, "dprhot_sim_fwd")
+
+    rows = rows + (("sim_store", k_simfwd, 2 * (bd + nd) + 4 * bn, 2 * bn * d, "mfma"),)
     for name, fn, by, fl, bound in rows:
         us = time_kernel(hp, fn, reps=20, iters=3)
         if bound == "mfma":
@@ -611,7 +621,7 @@ def roofline_at_scale(dev, d, B=8192, Nc=8192):
         out["forward_us"] = round(out["sim_gemm"]["us"] + out["lse_loss"]["us"] + out["dscores_gemm"]["us"], 1)
         out["step_us"] = round(out["forward_us"] + out["backward_gemms"]["us"], 1)
         out["step_mfma_frac"] = round(8 * bn * d / out["step_us"] * 1e-6 / MFMA_PEAK_TFLOPS, 4)
-    del hp
+    del hp, S_full
     torch.cuda.empty_cache()
     return out
 

@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -142,8 +142,9 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"no_8pb", 0, "1 keeps the backward pair on gemm256.h instead of the phase-interleaved schedule"},
     {"no_wide", 0, "1 keeps vocabulary-wide fp32 operands on the register-staged sim kernel (wide.h off)"},
     {"wide_nocopy", 0, "TIMING EXPERIMENT ONLY: 1 drops the bf16 copy-out of wide.h (the backward then reads garbage)"},
+    {"no_8p_store", 0, "1 keeps dprhot_sim_fwd's large shapes on the round-1 256 x 256 kernel (gemm256.h)"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -707,6 +708,15 @@ int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, in
   REQUIRE(Q && C && S, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   REQUIRE(aligned16(Q) && aligned16(C) && aligned16(S), "pointers must be 16-byte aligned");
+  if (nl_ok(B, Nc, d) && !opt(OPT_NO_8P_STORE)) {
+    // large score matrices (validation with the logits wanted, the head chunk of a retrieval): the phase-interleaved kernel with
+    // the store epilogue that writes whole rows (Epi8Store); the round-1 256 x 256 kernel stays behind the option
+    Epi8Store epi;
+    static_cast<Epi8Base&>(epi) = g8_base(Q, B, Nc, nullptr, 0, colmask, inv_T, nullptr);
+    epi.S = S;
+    GemmArgs a8{Q, C, B, Nc, d, d, d, d};
+    return launch_g8<Epi8Store, 2>(a8, epi, (hipStream_t)stream);
+  }
   const int tile = (force_tile() < 0 && big_ok(B, Nc, d)) ? kBigTile : pick_tile(B, Nc, d, 1, 2 * kNumCU);
   GemmArgs a{Q, C, B, Nc, d, d, d, cdiv(d, kTiles[tile].bk) * kTiles[tile].bk};
   EpiSim epi{S, colmask, B, Nc, inv_T, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0};

@@ -42,9 +42,9 @@ namespace dprhot {
 
 constexpr int G8_HALF = 128 * 64;                                   // elements of a half-tile image
 constexpr size_t g8_tiles_bytes = (size_t)2 * 4 * G8_HALF * 2;      // 2 buffers x {A0, A1, B0, B1} = 128 KiB
-constexpr size_t g8_scratch_bytes = 8 * 1024;                       // epilogue scratch
+constexpr size_t g8_scratch_bytes = 18 * 1024;                      // epilogue scratch (Epi8Store: 8 waves x 8 rows x 68 floats)
 constexpr size_t g8_meta_bytes = (size_t)2 * 1024 * sizeof(int);    // 2 x 1024 words of per-tile epilogue inputs
-constexpr size_t g8_lds_total = g8_tiles_bytes + g8_scratch_bytes + g8_meta_bytes;  // 144 KiB
+constexpr size_t g8_lds_total = g8_tiles_bytes + g8_scratch_bytes + g8_meta_bytes;  // 154 KiB
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -441,32 +441,55 @@ struct Epi8Base {
   }
 };
 
-// fp32 logits (sim_score with a caller buffer): S = acc / T, masked columns -inf   (dpr_task.py:104,211)
+typedef float g8_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void g8_lds_write4f(void* p, g8_f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(g8_lds_addr(p)), "v"(v) : "memory");
+}
+
+// fp32 logits (sim_score with a caller buffer): S = acc / T, masked columns -inf   (dpr_task.py:104,211).
+// The accumulator layout gives a lane 16-byte runs of 32 different rows: stored as they are, every store instruction touches 64
+// lines for 16 bytes each.  Eight rows at a time go through a per-wave LDS patch instead (the 16 lanes that hold them write, all
+// 64 read back row-major): every store instruction then writes four whole 256-byte rows of the wave's 64 columns.
 struct Epi8Store : Epi8Base {
   float* S;
   __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
     meta_fix(t);
-    const int i = t.lane & 31;
+    constexpr int TS = 64 + 4;
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float madd[8][4];
+    col_madd(t, madd);
+    float* const patch = t.scratch + (t.wm * 4 + t.wn) * (8 * TS);
+    const int rr = t.lane >> 4, cq = t.lane & 15;
+    const int n = t.n0 + t.wn * 64 + cq * 4;
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int a = 0; a < 4; ++a) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cn = run_col(t, b, q);
-        const g8_i32x4 f = g8_lds_read4(t.meta + cn);
-        const int n = t.n0 + cn;
-        if (n >= sim.N) continue;  // N % 4 == 0: a run is inside or outside as a whole
+      for (int sgrp = 0; sgrp < 4; ++sgrp) {
+        if ((i >> 3) == sgrp) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int m = t.m0 + t.wm * 128 + a * 32 + i;
-          if (m >= sim.M) continue;
-          float4 v;
-          v.x = f[0] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 0] * sim.inv_T;
-          v.y = f[1] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 1] * sim.inv_T;
-          v.z = f[2] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 2] * sim.inv_T;
-          v.w = f[3] != 0 ? -INFINITY : acc.v[a][b][q * 4 + 3] * sim.inv_T;
-          *reinterpret_cast<float4*>(S + (size_t)m * sim.N + n) = v;
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              g8_f32x4 v;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = acc.v[a][b][q * 4 + j] * sim.inv_T + madd[b * 4 + q][j];
+              g8_lds_write4f(patch + (i & 7) * TS + b * 32 + q * 8 + h * 4, v);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int row = rr + 4 * it;
+          const g8_i32x4 w = g8_lds_read4(patch + row * TS + cq * 4);
+          const int m = t.m0 + t.wm * 128 + a * 32 + sgrp * 8 + row;
+          if (m < sim.M && n < sim.N) {  // N % 8 == 0: a run of four columns is inside or outside as a whole
+            float4 o;
+            o.x = __int_as_float(w[0]); o.y = __int_as_float(w[1]); o.z = __int_as_float(w[2]); o.w = __int_as_float(w[3]);
+            *reinterpret_cast<float4*>(S + (size_t)m * sim.N + n) = o;
+          }
         }
       }
+    }
   }
 };
 

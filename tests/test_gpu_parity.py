@@ -314,6 +314,35 @@ def test_production_packed_step_every_rank_full_size(name, kn, dev):
     assert np.array_equal(ranks, g["ranks"][own * B:(own + 1) * B])
 
 
+@pytest.mark.parametrize("W,B,K,d", [(8, 32, 8, 768), (4, 64, 8, 512)])
+def test_packed_step_narrow_sim_units_against_the_oracle(W, B, K, d, kn, dev):
+    """The 64-column sim unit of the skinny plan (chosen when the 128-column units would leave most CUs idle: cfg2 gathered over 8
+    ranks = B 32 x Nc 2112, sk_plan) had only HIP-against-HIP checks: here every rank's packed step against the numpy oracle of the
+    reference's global step (dpr_task.py:163-212) -- loss, this rank's q.grad, and c.grad of every rank after the emulated
+    reduce-scatter."""
+    meta = dict(W=W, B=B, K=K, d=d, seed=8800 + W, dist="U", ragged=True)
+    parts, rows_c, Cb = _packed_world(meta, kn, dev)
+    n_ctx, T = B * K, 0.5
+    Q = np.concatenate([p[0] for p in parts])
+    C = np.concatenate([p[1] for p in parts])
+    y = np.concatenate([p[2] + r * n_ctx for r, p in enumerate(parts)])
+    m = np.concatenate([p[3] for p in parts])
+    ref = O.training_step_global(Q, C, y, m, T)
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
+    loss = 0.0
+    for r in range(W):
+        rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), 1.0 / T,
+                                                              1.0 / (T * W * B))
+        loss += ls.item()
+        dC += dcp.double()
+        assert rel(lse.cpu().numpy(), ref["lse"][r * B:(r + 1) * B]) <= LOGIT_RTOL
+        assert rel(dq.cpu().numpy(), ref["dQ"][r * B:(r + 1) * B]) <= GRAD_RTOL
+    assert abs(loss / (W * B) - ref["loss"]) <= LOSS_RTOL * max(1.0, abs(ref["loss"]))
+    got = dC.cpu().numpy().reshape(W, rows_c, d)[:, :n_ctx].reshape(W * n_ctx, d)
+    assert rel(got, ref["dC"]) <= GRAD_RTOL
+
+
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
 def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
     """dprhot_train_step_packed_f32 -- what the autograd operator runs under DDP -- for EVERY rank of cfg3 against the
