@@ -148,7 +148,7 @@ class HotPathStep:
         self.a_step = (P(self.q), P(self.c) if not self.dist else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
                        P(self.mask_all), self.inv_T, self.gscale, 1.0, P(self.go), None, P(self.row_loss), P(self.row_lse),
                        P(self.loss_sum), P(self.G), P(self.dQ), P(self.dC), ws, wsb, st)
-        self.small = B <= 32 and Nc <= 1152 and d % 16 == 0  # mirrors small_step_ok() in csrc/dprhot.hip
+        self.small = (B <= 32 and Nc <= 1152 or B <= 64 and Nc <= 256) and d % 16 == 0  # mirrors small_step_ok() in csrc/dprhot.hip
         # N > 1: everything between the all-gather and the reduce-scatter in one call (mask read from the packed buffer,
         # loss numerator riding in dC_part); DPRHOT_UNPACKED=1 keeps the separate unpack launch and the loss all-reduce
         self.packed_step = self.dist and not os.environ.get("DPRHOT_UNPACKED")

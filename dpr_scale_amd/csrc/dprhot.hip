@@ -394,7 +394,7 @@ SkPlan sk_plan(int B, int Nc, int d) {
   constexpr int min_nc = 2048;
   SkPlan p{};
   p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
-         Nc <= 16384 && (no_small || !(B <= SS_ROWS && Nc <= SS_MAXNC));
+         Nc <= 16384 && (no_small || !(B <= SS_MAXB && Nc <= SS_MAXNC));
   p.nt = cdiv(Nc, SK_COLS);
   {
     // sim unit width: 128 columns x 4 ring slots, or 64 columns x 8 slots (twice the units, two thirds of a unit's K range in flight).
@@ -1200,7 +1200,11 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
 // every other shape runs the three launches of dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd.
 static bool small_step_ok(int B, int Nc, int d) {
   const FwdPlan fp = fwd_plan(B, Nc, d);
-  return !opt(OPT_NO_SMALL_STEP) && B <= SS_ROWS && Nc <= SS_MAXNC && d % 16 == 0 && fp.short_rows && fp.splits <= 4 && !unfused_bwd();
+  // two row blocks (32 < B <= 64) up to 256 columns only -- measured (scratch/rb_probe.py, two launches against three): 64 x 256 x 768
+  // 13.3 against 16.2 us, 64 x 128 x 1024 13.5 / 14.0, but 64 x 512 18.6 / 17.5 and 64 x 768 24.0 / 22.8: every workgroup repeats
+  // BOTH blocks' softmax, and beyond 256 columns that second helping costs more than the launch it saves
+  return !opt(OPT_NO_SMALL_STEP) && B <= SS_MAXB && Nc <= (B <= SS_ROWS ? SS_MAXNC : 256) && d % 16 == 0 && fp.short_rows && fp.splits <= 4 &&
+         !unfused_bwd();
 }
 
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
@@ -1246,9 +1250,9 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   const int ncp = (Nc + 31) / 32 * 32;
   const dim3 grid(d / tw), block(1024);
   hipStream_t st = (hipStream_t)stream;
-#define DPRHOT_SS_LAUNCH(CPT, NS)                                                                                              \
+#define DPRHOT_SS_LAUNCH_N(CPT, NS, NRB)                                                                                      \
   do {                                                                                                                         \
-    auto kern = step_small_kernel<CPT, tw, NS>;                                                                                  \
+    auto kern = step_small_kernel<CPT, tw, NS, NRB>;                                                                             \
     static size_t attr_dev[64] = {}; /* per device; benign race: idempotent */                                                 \
     size_t& attr = attr_dev[lds > 48 * 1024 ? AttrOnce::cur() : 0];                                                            \
     if (lds > 48 * 1024 && attr < lds) {                                                                                       \
@@ -1256,6 +1260,11 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
       attr = lds;                                                                                                              \
     }                                                                                                                          \
     hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                                         \
+  } while (0)
+#define DPRHOT_SS_LAUNCH(CPT, NS)                      \
+  do {                                                 \
+    if (B <= SS_ROWS) DPRHOT_SS_LAUNCH_N(CPT, NS, 1);  \
+    else DPRHOT_SS_LAUNCH_N(CPT, NS, 2);               \
   } while (0)
   if (lds > 160 * 1024 || fp.splits > 4) return fail(DPRHOT_E_UNSUPPORTED, "small step: Nc=%d needs %zu bytes of LDS", Nc, lds);
   if (ncp <= 256) {
@@ -1271,8 +1280,9 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
   } else if (ncp <= 768) {
     DPRHOT_SS_LAUNCH(3, 1);  // above 512 columns the sim launch writes one slab (fwd_plan)
   } else {
-    DPRHOT_SS_LAUNCH(5, 1);
+    DPRHOT_SS_LAUNCH_N(5, 1, 1);  // (B <= 32 only: small_step_ok)
   }
+#undef DPRHOT_SS_LAUNCH_N
 #undef DPRHOT_SS_LAUNCH
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;

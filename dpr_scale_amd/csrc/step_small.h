@@ -20,7 +20,8 @@
 
 namespace dprhot {
 
-constexpr int SS_ROWS = 32;     // query rows held (B <= 32; rows beyond B are zero)
+constexpr int SS_ROWS = 32;     // query rows of one row block (rows beyond B are zero)
+constexpr int SS_MAXB = 64;     // query rows of the launch: two row blocks at most
 constexpr int SS_MAXNC = 1152;  // G image + C tile + dQ partials must fit the 160 KiB of LDS
 // TW = columns of d per workgroup (16 in the library); the C / Q tile images have row stride TW + 8 elements
 
@@ -49,7 +50,7 @@ struct StepSmallArgs {
 
 inline size_t step_small_lds(int Nc, int TW) {
   const int ncp = (Nc + 31) / 32 * 32, ts = TW + 8;
-  return (size_t)SS_ROWS * (ncp + 8) * 2 + (size_t)ncp * ts * 2 + (size_t)SS_ROWS * ts * 2 + SS_ROWS * sizeof(float) +
+  return (size_t)SS_ROWS * (ncp + 8) * 2 + (size_t)ncp * ts * 2 + (size_t)SS_ROWS * ts * 2 + SS_MAXB * sizeof(float) +
          (size_t)8 * SS_ROWS * TW * sizeof(float);  // + the dQ partial sums of the 8 K slices
 }
 
@@ -84,7 +85,8 @@ __device__ __forceinline__ bf16x8 ss_tr_frag(const uint16_t* T, int stride, int 
 
 // CPT: 8-value chunks of a row per thread (32 threads per row): Nc <= 256 * CPT.  TW: columns of d per workgroup.
 // NS: partial-logit slabs read (>= p.splits; the sim launch writes 1 slab above 512 columns, up to 4 below).
-template <int CPT, int TW, int NS>
+// NRB: row blocks of 32 (1: B <= 32, the body runs once, straight-line as before; 2: B <= 64, unrolled twice).
+template <int CPT, int TW, int NS, int NRB = 1>
 __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t ss_smem[];
   constexpr int TS = TW + 8;          // tile image row stride (elements)
@@ -103,24 +105,40 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   uint16_t* const Gs = ss_smem;                       // [32][gs]   G, row-major
   uint16_t* const Cs = Gs + SS_ROWS * gs;             // [ncp][TS]  C[:, n0:n0+TW]
   uint16_t* const Qs = Cs + ncp * TS;                 // [32][TS]   Q[:, n0:n0+TW]
-  float* const s_rl = reinterpret_cast<float*>(Qs + SS_ROWS * TS);  // [32] row losses
-  float* const red = s_rl + SS_ROWS;                  // [8][32][TW] dQ partial sums
+  float* const s_rl = reinterpret_cast<float*>(Qs + SS_ROWS * TS);  // [SS_MAXB] row losses of all row blocks
+  float* const red = s_rl + SS_MAXB;                  // [8][32][TW] dQ partial sums
 
-  // ---- all global reads of the launch, back to back (nothing is used before the last one is issued) ----
-  DPRHOT_TM(8);
-  const int row = tid >> 5, tr = tid & 31;
-  const bool active = row < p.B;
+  // Row blocks of 32 (round 3: B <= 64 -- the per-GPU batch of the DRAGON / NQ recipes -- takes two turns through the body below with
+  // the C tile resident and the dC accumulators kept in registers; a third launch plus a G round trip through HBM cost more than
+  // the second softmax: 5 + ~2.5 us against ~11).  The first block's loads are all issued back to back with the C tile's.
+  const int lrow = tid >> 5, tr = tid & 31;
   const float dsc = p.d_scale ? *p.d_scale : 1.0f;
+  const bool lead = tile == 0;
+  const float sc = p.h_scale * dsc;
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 dcacc[CPT][NF];
+#pragma unroll
+  for (int it = 0; it < CPT; ++it)
+#pragma unroll
+    for (int b = 0; b < NF; ++b) dcacc[it][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+  // ---- all global reads of the block, back to back (nothing is used before the last one is issued) ----
+  DPRHOT_TM(8);
+  uint4 creg[CU];  // the C tile: loaded and parked in LDS by the first block only
+  if (rb == 0) {
+#pragma unroll
+    for (int u = 0; u < CU; ++u) {
+      const int q = tid + u * 1024, j = q / TC, cc = q % TC;
+      creg[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (j < Nc) creg[u] = *reinterpret_cast<const uint4*>(p.Cb + (size_t)j * p.d + n0 + cc * 8);
+    }
+  }
+  const int row = rb * SS_ROWS + lrow;
+  const bool active = row < p.B;
   const int64_t yraw = active ? p.y[row] : (int64_t)-1;
   uint4 qreg = make_uint4(0u, 0u, 0u, 0u);
   if (active && tr < TC) qreg = *reinterpret_cast<const uint4*>(p.Qb + (size_t)row * p.d + n0 + tr * 8);
-  uint4 creg[CU];
-#pragma unroll
-  for (int u = 0; u < CU; ++u) {
-    const int q = tid + u * 1024, j = q / TC, cc = q % TC;
-    creg[u] = make_uint4(0u, 0u, 0u, 0u);
-    if (j < Nc) creg[u] = *reinterpret_cast<const uint4*>(p.Cb + (size_t)j * p.d + n0 + cc * 8);
-  }
   // partial-logit slabs (at most NS): every load is issued unconditionally on a valid address (absent slabs re-read
   // slab 0 and are dropped by a select at the add) -- a loop over p.splits would wait for one slab before asking for
   // the next: dependent trips to L2 instead of one
@@ -140,11 +158,14 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
 
   // ---- operand tiles -> LDS ----
   DPRHOT_TM(9);
-  if (tr < TC) *reinterpret_cast<uint4*>(Qs + row * TS + tr * 8) = qreg;
+  if (rb > 0) __syncthreads();  // the previous block's readers of Gs / Qs / red are done
+  if (tr < TC) *reinterpret_cast<uint4*>(Qs + lrow * TS + tr * 8) = qreg;
+  if (rb == 0) {
 #pragma unroll
-  for (int u = 0; u < CU; ++u) {
-    const int q = tid + u * 1024, j = q / TC, cc = q % TC;
-    if (j < ncp) *reinterpret_cast<uint4*>(Cs + j * TS + cc * 8) = creg[u];
+    for (int u = 0; u < CU; ++u) {
+      const int q = tid + u * 1024, j = q / TC, cc = q % TC;
+      if (j < ncp) *reinterpret_cast<uint4*>(Cs + j * TS + cc * 8) = creg[u];
+    }
   }
 
   // ---- row softmax (32 lanes per row: DPP over 16, one lane exchange across the two halves), loss, G ----
@@ -197,10 +218,9 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   gold += __shfl_xor(gold, 16);
   const float lse = m + logf(sm);
   const float inv_sm = 1.0f / sm;  // sm = 0 (dead row): inf * 0 = NaN, like exp(v - lse) with lse = NaN
-  const bool lead = tile == 0;
   if (tr == 0) {
     const float l = active ? lse - gold : 0.f;
-    s_rl[row] = l;
+    s_rl[rb * SS_ROWS + lrow] = l;
     if (lead && active) {
       if (p.row_lse) p.row_lse[row] = lse;
       if (p.row_loss) p.row_loss[row] = l;
@@ -213,14 +233,14 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
       uint4 gv = make_uint4(0u, 0u, 0u, 0u);
       if (active && chunk < cpr) {
         const int c0 = chunk * 8;
-        float g[8];
+        float gg[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float pr = ex[k][e] * inv_sm;
           if (c0 + e == yi) pr -= 1.0f;
-          g[e] = pr * p.grad_scale;
+          gg[e] = pr * p.grad_scale;
         }
-        gv = make_uint4(pk_bf16(g[0], g[1]), pk_bf16(g[2], g[3]), pk_bf16(g[4], g[5]), pk_bf16(g[6], g[7]));
+        gv = make_uint4(pk_bf16(gg[0], gg[1]), pk_bf16(gg[2], gg[3]), pk_bf16(gg[4], gg[5]), pk_bf16(gg[6], gg[7]));
         if (lead) {
           if (p.G != nullptr) *reinterpret_cast<uint4*>(p.G + (size_t)row * Nc + c0) = gv;
           if (p.S_out != nullptr) {
@@ -230,22 +250,14 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
           }
         }
       }
-      *reinterpret_cast<uint4*>(Gs + row * gs + chunk * 8) = gv;
+      *reinterpret_cast<uint4*>(Gs + lrow * gs + chunk * 8) = gv;
     }
   }
   DPRHOT_TM(12);
   __syncthreads();
   DPRHOT_TM(13);
-  if (lead && tid == 0) {
-    double tot = 0.0;
-    for (int r = 0; r < p.B; ++r) tot += (double)s_rl[r];
-    p.loss_sum[0] = (float)tot * p.loss_scale;
-    s_rl[0] = (float)tot * p.loss_scale;  // (row losses are no longer needed) for the stamp below, read after the next barrier
-  }
 
-  const float sc = p.h_scale * dsc;
-  const int i = lane & 15, g = lane >> 4;
-  // ---- dQ[0:32, n0:n0+TW] = G[32, Nc] x C[Nc, TW]: wave w -> rows (w & 1) * 16.., K slice w >> 1 of 8; partial sums
+  // ---- dQ[rows of the block, n0:n0+TW] = G[32, Nc] x C[Nc, TW]: wave w -> rows (w & 1) * 16.., K slice w >> 1 of 8; partial sums
   //      through LDS, added in slice order ----
   {
     const int wm = wave & 1, ks = wave >> 1;
@@ -270,48 +282,69 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
       for (int r = 0; r < 4; ++r) red[(ks * SS_ROWS + wm * 16 + g * 4 + r) * TW + b * 16 + i] = acc[b][r];
   }
   __syncthreads();
-  // ---- dC_part[0:Nc, n0:n0+TW] = G^T[Nc, 32] x Q[32, TW]: one 16-row block of contexts per wave and round ----
+  // ---- dC_part[0:Nc, n0:n0+TW] += G^T[Nc, 32] x Q[32, TW]: one 16-row block of contexts per wave and round ----
   DPRHOT_TM(14);
   {
-    const bool stamp = lead && p.stamp_period > 0;  // column 0 of d belongs to workgroup 0
     bf16x8 bq[NF];
 #pragma unroll
     for (int b = 0; b < NF; ++b) bq[b] = ss_tr_frag(Qs, TS, 0, b * 16, lane);
-    float* out = p.dC + (size_t)(wave * 16 + g * 4) * p.d + n0 + i;
-    const size_t step = (size_t)256 * p.d;
 #pragma unroll
     for (int it = 0; it < CPT; ++it) {  // Nc <= 256 * CPT rows, 256 per round of the sixteen waves
       const int j0 = wave * 16 + it * 256;
       if (j0 < Nc) {
         const bf16x8 af = ss_tr_frag(Gs, gs, 0, j0, lane);  // A(m = context j0 + i, k = query row) = G[k][m]
-        f32x4 acc[NF];
 #pragma unroll
-        for (int b = 0; b < NF; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[b], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int b = 0; b < NF; ++b) dcacc[it][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[b], dcacc[it][b], 0, 0, 0);
+      }
+    }
+  }
+  // dQ of the block: add the 8 K slices in order
+  for (int e = tid; e < SS_ROWS * TW; e += 1024) {
+    const int r = e / TW, ccol = e - r * TW;
+    if (rb * SS_ROWS + r < p.B) {
+      float s = red[e];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) s += red[k * SS_ROWS * TW + e];
+      p.dQ[(size_t)(rb * SS_ROWS + r) * p.d + n0 + ccol] = s * sc;
+    }
+  }
+  }  // row blocks
+
+  __syncthreads();  // every block's row losses are in s_rl (and red is free)
+  if (lead && tid == 0) {
+    double tot = 0.0;
+    for (int r = 0; r < p.B; ++r) tot += (double)s_rl[r];
+    p.loss_sum[0] = (float)tot * p.loss_scale;
+    red[0] = (float)tot * p.loss_scale;  // for the stamp below
+  }
+  {
+    const bool stamp = lead && p.stamp_period > 0;  // column 0 of d belongs to workgroup 0
+    float lsum = 0.f;
+    if (stamp) {  // workgroup-uniform
+      __syncthreads();
+      lsum = red[0];
+    }
+    float* out = p.dC + (size_t)(wave * 16 + g * 4) * p.d + n0 + i;
+    const size_t step = (size_t)256 * p.d;
+#pragma unroll
+    for (int it = 0; it < CPT; ++it) {
+      const int j0 = wave * 16 + it * 256;
+      if (j0 < Nc) {
         float* o = out;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (j0 + g * 4 + r < Nc) {
 #pragma unroll
             for (int b = 0; b < NF; ++b) {
-              float v = acc[b][r] * sc;
-              if (b == 0 && i == 0 && stamp && (j0 + g * 4 + r) % p.stamp_period == p.stamp_row) v = s_rl[0];
-              o[b * 16] = v;
+              float vv = dcacc[it][b][r] * sc;
+              if (b == 0 && i == 0 && stamp && (j0 + g * 4 + r) % p.stamp_period == p.stamp_row) vv = lsum;
+              o[b * 16] = vv;
             }
           }
           o += p.d;
         }
       }
       out += step;
-    }
-  }
-  // dQ: add the 8 K slices in order
-  for (int e = tid; e < SS_ROWS * TW; e += 1024) {
-    const int r = e / TW, ccol = e - r * TW;
-    if (r < p.B) {
-      float s = red[e];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) s += red[k * SS_ROWS * TW + e];
-      p.dQ[(size_t)r * p.d + n0 + ccol] = s * sc;
     }
   }
   DPRHOT_TM(15);

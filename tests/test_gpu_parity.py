@@ -314,6 +314,69 @@ def test_production_packed_step_every_rank_full_size(name, kn, dev):
     assert np.array_equal(ranks, g["ranks"][own * B:(own + 1) * B])
 
 
+@pytest.mark.parametrize("B,K,d,T,ragged", [(64, 8, 768, 1.0, True), (48, 4, 256, 0.5, True), (40, 16, 128, 0.05, False), (64, 2, 1024, 1.0, False),
+                                            (33, 8, 64, 1.0, True), (64, 12, 768, 1.0, True)])
+def test_two_row_blocks_in_the_fused_softmax_backward_kernel(B, K, d, T, ragged, kn, dev):
+    """32 < B <= 64 (the per-GPU batch of the DRAGON / NQ recipes) with up to 256 contexts: the step is still TWO launches -- the
+    fused softmax + backward kernel takes two turns of 32 rows with the C tile resident and dC accumulated in registers
+    (step_small.h, NRB = 2); wider shapes of the list take the three-launch plan.  The whole operator against the fp64 oracle,
+    AMP-style grad_output included, and the fused kernel against the three-launch plan."""
+    from dpr_scale_amd import _lib, hotpath
+
+    q, c, y, m = O.synth_embeddings(5000 + B + K, B, K, d, "U", ragged)
+    ref = O.training_step_global(q, c, y, m, T)
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = hotpath.inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), T)
+    (loss * 4.0).backward()
+    assert abs(loss.item() - ref["loss"]) <= LOSS_RTOL * max(1.0, abs(ref["loss"]))
+    assert rel(tq.grad.cpu().numpy() / 4.0, ref["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy() / 4.0, ref["dC"]) <= GRAD_RTOL
+    # the same step with the fused kernel switched off (three launches): logsumexp, G and gradients agree
+    Nc = B * K
+    if Nc % 8 == 0:
+        outs = []
+        for off in (0, 1):
+            _lib.set_option("no_small_step", off)
+            try:
+                Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+                Cb = torch.empty((Nc, d), dtype=torch.bfloat16, device=dev)
+                rl, lse, ls, G, dQ, dC = kn.inbatch_step_f32(t(q, dev), t(c, dev), Qb, Cb, t(y, dev), 0, t(m.astype(np.uint8), dev), 1.0 / T,
+                                                             1.0 / (T * B))
+                outs.append((lse.cpu().numpy(), G.float().cpu().numpy(), dQ.cpu().numpy(), dC.cpu().numpy(), ls.item(), rl.cpu().numpy()))
+            finally:
+                _lib.set_option("no_small_step", 0)
+        a, b = outs
+        assert rel(a[0], ref["lse"]) <= LOGIT_RTOL and rel(a[0], b[0]) <= 1e-5
+        assert rel(a[1], b[1]) <= 1e-2 and rel(a[2], b[2]) <= 2e-3 and rel(a[3], b[3]) <= 2e-3
+        assert abs(a[4] - b[4]) <= 1e-5 * max(1.0, abs(b[4])) and abs(a[4] - a[5].sum()) <= 1e-4 * max(1.0, abs(a[4]))
+
+
+def test_two_row_blocks_in_the_packed_multi_rank_step(kn, dev):
+    """cfg5-like ranks over a small world (W 2 x B 64 x K 2 x d 1024 -> 272 gathered columns): the packed step on the two-block fused
+    kernel, loss stamp included, against the oracle of the global step."""
+    meta = dict(W=2, B=64, K=2, d=1024, seed=9100, dist="U", ragged=True)
+    W, B, K, d = 2, 64, 2, 1024
+    parts, rows_c, Cb = _packed_world(meta, kn, dev)
+    n_ctx = B * K
+    Q = np.concatenate([p[0] for p in parts])
+    C = np.concatenate([p[1] for p in parts])
+    y = np.concatenate([p[2] + r * n_ctx for r, p in enumerate(parts)])
+    m = np.concatenate([p[3] for p in parts])
+    ref = O.training_step_global(Q, C, y, m, 1.0)
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
+    local = []
+    for r in range(W):
+        rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), 1.0, 1.0 / (W * B))
+        local.append(ls.item())
+        dC += dcp.double()
+        assert rel(dq.cpu().numpy(), ref["dQ"][r * B:(r + 1) * B]) <= GRAD_RTOL
+    assert abs(sum(local) / (W * B) - ref["loss"]) <= LOSS_RTOL * max(1.0, abs(ref["loss"]))
+    chunks = dC.cpu().numpy().reshape(W, rows_c, d)
+    assert rel(chunks[:, :n_ctx].reshape(W * n_ctx, d), ref["dC"]) <= GRAD_RTOL
+    for r in range(W):
+        assert abs(chunks[r, n_ctx, 0] - sum(local)) <= 1e-5 * max(1.0, abs(sum(local)))  # the piggy-backed loss numerator
+
+
 @pytest.mark.parametrize("W,B,K,d", [(8, 32, 8, 768), (4, 64, 8, 512)])
 def test_packed_step_narrow_sim_units_against_the_oracle(W, B, K, d, kn, dev):
     """The 64-column sim unit of the skinny plan (chosen when the 128-column units would leave most CUs idle: cfg2 gathered over 8
