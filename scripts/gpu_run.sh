@@ -46,7 +46,7 @@ for task in "$@"; do
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
         i=$((i+1)); rm -rf /tmp/prof_pmc$i
-        ( cd /tmp && timeout 600 rocprofv3 --pmc $set -d /tmp/prof_pmc$i -o p -- python $GRAFT_REPO_ROOT/bench_sweep.py --shapes 8192:8192 --reps 5 ) > $OUT/prof_pmc$i.log 2>&1; echo "pmc$i rc=$?"
+        ( cd /tmp && timeout 600 rocprofv3 --pmc $set -d /tmp/prof_pmc$i -o p -- python $GRAFT_REPO_ROOT/bench_sweep.py --shapes 8192x8192 ) > $OUT/prof_pmc$i.log 2>&1; echo "pmc$i rc=$?"
         python scripts/pmc_query.py "$(find /tmp/prof_pmc$i -name '*.db' | head -1)" >> $OUT/pmc_8192.txt
       done; cut -c1-200 $OUT/pmc_8192.txt | head -60 ;;
     sweep)  ( timeout 900 python bench_sweep.py $arg ) > $OUT/sweep.jsonl 2> $OUT/sweep.err; echo "sweep rc=$?"; python scripts/show_sweep.py $OUT/sweep.jsonl 2>/dev/null | head -30 ;;
