@@ -125,6 +125,11 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   for (int rb = 0; rb < NRB; ++rb) {
   // ---- all global reads of the block, back to back (nothing is used before the last one is issued) ----
   DPRHOT_TM(8);
+  const int row = rb * SS_ROWS + lrow;
+  const bool active = row < p.B;
+  const int64_t yraw = active ? p.y[row] : (int64_t)-1;
+  uint4 qreg = make_uint4(0u, 0u, 0u, 0u);
+  if (active && tr < TC) qreg = *reinterpret_cast<const uint4*>(p.Qb + (size_t)row * p.d + n0 + tr * 8);
   uint4 creg[CU];  // the C tile: loaded and parked in LDS by the first block only
   if (rb == 0) {
 #pragma unroll
@@ -134,11 +139,6 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
       if (j < Nc) creg[u] = *reinterpret_cast<const uint4*>(p.Cb + (size_t)j * p.d + n0 + cc * 8);
     }
   }
-  const int row = rb * SS_ROWS + lrow;
-  const bool active = row < p.B;
-  const int64_t yraw = active ? p.y[row] : (int64_t)-1;
-  uint4 qreg = make_uint4(0u, 0u, 0u, 0u);
-  if (active && tr < TC) qreg = *reinterpret_cast<const uint4*>(p.Qb + (size_t)row * p.d + n0 + tr * 8);
   // partial-logit slabs (at most NS): every load is issued unconditionally on a valid address (absent slabs re-read
   // slab 0 and are dropped by a select at the add) -- a loop over p.splits would wait for one slab before asking for
   // the next: dependent trips to L2 instead of one
@@ -256,6 +256,14 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   DPRHOT_TM(12);
   __syncthreads();
   DPRHOT_TM(13);
+  if constexpr (NRB == 1) {  // one block: the loss is complete here, summed under the GEMMs
+    if (lead && tid == 0) {
+      double tot = 0.0;
+      for (int r = 0; r < p.B; ++r) tot += (double)s_rl[r];
+      p.loss_sum[0] = (float)tot * p.loss_scale;
+      s_rl[0] = (float)tot * p.loss_scale;  // (row losses are no longer needed) for the stamp below, read after the next barrier
+    }
+  }
 
   // ---- dQ[rows of the block, n0:n0+TW] = G[32, Nc] x C[Nc, TW]: wave w -> rows (w & 1) * 16.., K slice w >> 1 of 8; partial sums
   //      through LDS, added in slice order ----
@@ -288,13 +296,43 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
     bf16x8 bq[NF];
 #pragma unroll
     for (int b = 0; b < NF; ++b) bq[b] = ss_tr_frag(Qs, TS, 0, b * 16, lane);
+    if constexpr (NRB == 1) {  // one block: every 16-row block of contexts is stored as soon as it is multiplied
+      const bool stamp = lead && p.stamp_period > 0;  // column 0 of d belongs to workgroup 0
+      float* out = p.dC + (size_t)(wave * 16 + g * 4) * p.d + n0 + i;
+      const size_t step = (size_t)256 * p.d;
 #pragma unroll
-    for (int it = 0; it < CPT; ++it) {  // Nc <= 256 * CPT rows, 256 per round of the sixteen waves
-      const int j0 = wave * 16 + it * 256;
-      if (j0 < Nc) {
-        const bf16x8 af = ss_tr_frag(Gs, gs, 0, j0, lane);  // A(m = context j0 + i, k = query row) = G[k][m]
+      for (int it = 0; it < CPT; ++it) {  // Nc <= 256 * CPT rows, 256 per round of the sixteen waves
+        const int j0 = wave * 16 + it * 256;
+        if (j0 < Nc) {
+          const bf16x8 af = ss_tr_frag(Gs, gs, 0, j0, lane);  // A(m = context j0 + i, k = query row) = G[k][m]
+          f32x4 acc[NF];
 #pragma unroll
-        for (int b = 0; b < NF; ++b) dcacc[it][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[b], dcacc[it][b], 0, 0, 0);
+          for (int b = 0; b < NF; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[b], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          float* o = out;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (j0 + g * 4 + r < Nc) {
+#pragma unroll
+              for (int b = 0; b < NF; ++b) {
+                float vv = acc[b][r] * sc;
+                if (b == 0 && i == 0 && stamp && (j0 + g * 4 + r) % p.stamp_period == p.stamp_row) vv = s_rl[0];
+                o[b * 16] = vv;
+              }
+            }
+            o += p.d;
+          }
+        }
+        out += step;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < CPT; ++it) {
+        const int j0 = wave * 16 + it * 256;
+        if (j0 < Nc) {
+          const bf16x8 af = ss_tr_frag(Gs, gs, 0, j0, lane);
+#pragma unroll
+          for (int b = 0; b < NF; ++b) dcacc[it][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bq[b], dcacc[it][b], 0, 0, 0);
+        }
       }
     }
   }
@@ -310,6 +348,7 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
   }
   }  // row blocks
 
+  if constexpr (NRB > 1) {
   __syncthreads();  // every block's row losses are in s_rl (and red is free)
   if (lead && tid == 0) {
     double tot = 0.0;
@@ -347,6 +386,7 @@ __global__ __launch_bounds__(1024) void step_small_kernel(StepSmallArgs p) {
       out += step;
     }
   }
+  }  // NRB > 1
   DPRHOT_TM(15);
 }
 
