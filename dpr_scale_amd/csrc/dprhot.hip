@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -143,8 +143,10 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"no_wide", 0, "1 keeps vocabulary-wide fp32 operands on the register-staged sim kernel (wide.h off)"},
     {"wide_nocopy", 0, "TIMING EXPERIMENT ONLY: 1 drops the bf16 copy-out of wide.h (the backward then reads garbage)"},
     {"no_8p_store", 0, "1 keeps dprhot_sim_fwd's large shapes on the round-1 256 x 256 kernel (gemm256.h)"},
+    {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
+    {"nt_stores", 1, "0 writes the router-width fp32 gradients with plain instead of non-temporal stores (A/B of the cache policy)"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -490,6 +492,7 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
   p.tpr = tpr;
   int rpb = 1024 / tpr;
   if (rpb > B) rpb = B;
+  if (p.splits > 4 && rpb > cdiv(B, 128)) rpb = cdiv(B, 128);  // many slabs: the launch is the slab read (up to 16 MB) -- >= 128 workgroups
   if (rpb < 1) rpb = 1;
   p.threads = rpb * tpr;
   p.blocks = cdiv(B, rpb);
@@ -501,6 +504,13 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
 bool wide_sim_ok(int B, int Nc, int d, const FwdPlan& fp) {
   return !opt(OPT_NO_WIDE) && d >= 4096 && Nc <= 4096 && B <= 256 && fp.short_rows && d % WD_KS == 0 && fp.kchunk % WD_KS == 0 &&
          (double)Nc * d * 4 < 4.0e9 && (double)B * d * 4 < 4.0e9;
+}
+
+// backward of the same shape class on the units of skinny.h (dprhot_inbatch_bwd): rows in blocks of 32 up to 128, vectors in whole
+// 64-column dQ tiles, contexts within one dQ slice (<= 24 ring steps of 64), 32-bit element offsets
+bool wide_bwd_ok(int B, int Nc, int d) {
+  return !opt(OPT_NO_WIDE_BWD) && !opt(OPT_NO_SKINNY) && force_tile() < 0 && !unfused_bwd() && d >= 4096 && d % 64 == 0 && B <= SK_MAXB &&
+         B % 32 == 0 && Nc % 8 == 0 && Nc >= 64 && Nc <= 1536 && (double)Nc * d < 4.0e9;
 }
 
 int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
@@ -595,7 +605,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     float* part = g_dq_part != nullptr ? g_dq_part : reinterpret_cast<float*>(ws + wl.dq_part);
     const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = sk.nt * (d / SK_DN);
     SkBwdArgs b{G, Qb, Cb, B, Nc, d, h_scale, d_scale, dC_part, rl, loss_sum, g_loss_scale, g_dc_bf16 ? 1 : 0,
-                g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, sk.ksteps, sk.nslices, part, ndq_pad};
+                g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, sk.ksteps, sk.nslices, part, dQ, ndq_pad};
     const size_t lds = sk_bwd_lds();
     static AttrOnce attr_done;
     if (!attr_done) {
@@ -604,7 +614,8 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     }
     hipLaunchKernelGGL(sk_bwd_kernel, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
     HIP_TRY(hipGetLastError());
-    if (g_dq_part == nullptr) {  // (else the caller's finishing launch forms dQ from the slabs: dprhot_rescale_grads)
+    if (g_dq_part == nullptr && sk.nslices > 1) {  // (else the caller's finishing launch forms dQ from the slabs: dprhot_rescale_grads;
+                                                   //  one slice: the dQ units stored the scaled sum themselves)
       const size_t n4 = (size_t)B * d / 4;
       hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
       HIP_TRY(hipGetLastError());
@@ -1148,6 +1159,26 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     return DPRHOT_OK;
   }
   REQUIRE(aligned16(G) && aligned16(Q) && aligned16(C) && aligned16(dQ) && aligned16(dC_part), "pointers must be 16-byte aligned");
+  if (wide_bwd_ok(B, Nc, d) && g_packed.stamp_src == nullptr) {
+    // Vocabulary-wide vectors under few rows (CITADEL router: 128 x 1024 x 30528): every unit of either GEMM is a short K loop in front
+    // of a large store -- the unit shapes of skinny.h (whole operand footprint in flight by LDS-DMA, stores through LDS in whole
+    // lines), dC tiles and dQ tiles side by side in one launch; the contexts fit one dQ slice, so no partial sums and no reduction.
+    // The 141 MB of fp32 gradients leave with non-temporal stores: nobody re-reads them inside the step, and written normally they push
+    // the step's operands out of the 256 MB Infinity Cache (measured, scratch/router_ab.py: step 116 -> 99.5 us; the same policy on the
+    // 8192^2 launches -- stored logits, 256 x 256 backward -- LOST 5-10 % and is not used there: profiles/r03_nt_stores_ab.txt).
+    const int ksteps = cdiv(Nc, 64);
+    const int ndq = d / SK_QN, ndq_pad = (ndq + 7) & ~7, ndc = cdiv(Nc, SK_COLS) * cdiv(d, SK_DN);
+    SkBwdArgs b{G, Q, C, B, Nc, d, h_scale, d_scale, dC_part, nullptr, nullptr, 1.0f, 0, 0, 0, ksteps, 1, nullptr, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0};
+    const size_t lds = sk_bwd_lds();
+    static AttrOnce attr_done;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(sk_bwd_kernel, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
+    HIP_TRY(hipGetLastError());
+    return DPRHOT_OK;
+  }
   const WsLayout wl = ws_layout(B, Nc, d);
   const DqPlan p = dq_plan(B, Nc, d);
   char* ws = static_cast<char*>(workspace);

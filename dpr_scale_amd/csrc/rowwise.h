@@ -383,7 +383,21 @@ __global__ __launch_bounds__(1024) void gfinal_short_kernel(GShortArgs p) {
     if (active && chunk < cpr) {
       const float* src = p.slabs + (size_t)row * p.Nc + (size_t)chunk * 8;
       float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-      for (int z = 1; z < p.splits; ++z) {
+      int z = 1;
+      for (; z + 7 < p.splits; z += 8) {  // many slabs (vocabulary-wide vectors: up to 32): eight slabs' loads in flight, added in slab order
+        float4 a2[8], b2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a2[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + u) * p.slab_stride);
+          b2[u] = *reinterpret_cast<const float4*>(src + (size_t)(z + u) * p.slab_stride + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a.x += a2[u].x; a.y += a2[u].y; a.z += a2[u].z; a.w += a2[u].w;
+          b.x += b2[u].x; b.y += b2[u].y; b.z += b2[u].z; b.w += b2[u].w;
+        }
+      }
+      for (; z < p.splits; ++z) {
         const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)z * p.slab_stride);
         const float4 b2 = *reinterpret_cast<const float4*>(src + (size_t)z * p.slab_stride + 4);
         a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;

@@ -393,15 +393,17 @@ struct SkBwdArgs {
   float h_scale;
   const float* d_scale;
   void* dC;               // [Nc][d] fp32, or bf16 when dc_bf16 (the wire format of the reduce-scatter, written here)
-  const float* row_loss;  // [B] (sk_g_kernel)
-  float* loss_sum;        // [1] out: loss_scale * sum of the row losses (written by dC unit 0)
+  const float* row_loss;  // [B] (sk_g_kernel), or nullptr: backward only -- the forward call formed the loss, no stamp
+  float* loss_sum;        // [1] out: loss_scale * sum of the row losses (written by dC unit 0; row_loss != nullptr)
   float loss_scale;
   int dc_bf16;
   int stamp_period, stamp_row;  // > 0 (fp32 dC only): dC[m][0] = loss_sum where m % stamp_period == stamp_row (EpiScaleF32)
   int ksteps;             // 64-context steps per dQ slice
   int nslices;
-  float* part;            // [nslices][B][d] dQ partial sums
-  int ndq_pad;            // dQ units rounded up to a multiple of 8 (keeps workgroup % 8 == XCD for the dC units)
+  float* part;            // [nslices][B][d] dQ partial sums (nslices > 1)
+  float* dQ;              // [B][d]: nslices == 1 -- the one slice IS the sum, scaled and stored here
+  int ndq_pad;
+  int nt_store = 0;       // 1: fp32 gradients leave with non-temporal stores (hundreds of MB nobody re-reads soon: keep them out of the caches)            // dQ units rounded up to a multiple of 8 (keeps workgroup % 8 == XCD for the dC units)
 };
 
 constexpr int SK_DC_TS = SK_DN + 4;  // fp32 output tile row stride in LDS
@@ -423,7 +425,7 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
   uint16_t* const Gs = sk_smem;                 // [128 k = query row][128 m = context]
   uint16_t* const Qs = sk_smem + kImg;          // [128 k = query row][128 n = d column]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ndt = p.d / SK_DN;
+  const int ndt = (p.d + SK_DN - 1) / SK_DN;  // d % 64 == 0: the last tile may be half a tile (router width 30528 = 238.5 x 128)
   const int dt = unit % ndt, ct = unit / ndt;
   const int n0 = ct * SK_COLS, c0 = dt * SK_DN;
   const int kmax = p.B;  // contraction length
@@ -437,14 +439,15 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
       // contexts beyond Nc (ragged last tile) only feed output rows that are never stored: any valid address will do
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.G + (size_t)krow * p.Nc + min(n0 + col, p.Nc - 8)),
                                        (g2_lds_ptr*)(Gs + (wave * nins + j) * 4 * SK_COLS), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.Qb + (size_t)krow * p.d + c0 + col),
+      // (columns beyond d in a ragged last tile feed output columns that are never stored)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.Qb + (size_t)krow * p.d + min(c0 + col, p.d - 8)),
                                        (g2_lds_ptr*)(Qs + (wave * nins + j) * 4 * SK_DN), 16, 0, 0);
     }
   }
   const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
-  const bool stamp = dt == 0 && p.stamp_period > 0 && !p.dc_bf16;
+  const bool stamp = dt == 0 && p.stamp_period > 0 && !p.dc_bf16 && p.row_loss != nullptr;
   float lsum = 0.f;
-  if (stamp || unit == 0) {
+  if ((stamp || unit == 0) && p.row_loss != nullptr) {
     lsum = sk_loss_sum(p.row_loss, p.B, lane) * p.loss_scale;
     if (unit == 0 && tid == 0) p.loss_sum[0] = lsum;
   }
@@ -489,7 +492,7 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
     for (int it = 0; it < 8; ++it) {
       const int e = tid + it * SK_THREADS, row = e >> 4, c8 = e & 15;
       const int m = n0 + row;
-      if (m < p.Nc) {
+      if (m < p.Nc && c0 + c8 * 8 < p.d) {
         const float4 a = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + c8 * 8);
         const float4 b = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + c8 * 8 + 4);
         *reinterpret_cast<uint4*>(out + (size_t)m * p.d + c0 + c8 * 8) = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
@@ -501,10 +504,11 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
     for (int it = 0; it < 16; ++it) {
       const int e = tid + it * SK_THREADS, row = e >> 5, cq = e & 31;
       const int m = n0 + row;
-      if (m < p.Nc) {
+      if (m < p.Nc && c0 + cq * 4 < p.d) {
         float4 v = *reinterpret_cast<const float4*>(T + row * SK_DC_TS + cq * 4);
         if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
-        *reinterpret_cast<float4*>(out + (size_t)m * p.d + c0 + cq * 4) = v;
+        if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)m * p.d + c0 + cq * 4));
+        else *reinterpret_cast<float4*>(out + (size_t)m * p.d + c0 + cq * 4) = v;
       }
     }
   }
@@ -642,11 +646,18 @@ __device__ __forceinline__ void sk_dq_unit(const SkBwdArgs& p, int unit, uint16_
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(wave * 32 + a * 16 + g4 * 4 + r) * TS + b * 16 + i16] = acc[a][b][r];
   sk_barrier();
-  float* out = p.part + (size_t)ks * p.B * p.d;
+  const bool fin = p.nslices == 1;  // the one slice covers every context: this tile IS dQ's
+  float* out = fin ? p.dQ : p.part + (size_t)ks * p.B * p.d;
+  const float sc = fin ? p.h_scale * (p.d_scale ? *p.d_scale : 1.0f) : 1.0f;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int e = tid + it * SK_THREADS, row = e >> 4, cq = e & 15;
-    if (row < p.B) *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + cq * 4) = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
+    if (row < p.B) {
+      float4 v = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
+      else *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + cq * 4) = v;
+    }
   }
   DPRHOT_TMB(2, 3);
 }

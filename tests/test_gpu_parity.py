@@ -449,7 +449,8 @@ def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
     assert rel(chunk[:n_ctx].sum(0), g["dc_own_colsum"]) <= GRAD_RTOL
 
 
-@pytest.mark.parametrize("B,K,d,ragged", [(128, 8, 4128, True), (40, 6, 8192, False), (16, 4, 30528, True), (200, 2, 4096, True)])
+@pytest.mark.parametrize("B,K,d,ragged", [(128, 8, 4128, True), (40, 6, 8192, False), (16, 4, 30528, True), (200, 2, 4096, True),
+                                          (128, 8, 4160, True), (64, 11, 4096, False), (96, 4, 6208, True), (32, 9, 4096, False), (32, 8, 30528, False)])
 def test_vocabulary_wide_fp32_operands_through_the_lds_dma_sim(B, K, d, ragged, kn, dev):
     """csrc/wide.h: fp32 operands with a contraction thousands long (the CITADEL router shape class) go global -> LDS by DMA and are
     rounded to bf16 on the fragment read; split-K slabs, bf16 copy-out for the backward.  Loss / gradients against the fp64 oracle,
@@ -463,8 +464,18 @@ def test_vocabulary_wide_fp32_operands_through_the_lds_dma_sim(B, K, d, ragged, 
     loss.backward()
     assert abs(loss.item() - ref["loss"]) <= LOSS_RTOL * max(1.0, abs(ref["loss"]))
     assert rel(tq.grad.cpu().numpy(), ref["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy(), ref["dC"]) <= GRAD_RTOL
-    # the forward alone, both kernels: logits bit-comparable up to the summation order of the slabs
     Nc = B * K
+    if B % 32 == 0 and B <= 128 and d % 64 == 0 and Nc % 8 == 0 and Nc <= 1536:
+        # these shapes take the backward units of csrc/skinny.h (dC tiles and unsplit dQ tiles side by side, one launch): the same G
+        # through the generic pair kernel (option no_wide_bwd) must give the same gradients up to the summation order of the K ranges
+        _lib.set_option("no_wide_bwd", 1)
+        try:
+            tq2, tc2 = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+            hotpath.inbatch_contrastive_loss(tq2, tc2, t(y, dev), t(m, dev), 1.0).backward()
+        finally:
+            _lib.set_option("no_wide_bwd", 0)
+        assert rel(tc2.grad.cpu().numpy(), tc.grad.cpu().numpy()) <= 1e-5 and rel(tq2.grad.cpu().numpy(), tq.grad.cpu().numpy()) <= 1e-5
+    # the forward alone, both kernels: logits bit-comparable up to the summation order of the slabs
     if Nc % 8 == 0:
         outs = []
         for no_wide in (0, 1):
