@@ -144,7 +144,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"wide_nocopy", 0, "TIMING EXPERIMENT ONLY: 1 drops the bf16 copy-out of wide.h (the backward then reads garbage)"},
     {"no_8p_store", 0, "1 keeps dprhot_sim_fwd's large shapes on the round-1 256 x 256 kernel (gemm256.h)"},
     {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
-    {"nt_stores", 1, "0 writes the router-width fp32 gradients with plain instead of non-temporal stores (A/B of the cache policy)"},
+    {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
 };
 int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
@@ -605,7 +605,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     float* part = g_dq_part != nullptr ? g_dq_part : reinterpret_cast<float*>(ws + wl.dq_part);
     const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = sk.nt * (d / SK_DN);
     SkBwdArgs b{G, Qb, Cb, B, Nc, d, h_scale, d_scale, dC_part, rl, loss_sum, g_loss_scale, g_dc_bf16 ? 1 : 0,
-                g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, sk.ksteps, sk.nslices, part, dQ, ndq_pad};
+                g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, sk.ksteps, sk.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0};
     const size_t lds = sk_bwd_lds();
     static AttrOnce attr_done;
     if (!attr_done) {
