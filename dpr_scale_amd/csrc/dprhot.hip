@@ -387,16 +387,19 @@ DqPlan dq_plan(int B, int Nc, int d) {
 
 int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
 
-// Few query rows against many contexts (skinny.h): B <= 128 (a multiple of 32), d a multiple of 128 up to 1024, 2048 <= Nc <= 16384
-// (measured: at Nc ~ 1000 the short-row plan below is as fast or faster)
-// (beyond that the per-unit recomputation of the row logsumexp from Nc / 128 tile values stops being cheap).
+// Few query rows against many contexts (skinny.h): B <= 128 (a multiple of 32), d a multiple of 128 up to 1024, 512 (256 above 64 rows) <= Nc <= 16384
+// (beyond that the per-unit recomputation of the row logsumexp from Nc / 128 tile values stops being cheap).  Lower bound, measured
+// against the three-launch plan and the fused small step (scripts/bench_rankstep.py, round 3): 128 x 520 18.2 vs 22.0 us, 128 x 1032
+// 18.5 vs 26.2, 96 x 776 17.8 vs 22.8, 64 x 776 17.1 vs 18.0, 64 x 1088 18.2 vs 20.1 (64 x 520: 17.0 both); with B = 32 the fused
+// small step wins up to ~1000 columns (776: 16.2 vs 16.4; 904: 16.4 vs 16.5) and loses above (1056: 17.4 vs 16.6).
 struct SkPlan { bool ok; int nt, nts, scols, nrb, ksteps, nslices; };
 SkPlan sk_plan(int B, int Nc, int d) {
   const bool off = opt(OPT_NO_SKINNY) != 0, no_small = opt(OPT_NO_SMALL_STEP) != 0;  // (no_small lets this plan take the small-step shapes)
-  constexpr int min_nc = 2048;
+  const int min_nc = B > 64 ? 256 : 512;  // (128 x 264: 17.8 vs 21.1 us; 96 x 392: 17.5 vs 21.2; 64 x 392: 17.0 vs 16.8)
+  const bool fused_small = (B <= SS_ROWS && Nc <= 1024) || (B <= SS_MAXB && Nc <= 256);  // shapes the fused small step keeps (small_step_ok)
   SkPlan p{};
   p.ok = !off && force_tile() < 0 && !unfused_bwd() && B <= SK_MAXB && B % 32 == 0 && d % 128 == 0 && d >= 128 && d <= 1024 && Nc >= min_nc &&
-         Nc <= 16384 && (no_small || !(B <= SS_MAXB && Nc <= SS_MAXNC));
+         Nc <= 16384 && (no_small || !fused_small);
   p.nt = cdiv(Nc, SK_COLS);
   {
     // sim unit width: 128 columns x 4 ring slots, or 64 columns x 8 slots (twice the units, two thirds of a unit's K range in flight).
