@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -145,8 +145,9 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"no_8p_store", 0, "1 keeps dprhot_sim_fwd's large shapes on the round-1 256 x 256 kernel (gemm256.h)"},
     {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
     {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
+    {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -416,6 +417,9 @@ SkPlan sk_plan(int B, int Nc, int d) {
   if (!p.ok) return p;  // (also keeps d < 64 away from the division below: every entry point derives this plan for its workspace layout)
   const int nk = cdiv(Nc, 64), ndt = d / SK_QN;
   int ns = kNumCU / 2 / ndt;  // dQ units: (slice of contexts) x (64 columns of d); ~half a unit per CU measured best: the
+  if (nk <= 8) ns = 1;  // up to 512 contexts one slice is short enough, and it needs no partial sums and no reduction launch (128 x 264: 17.8 -> 15.7 us;
+                        // at 520 contexts it is a tie, beyond that the unsplit units are the launch's long pole)
+  if (opt(OPT_SK_DQ_SLICES) > 0) ns = opt(OPT_SK_DQ_SLICES);
   if (ns < 1) ns = 1;         // units run next to the dC units, and fewer slices mean fewer partial sums to write and re-read
   if (ns > 64) ns = 64;   // bounds the fp32 partial traffic
   p.ksteps = cdiv(nk, ns);
@@ -1363,14 +1367,15 @@ int dprhot_train_dq_slabs(int B, int Nc, int d, int* h_nslabs) {
   REQUIRE(h_nslabs != nullptr, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   const SkPlan sk = sk_plan(B, Nc, d);
-  *h_nslabs = sk.ok ? sk.nslices : 0;  // the other plans either do not split dQ or combine it inside their last launch's shadow
+  *h_nslabs = sk.ok && sk.nslices > 1 ? sk.nslices : 0;  // the other plans (and a one-slice few-rows plan) do not split dQ or combine it themselves
   return DPRHOT_OK;
 }
 
 static int train_dq_part_ok(const float* dq_part, int B, int Nc, int d) {
   if (dq_part == nullptr) return DPRHOT_OK;
   REQUIRE(aligned16(dq_part), "dq_part must be 16-byte aligned");
-  if (!sk_plan(B, Nc, d).ok) return fail(DPRHOT_E_INVALID, "train_step: dq_part given but B=%d Nc=%d d=%d leaves no slabs (dprhot_train_dq_slabs = 0)", B, Nc, d);
+  const SkPlan sk = sk_plan(B, Nc, d);
+  if (!sk.ok || sk.nslices <= 1) return fail(DPRHOT_E_INVALID, "train_step: dq_part given but B=%d Nc=%d d=%d leaves no slabs (dprhot_train_dq_slabs = 0)", B, Nc, d);
   return DPRHOT_OK;
 }
 

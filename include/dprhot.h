@@ -49,7 +49,7 @@ const char* dprhot_last_error(void);
 
 /* Process-wide test / A-B switches of the shape plans (all default to "plan decides"; production never calls this).  Names:
  *   tile (-1 | 0..5)   no_tr   unfused_bwd   big_min (256)   no_nl   no_big_bwd   no_skinny   no_small_step   no_short
- *   sk_cols (0 | 64 | 128)   search_unfused   no_8pb   no_wide   no_8p_store   no_wide_bwd   nt_stores (1)
+ *   sk_cols (0 | 64 | 128)   search_unfused   no_8pb   no_wide   no_8p_store   no_wide_bwd   nt_stores (1)   sk_dq_slices (0)
  * Setting one changes the plans of every later call on every thread (workspace sizes included: query them after setting).
  * DPRHOT_E_INVALID for an unknown name. */
 int dprhot_set_option(const char* name, int value);

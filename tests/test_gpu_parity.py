@@ -667,7 +667,25 @@ def test_corpus_search_worst_case_order_and_reversed_shards(kn, dev):
         assert torch.equal(i, order) and torch.equal(v, S.gather(1, order))
 
 
-@pytest.mark.parametrize("B,K,d", [(32, 8, 768), (4, 2, 128), (8, 64, 768), (5, 5, 80), (64, 16, 768), (32, 66, 768)])
+@pytest.mark.parametrize("B,K,d", [(128, 3, 768), (128, 4, 768), (128, 5, 768), (96, 8, 512), (64, 12, 1024), (32, 40, 768)])
+def test_operator_on_the_mid_size_shapes_of_the_few_rows_plan(B, K, d, kn, dev):
+    """Shapes the few-rows plan took over at the end of round 3 (csrc/dprhot.hip sk_plan: from 256 / 512 / 1024 columns depending on
+    the rows; up to 512 contexts its dQ units are unsplit and dprhot_train_dq_slabs reports no slabs): the autograd operator with a
+    non-unit grad_output against the oracle."""
+    from dpr_scale_amd import _lib, hotpath
+
+    q, c, y, m = O.synth_embeddings(7300 + B + K, B, K, d, "U", False)
+    ref = O.training_step_global(q, c, y, m, 0.5)
+    Nc = B * K
+    assert (_lib.train_dq_slabs(B, Nc, d) == 0) == ((Nc + 63) // 64 <= 8)  # (every shape of this test is on the few-rows plan)
+    tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+    loss = hotpath.inbatch_contrastive_loss(tq, tc, t(y, dev), t(m, dev), 0.5)
+    (loss * 64.0).backward()
+    assert abs(loss.item() - ref["loss"]) <= LOSS_RTOL * max(1.0, abs(ref["loss"]))
+    assert rel(tq.grad.cpu().numpy() / 64.0, ref["dQ"]) <= GRAD_RTOL and rel(tc.grad.cpu().numpy() / 64.0, ref["dC"]) <= GRAD_RTOL
+
+
+@pytest.mark.parametrize("B,K,d", [(32, 8, 768), (4, 2, 128), (8, 64, 768), (5, 5, 80), (64, 16, 768), (32, 66, 768), (128, 3, 768), (96, 5, 512)])
 def test_whole_step_call_equals_forward_plus_backward(B, K, d, kn, dev):
     """dprhot_inbatch_step_f32 (sim + ONE softmax/dScores/dQ/dC kernel at the small shapes; three launches otherwise)
     against dprhot_inbatch_fwd_f32 followed by dprhot_inbatch_bwd, and against the oracle."""
