@@ -10,6 +10,7 @@
 #   bench:<args>     python bench.py <args> (use + for spaces)
 #   prof-bench       rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of the cfg2 bench loop -> gpurun_out/prof_summary/
 #   prof-rank        the same three passes of the cfg3-per-rank step (scripts/bench_rankstep.py)   -> gpurun_out/prof_rank_summary/
+#   prof-router      the same three passes of the router-width step (bench.py --only router)               -> gpurun_out/prof_router_summary/
 #   prof-op          kernel trace of the autograd operator loop (bench.py --only operator)        -> gpurun_out/prof_op_summary/
 #   pmc8192          SQ counters (MFMA busy, LDS conflicts, waits) of the 8192^2 x 768 launches    -> gpurun_out/pmc_8192.txt
 #   sweep / eval     bench_sweep.py / bench_eval.py                 -> gpurun_out/sweep.jsonl, eval_search.jsonl
@@ -41,6 +42,7 @@ for task in "$@"; do
     bench)  ( timeout 1500 python bench.py $arg ) > $OUT/bench_n1.log 2>&1; echo "bench rc=$?"; tail -n 1 $OUT/bench_n1.log > $OUT/bench_n1.json; cut -c1-1500 $OUT/bench_n1.json ;;
     prof-bench) three_passes bench r03_bench_cfg2 python $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --repeats 3 --only step --driver eager ;;
     prof-rank)  three_passes rank r03_cfg3rank python $GRAFT_REPO_ROOT/scripts/bench_rankstep.py --shapes ${arg:-128:8:768:8} --eager --reps 50 ;;
+    prof-router) three_passes router r03_router python $GRAFT_REPO_ROOT/bench.py --only router ;;
     prof-op)    three_passes op r03_operator python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --repeats 3 --only operator ;;
     pmc8192)
       i=0
