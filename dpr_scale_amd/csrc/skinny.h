@@ -427,7 +427,12 @@ __device__ __forceinline__ void sk_dc_unit(const SkBwdArgs& p, int unit, uint16_
   uint16_t* const Qs = sk_smem + kImg;          // [128 k = query row][128 n = d column]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ndt = (p.d + SK_DN - 1) / SK_DN;  // d % 64 == 0: the last tile may be half a tile (router width 30528 = 238.5 x 128)
-  const int dt = unit % ndt, ct = unit / ndt;
+  // consecutive units run on one XCD (sk_xcd_order): let them share the tile of the LARGER operand -- the G tile (walk the d tiles)
+  // when there are more contexts than vector components, the Q tile (walk the context tiles) at router width, where Q is 7.8 MB and
+  // every tile of it was fetched once per context tile (PMC: 128 MB fetched per launch for 70 MB of operands)
+  const int nctile = (p.Nc + SK_COLS - 1) / SK_COLS;
+  const bool ct_fast = p.Nc < p.d;
+  const int dt = ct_fast ? unit / nctile : unit % ndt, ct = ct_fast ? unit % nctile : unit / ndt;
   const int n0 = ct * SK_COLS, c0 = dt * SK_DN;
   const int kmax = p.B;  // contraction length
   DPRHOT_TMB(1, 0);
