@@ -11,6 +11,7 @@
 #   prof-bench       rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of the cfg2 bench loop -> gpurun_out/prof_summary/
 #   prof-rank        the same three passes of the cfg3-per-rank step (scripts/bench_rankstep.py)   -> gpurun_out/prof_rank_summary/
 #   prof-router      the same three passes of the router-width step (bench.py --only router)               -> gpurun_out/prof_router_summary/
+#   prof-8192        the same three passes of the 8192^2 x 768 launches (bench_sweep.py)                   -> gpurun_out/prof_big_summary/
 #   prof-op          kernel trace of the autograd operator loop (bench.py --only operator)        -> gpurun_out/prof_op_summary/
 #   pmc8192          SQ counters (MFMA busy, LDS conflicts, waits) of the 8192^2 x 768 launches    -> gpurun_out/pmc_8192.txt
 #   sweep / eval     bench_sweep.py / bench_eval.py                 -> gpurun_out/sweep.jsonl, eval_search.jsonl
@@ -43,6 +44,7 @@ for task in "$@"; do
     prof-bench) three_passes bench r03_bench_cfg2 python $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --repeats 3 --only step --driver eager ;;
     prof-rank)  three_passes rank r03_cfg3rank python $GRAFT_REPO_ROOT/scripts/bench_rankstep.py --shapes ${arg:-128:8:768:8} --eager --reps 50 ;;
     prof-router) three_passes router r03_router python $GRAFT_REPO_ROOT/bench.py --only router ;;
+    prof-8192)  three_passes big r03_8192 python $GRAFT_REPO_ROOT/bench_sweep.py --shapes 8192x8192 ;;
     prof-op)    three_passes op r03_operator python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --repeats 3 --only operator ;;
     pmc8192)
       i=0
