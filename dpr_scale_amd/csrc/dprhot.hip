@@ -1166,6 +1166,36 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     return DPRHOT_OK;
   }
   REQUIRE(aligned16(G) && aligned16(Q) && aligned16(C) && aligned16(dQ) && aligned16(dC_part), "pointers must be 16-byte aligned");
+  if (g_packed.stamp_src == nullptr) {
+    // Shapes of the few-rows plan: the same backward units as the one-call step (dC tiles and split-K dQ tiles side by side, then the
+    // slab reduction) for callers that run sim / loss / backward as separate calls (a subclass's own loss on sim_score's logits):
+    // 128 x 8192 x 768 23 -> ~15 us against the generic pair kernel.
+    const SkPlan sk = sk_plan(B, Nc, d);
+    if (sk.ok) {
+      const WsLayout wl = ws_layout(B, Nc, d);
+      char* ws = static_cast<char*>(workspace);
+      if (sk.nslices > 1 && (ws == nullptr || workspace_bytes < wl.total))
+        return fail(DPRHOT_E_WORKSPACE, "inbatch_bwd needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+      float* part = sk.nslices > 1 ? reinterpret_cast<float*>(ws + wl.dq_part) : nullptr;
+      const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = sk.nt * (d / SK_DN);
+      SkBwdArgs b{G, Q, C, B, Nc, d, h_scale, d_scale, dC_part, nullptr, nullptr, 1.0f, 0, 0, 0, sk.ksteps, sk.nslices, part, dQ, ndq_pad,
+                  opt(OPT_NT_STORES) ? 1 : 0};
+      const size_t lds = sk_bwd_lds();
+      static AttrOnce attr_done;
+      if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(sk_bwd_kernel, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
+      HIP_TRY(hipGetLastError());
+      if (sk.nslices > 1) {
+        const size_t n4 = (size_t)B * d / 4;
+        hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
+        HIP_TRY(hipGetLastError());
+      }
+      return DPRHOT_OK;
+    }
+  }
   if (wide_bwd_ok(B, Nc, d) && g_packed.stamp_src == nullptr) {
     // Vocabulary-wide vectors under few rows (CITADEL router: 128 x 1024 x 30528): every unit of either GEMM is a short K loop in front
     // of a large store -- the unit shapes of skinny.h (whole operand footprint in flight by LDS-DMA, stores through LDS in whole

@@ -279,8 +279,13 @@ static void run_case(int B, int Nc, int d, int K, float T, bool ragged, bool tim
     OK(dprhot_inbatch_bwd(dG.p, dQ_.p, dC_.p, B, Nc, d, 2.0f, dgo.p, q2.p, c2.p, ws.p, wsb, nullptr));
     CK(hipDeviceSynchronize());
     auto x = q2.down(), y0 = ddq.down(), z = c2.down(), w = ddc.down();
-    report("inbatch_bwd dQ == pieces", memcmp(x.data(), y0.data(), x.size() * 4) != 0, 0);
-    report("inbatch_bwd dC == pieces", memcmp(z.data(), w.data(), z.size() * 4) != 0, 0);
+    {  // (the fused entry point may run other kernels than the pieces -- the few-rows units at B <= 128: same sums, other order)
+      double eq = 0, mq = 0, ec = 0, mc = 0;
+      for (size_t i = 0; i < x.size(); ++i) { eq = std::max(eq, (double)fabs(x[i] - y0[i])); mq = std::max(mq, (double)fabs(y0[i])); }
+      for (size_t i = 0; i < z.size(); ++i) { ec = std::max(ec, (double)fabs(z[i] - w[i])); mc = std::max(mc, (double)fabs(w[i])); }
+      report("inbatch_bwd dQ vs pieces (rel max)", eq / std::max(mq, 1e-30), 1e-5);
+      report("inbatch_bwd dC vs pieces (rel max)", ec / std::max(mc, 1e-30), 1e-5);
+    }
     // whole step in one call (two launches at the small shapes): loss / G against the host reference, gradients against
     // dprhot_inbatch_bwd fed with the step's own G
     {
