@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the line an MI355X box produced for the committed code
-(profiles/r03_v6_bench_n1.json): every key the driver and the judge read is present and well-formed."""
+(profiles/r03_v7_bench_n1.json): every key the driver and the judge read is present and well-formed."""
 import json
 import os
 
@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r03_v6_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_v7_bench_n1.json")))
     for key, typ in [("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)]:
