@@ -81,6 +81,13 @@ def test_argument_validation_is_host_side():
     n = ctypes.c_int(-1)
     assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and 1 <= n.value <= 64  # cfg3 per rank: split-K slabs
     assert lib.dprhot_train_dq_slabs(32, 256, 768, ctypes.byref(n)) == 0 and n.value == 0          # cfg2: dQ comes out whole
+    # the few-rows plan's measured boundaries ("Mid-size steps"), seen through the slab count: split-K slabs where
+    # the plan applies with more than 512 contexts, none where its dQ units are unsplit or another plan has the shape
+    for shape, want_slabs in (((128, 1032, 768), True), ((64, 1088, 1024), True), ((32, 1056, 768), True), ((32, 2112, 768), True),
+                              ((128, 264, 768), False), ((128, 520, 768), True), ((96, 512, 768), False), ((64, 392, 768), False),
+                              ((32, 528, 768), False), ((32, 1024, 768), False), ((64, 256, 768), False), ((100, 1032, 768), False),
+                              ((128, 1032, 800), False)):
+        assert lib.dprhot_train_dq_slabs(*shape, ctypes.byref(n)) == 0 and (n.value > 1) == want_slabs, (shape, n.value)
     # explicit option table instead of environment variables
     assert lib.dprhot_set_option(b"no_skinny", 1) == 0
     assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and n.value == 0
