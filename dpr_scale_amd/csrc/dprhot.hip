@@ -487,9 +487,10 @@ FwdPlan fwd_plan(int B, int Nc, int d) {
     if (splits > 32) splits = 32;
     if (splits < 4) splits = 4;
   }
-  // 512 < Nc <= SS_MAXNC (the BASELINE shape gathered over 2..4 ranks): enough column tiles without a K split, and
-  // every workgroup of the fused softmax+backward kernel that follows re-reads the logits -- one slab, not four
-  if (B <= SS_ROWS && Nc > 512 && Nc <= SS_MAXNC) splits = 1;
+  // 768 < Nc <= SS_MAXNC (the BASELINE shape gathered over 3..4 ranks): enough column tiles without a K split, and
+  // every workgroup of the fused softmax+backward kernel that follows re-reads the logits -- one slab, not four.  (Up to 768
+  // columns the K split still pays: 32 x 528, cfg2 over two ranks, 13.25 -> 12.85 us; 32 x 648 13.75 -> 13.55.)
+  if (B <= SS_ROWS && Nc > 768 && Nc <= SS_MAXNC) splits = 1;
   p.kchunk = cdiv(ksteps, splits) * bk;
   p.splits = cdiv(d, p.kchunk);
   const int cpr = Nc / 8;
@@ -1346,9 +1347,12 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
     else if (fp.splits == 3) DPRHOT_SS_LAUNCH(2, 3);
     else DPRHOT_SS_LAUNCH(2, 4);
   } else if (ncp <= 768) {
-    DPRHOT_SS_LAUNCH(3, 1);  // above 512 columns the sim launch writes one slab (fwd_plan)
+    if (fp.splits <= 1) DPRHOT_SS_LAUNCH(3, 1);
+    else if (fp.splits == 2) DPRHOT_SS_LAUNCH(3, 2);
+    else if (fp.splits == 3) DPRHOT_SS_LAUNCH(3, 3);
+    else DPRHOT_SS_LAUNCH(3, 4);
   } else {
-    DPRHOT_SS_LAUNCH_N(5, 1, 1);  // (B <= 32 only: small_step_ok)
+    DPRHOT_SS_LAUNCH_N(5, 1, 1);  // (B <= 32 only: small_step_ok; above 768 columns the sim launch writes one slab: fwd_plan)
   }
 #undef DPRHOT_SS_LAUNCH_N
 #undef DPRHOT_SS_LAUNCH
