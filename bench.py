@@ -145,15 +145,19 @@ class HotPathStep:
         self.a_unpack = (P(self.Cb), self.W, self.n_ctx, d, P(self.mask_all), st)
         self.a_bwd = (P(self.G), P(self.Qb), P(self.Cb), B, Nc, d, 1.0, P(self.go), P(self.dQ), P(self.dC), ws, wsb, st)
         # the whole step in one C call (dprhot_inbatch_step_f32): 2 launches at the small shapes, else fwd_f32 + bwd
+        # the dScores are an OUTPUT nobody reads in a training step: where the shape's plan can do without them (dprhot_step_wants_g:
+        # the few-rows plan, cfg3 per rank) the step is called with G == NULL, as the autograd operator calls it (DPRHOT_BENCH_G=1: A/B)
+        self.want_g = os.environ.get("DPRHOT_BENCH_G") == "1" or self._lib.step_wants_g(B, Nc, d)
+        g_arg = P(self.G) if self.want_g else None
         self.a_step = (P(self.q), P(self.c) if not self.dist else None, P(self.Qb), P(self.Cb), B, Nc, d, P(self.y), off,
                        P(self.mask_all), self.inv_T, self.gscale, 1.0, P(self.go), None, P(self.row_loss), P(self.row_lse),
-                       P(self.loss_sum), P(self.G), P(self.dQ), P(self.dC), ws, wsb, st)
+                       P(self.loss_sum), g_arg, P(self.dQ), P(self.dC), ws, wsb, st)
         self.small = (B <= 32 and Nc <= 1152 or B <= 64 and Nc <= 256) and d % 16 == 0  # mirrors small_step_ok() in csrc/dprhot.hip
         # N > 1: everything between the all-gather and the reduce-scatter in one call (mask read from the packed buffer,
         # loss numerator riding in dC_part); DPRHOT_UNPACKED=1 keeps the separate unpack launch and the loss all-reduce
         self.packed_step = self.dist and not os.environ.get("DPRHOT_UNPACKED")
         self.a_pstep = (P(self.q), P(self.Cb), P(self.Qb), B, self.W, self.r, self.n_ctx, d, P(self.y), self.inv_T,
-                        self.gscale, 1.0, P(self.go), P(self.row_loss), P(self.row_lse), P(self.loss_sum), P(self.G), P(self.dQ),
+                        self.gscale, 1.0, P(self.go), P(self.row_loss), P(self.row_lse), P(self.loss_sum), g_arg, P(self.dQ),
                         P(self.dC), ws, wsb, st)
         self.a_sim = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, None, ws, wsb, st)
         self.c_step = (self._prepared(self.lib.dprhot_inbatch_step_packed_f32, self.a_pstep) if self.packed_step
@@ -525,6 +529,15 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
         hp.Cb[r * hp.rows_c:(r + 1) * hp.rows_c].copy_(hp.send)
     torch.cuda.synchronize()
     us = time_kernel(hp, hp.k_step, reps=20, iters=10)
+    us_with_g = None
+    if not hp.want_g:  # the same step with the dScores asked for (the four-launch plan of rounds 2-3), same process, same box
+        os.environ["DPRHOT_BENCH_G"] = "1"
+        try:
+            hp.bind_stream()
+            us_with_g = round(time_kernel(hp, hp.k_step, reps=20, iters=10), 2)
+        finally:
+            del os.environ["DPRHOT_BENCH_G"]
+            hp.bind_stream()
     bn, bd, nd = float(B) * hp.Nc, float(B) * d, float(hp.Nc) * d
     algo = (4 * bd + 2 * nd + 4 * bn) + 6 * bn + (2 * bn + 2 * nd + 4 * bd) + (2 * bn + 2 * bd + 4 * nd)
     # the same step as the autograd operator issues it under DDP: dprhot_train_step_packed_f32 (loss mean out of the kernel, dQ left
@@ -541,7 +554,7 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
         def train_step():
             st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             rc = lib.dprhot_train_step_packed_f32(P(hp.q), P(hp.Cb), P(hp.Qb), B, W, 0, hp.n_ctx, d, P(hp.y), hp.inv_T, hp.gscale, 1.0 / hp.Nq,
-                                                  P(hp.go), P(hp.row_loss), P(hp.row_lse), P(hp.loss_sum), P(hp.G), P(hp.dQ),
+                                                  P(hp.go), P(hp.row_loss), P(hp.row_lse), P(hp.loss_sum), P(hp.G) if hp.want_g else None, P(hp.dQ),
                                                   P(part) if nsl > 0 else None, P(dCw), kind, P(hp.ws), hp.ws_bytes, st)
             rc = rc or lib.dprhot_rescale_grads(P(hp.dQ), hp.dQ.numel(), P(part) if nsl > 0 else None, nsl, P(dCw), dCw.numel(), kind,
                                                 P(hp.go), P(hp.go), P(out2), st)
@@ -554,7 +567,9 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
             op_us[wire] = repr(e)
     out = {"workload": f"cfg3 per rank: B={B} rows x Nc={hp.Nc} gathered columns (W={W} x {hp.rows_c} packed rows) x d={d}, "
                        "bf16 contexts resident, fp32 q in, fp32 dQ / dC_part out",
-           "step_us": round(us, 2), "pairs_per_s_per_gpu": round(B / us * 1e6, 1), "bound": "hbm",
+           "step_us": round(us, 2), "launches": "sim (tile-local softmax out) | dC + dQ units deriving the row logsumexp themselves | dQ slab sum"
+           if us_with_g is not None else "sim | dScores | dC + dQ units | dQ slab sum",
+           "step_us_with_dscores_launch": us_with_g, "pairs_per_s_per_gpu": round(B / us * 1e6, 1), "bound": "hbm",
            "algorithmic_bytes": algo, "achieved": round(algo / us * 1e-3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(algo / us * 1e-3 / HBM_PEAK_GBS, 4), "flops": 6 * bn * d,
            "mfma_frac": round(6 * bn * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4),

@@ -71,6 +71,7 @@ SIGNATURES = {
     "dprhot_pairwise_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "dprhot_pairwise_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dprhot_train_dq_slabs": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
+    "dprhot_step_wants_g": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
     "dprhot_train_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p, c_float,
                                       c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_void_p, c_size_t, c_void_p]),
@@ -113,9 +114,19 @@ def version() -> int:
     return lib.dprhot_version()
 
 
+_OPTIONS_EPOCH = 0
+
+
+def options_epoch() -> int:
+    """Bumped by every set_option(): host-side caches of plan facts (slab counts, whether a step wants a G buffer) key on it."""
+    return _OPTIONS_EPOCH
+
+
 def set_option(name: str, value: int):
     """Process-wide test / A-B switch of the plans (include/dprhot.h); production never calls this."""
+    global _OPTIONS_EPOCH
     check(lib.dprhot_set_option(name.encode(), int(value)), f"dprhot_set_option({name})")
+    _OPTIONS_EPOCH += 1
 
 
 def get_option(name: str) -> int:
@@ -140,6 +151,12 @@ def train_dq_slabs(B: int, Nc: int, d: int) -> int:
     out = c_int(0)
     check(lib.dprhot_train_dq_slabs(B, Nc, d, ctypes.byref(out)), "dprhot_train_dq_slabs")
     return out.value
+
+
+def step_wants_g(B: int, Nc: int, d: int) -> bool:
+    out = c_int(1)
+    check(lib.dprhot_step_wants_g(B, Nc, d, ctypes.byref(out)), "dprhot_step_wants_g")
+    return bool(out.value)
 
 
 def workspace_bytes(B: int, Nc: int, d: int) -> int:

@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -146,8 +146,9 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
     {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
     {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
+    {"sk_fused", 1, "0 keeps the dScores launch of the few-rows plan (sk_g_kernel) where the caller passes G == NULL (A/B of the three-launch step)"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -427,6 +428,19 @@ SkPlan sk_plan(int B, int Nc, int d) {
   return p;
 }
 
+// The few-rows step without its dScores launch (skinny.h, round 4: sk_sim_kernel writes the tile-local softmax, sk_bwdf_kernel derives
+// the row logsumexp and the per-tile factors itself).  nts = statistics tiles, nk = 64-context steps of the dQ units (tile space: the
+// packed layout's remapped tiles skip the header rows).  128-column statistics tiles only (a dC unit is one tile), at most 128 of
+// them, the dQ slices as the plan cut them and short enough for a unit's factor table (SK_FT tiles).
+struct SkFused { bool ok; int ksteps; };
+SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk) {
+  SkFused f{false, 0};
+  if (!sk.ok || sk.scols != SK_COLS || nts > 128 || sk.nslices < 1) return f;
+  f.ksteps = cdiv(nk, sk.nslices);  // (a tiling with fewer steps may leave the last slices empty: their units write zero slabs)
+  f.ok = (f.ksteps + 1) / 2 + 1 <= SK_FT;
+  return f;
+}
+
 struct FwdPlan { bool short_rows; int tile, splits, kchunk, nt, tpr, cpt, threads, blocks; };
 FwdPlan fwd_plan(int B, int Nc, int d);
 
@@ -586,6 +600,15 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   const int nts = remap ? (Nc / g_packed.rows_c) * tpr : sk.nts;
   SkSimArgs a{q, nullptr, Cb, Qb, B, Nc, d, y, y_offset, colmask, inv_T, S, tile_lse, gold, g_packed.base, g_packed.rows_c,
               g_packed.n_ctx, g_packed.row_bytes, tpr};
+  // G == NULL (nobody wants the dScores): three launches -- the sim launch leaves the tile-local softmax in the logit workspace
+  const int nk_f = remap ? 2 * nts : cdiv(Nc, 64);
+  const SkFused fz = sk_fused_plan(sk, nts, nk_f);
+  const bool fused = G == nullptr && S_out == nullptr && fz.ok && opt(OPT_SK_FUSED) != 0;
+  if (G == nullptr && !fused) return fail(DPRHOT_E_INVALID, "few-rows step: G == NULL needs the fused-dScores plan (dprhot_step_wants_g)");
+  if (fused) {
+    a.S = nullptr;
+    a.P = reinterpret_cast<uint16_t*>(ws + wl.logits);
+  }
   const int grid1 = sk.nrb * nts;
   int rc = DPRHOT_OK;
   switch (d / 128) {  // NCH = d / 64
@@ -600,6 +623,35 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     default: return fail(DPRHOT_E_UNSUPPORTED, "skinny step: d=%d", d);
   }
   if (rc) return rc;
+  if (fused) {
+    float* part = g_dq_part != nullptr ? g_dq_part : reinterpret_cast<float*>(ws + wl.dq_part);
+    const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = nts * (d / SK_DN);
+    SkBwdFArgs b{a.P, Qb, Cb, B, Nc, d, tile_lse, gold, y, y_offset, nts, tpr, g_packed.rows_c, g_packed.n_ctx, grad_scale, h_scale, d_scale,
+                 dC_part, g_dc_bf16 ? 1 : 0, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, loss_sum, g_loss_scale,
+                 row_loss, row_lse, fz.ksteps, sk.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0};
+    const size_t lds = sk_bwdf_lds();
+    static AttrOnce attr_done[2];
+    if (nts <= 64) {
+      if (!attr_done[0]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwdf_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[0] = true;
+      }
+      hipLaunchKernelGGL(sk_bwdf_kernel<8>, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
+    } else {
+      if (!attr_done[1]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwdf_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[1] = true;
+      }
+      hipLaunchKernelGGL(sk_bwdf_kernel<16>, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
+    }
+    HIP_TRY(hipGetLastError());
+    if (g_dq_part == nullptr && sk.nslices > 1) {
+      const size_t n4 = (size_t)B * d / 4;
+      hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
+      HIP_TRY(hipGetLastError());
+    }
+    return DPRHOT_OK;
+  }
   float* rl = row_loss ? row_loss : reinterpret_cast<float*>(ws + wl.rloss);  // the backward launch forms the loss from the row losses
   {
     const int parts = B >= 128 ? 2 : (B >= 64 ? 4 : 8);  // >= 256 workgroups; a part is at most 4 x 256 chunks of 8 columns
@@ -1276,13 +1328,28 @@ static bool small_step_ok(int B, int Nc, int d) {
          !unfused_bwd();
 }
 
+int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants) {
+  REQUIRE(h_wants != nullptr, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  // 0 where the few-rows plan takes the fused-dScores form -- judged on the plain column tiling: the packed layout's remapped tiles
+  // are never more and their slices never longer.  A pure function of the shape, like every plan here.
+  const SkPlan sk = sk_plan(B, Nc, d);
+  *h_wants = (opt(OPT_SK_FUSED) != 0 && sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64)).ok) ? 0 : 1;
+  return DPRHOT_OK;
+}
+
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
                             int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float h_scale, const float* d_scale,
                             float* S_out, float* row_loss, float* row_lse, float* loss_sum, dprhot_bf16* G, float* dQ, float* dC_part,
                             void* workspace, size_t workspace_bytes, void* stream) {
-  REQUIRE(loss_sum && G && dQ && dC_part, "NULL pointer (loss_sum, G, dQ and dC_part are required)");
+  REQUIRE(loss_sum && dQ && dC_part, "NULL pointer (loss_sum, dQ and dC_part are required)");
   REQUIRE(aligned16(G) && aligned16(dQ) && aligned16(dC_part), "pointers must be 16-byte aligned");
   if (int rc = check_shape(B, Nc, d)) return rc;
+  if (G == nullptr) {
+    int wants = 1;
+    if (int rc = dprhot_step_wants_g(B, Nc, d, &wants)) return rc;
+    REQUIRE(wants == 0, "G == NULL at B=%d Nc=%d d=%d: this shape's plan materialises the dScores (dprhot_step_wants_g = 1)", B, Nc, d);
+  }
   {
     const SkPlan sk = sk_plan(B, Nc, d);
     if (sk.ok) {

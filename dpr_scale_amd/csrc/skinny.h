@@ -89,6 +89,11 @@ struct SkSimArgs {
   // rows) -- the header rows between the ranks' blocks are never multiplied (their logits are -inf by definition), and cfg3 per
   // rank is 4 x 64 = 256 units, one per CU, instead of 260 (4 CUs with two units each set the launch's duration: 9.8 vs 6.9 us).
   int tiles_per_rank;      // 0: tile t = columns [t * COLS, ...)
+  // Fused-dScores plan (round 4, sk_bwdf_kernel below): P [B][Nc] bf16 = exp(S - tile_lse) -- every tile's OWN softmax, the gold
+  // column stored as 0 (its gradient term is added in fp32 by the backward units) -- instead of the fp32 logits (S == nullptr then).
+  // What the backward needs of the row softmax is then one factor per (row, tile), exp(tile_lse - row_lse): no launch in between
+  // has to see whole rows.
+  uint16_t* P = nullptr;
 };
 
 constexpr int SK_ASTAGE = 2 * SK_ROWS * SK_KC;  // elements: two [32 rows][64 k] images of the q rows
@@ -265,11 +270,19 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     sm = ss_sum8(sm);
     if (row < p.B) {
       if (sseg == 0) p.tile_lse[((size_t)(ct >> 2) * p.B + row) * 4 + (ct & 3)] = mx == -INFINITY ? -INFINITY : mx + logf(sm);
+      const float inv = sm > 0.f ? 1.0f / sm : 0.f;  // (a tile whose columns are all masked: every probability is 0)
 #pragma unroll
       for (int qd = 0; qd < QD; ++qd) {
         const int col = (qd * 8 + sseg) * 4;
-        if (n0 + col < p.Nc) *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col) = v[qd];
+        if (p.S != nullptr && n0 + col < p.Nc) *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col) = v[qd];
         if (yi >= col && yi < col + 4) p.gold[row] = yi == col ? v[qd].x : (yi == col + 1 ? v[qd].y : (yi == col + 2 ? v[qd].z : v[qd].w));
+        if (p.P != nullptr && n0 + col < p.Nc) {
+          // exp(-inf - mx) == 0 at masked columns; the gold column leaves as 0 (sk_bwdf_kernel adds its term in fp32)
+          const float e0 = yi == col ? 0.f : __expf(v[qd].x - mx) * inv, e1 = yi == col + 1 ? 0.f : __expf(v[qd].y - mx) * inv;
+          const float e2 = yi == col + 2 ? 0.f : __expf(v[qd].z - mx) * inv, e3 = yi == col + 3 ? 0.f : __expf(v[qd].w - mx) * inv;
+          const bool dead = mx == -INFINITY;
+          *reinterpret_cast<uint2*>(p.P + (size_t)row * p.Nc + n0 + col) = dead ? make_uint2(0u, 0u) : make_uint2(pk_bf16(e0, e1), pk_bf16(e2, e3));
+        }
       }
     }
   }
@@ -278,7 +291,10 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (ct / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
     for (int i = tid; i < SK_ROWS * hdr; i += SK_THREADS) {
       const int row = m0 + i / hdr;
-      if (row < p.B) p.S[(size_t)row * p.Nc + h0 + i % hdr] = -INFINITY;
+      if (row < p.B) {
+        if (p.S != nullptr) p.S[(size_t)row * p.Nc + h0 + i % hdr] = -INFINITY;
+        if (p.P != nullptr) p.P[(size_t)row * p.Nc + h0 + i % hdr] = 0;
+      }
     }
   }
   DPRHOT_TMB(0, 4);
@@ -713,6 +729,576 @@ __global__ __launch_bounds__(256) void sk_dq_reduce_kernel(const float* __restri
     a.z = ((a.z + b.z) + (c.z + e.z)) * sc;
     a.w = ((a.w + b.w) + (c.w + e.w)) * sc;
     reinterpret_cast<float4*>(out)[idx] = a;
+  }
+}
+
+
+// =====================================================================================================================
+// Round 4: the step WITHOUT the dScores launch  (sk_sim_kernel with P  ->  sk_bwdf_kernel  [-> sk_dq_reduce_kernel])
+// =====================================================================================================================
+// G = (softmax(S) - onehot) * scale needs every row's logsumexp -- a dependency on ALL column tiles of the sim launch, which is why
+// sk_g_kernel sat between the sim and the backward launches (4.6 of cfg3-per-rank's 29.7 us, 0.18 of the HBM rate, plus a 4 MB fp32
+// logit round trip and a 2 MB G round trip).  Factor it instead:
+//     softmax_ij = exp(S_ij - lse_i) = exp(S_ij - lse_it) * exp(lse_it - lse_i) =: P_ij * f_it          (t = the 128-column tile of j)
+// P is local to a sim unit (its own tile's softmax: written by the sim epilogue in bf16 -- the precision G had) and f_it is ONE
+// number per (row, tile) that every backward unit derives from the nt tile values of its rows (33 KB of L2 reads, 32 exponentials
+// per thread).  Then
+//     dQ_i = sum_t f_it * (sum_{j in t} P_ij C_j)  + g_i * C[y_i]       a dQ unit multiplies into a scratch accumulator per 64-context
+//                                                                       step and adds f * scratch to its sum (32 FMAs per step)
+//     dC_j = sum_i P_ij (f_it q_i)                 + [j == y_i] g_i q_i  a dC unit scales its Q image's rows in LDS by f_it once
+// with g_i = (exp(S_gold,i - lse_i) - 1) * scale in fp32: the gold column is 0 in P and its term is added from the bf16 operand row
+// in the epilogue -- exact where the old path rounded G_gold to bf16, and immune to f_it underflowing when the gold tile lies far
+// below the row maximum.  Units work in TILE space (tile t = the sim's statistics tile: with the packed layout's remapping the
+// header rows between the ranks' blocks belong to no tile; the last tile of a rank writes their zero gradient rows and the stamp).
+//
+// Loads that must not drain the LDS-DMA queue (tile statistics, labels, gold logits, the gold rows) are inline-asm loads counted by
+// hand: hipcc answers any ordinary load next to an LDS-DMA with s_waitcnt vmcnt(0) (guide section 5.7; visible in sk_sim_kernel's
+// prologue), which would serialise "statistics -> logsumexp -> factors" behind the operand DMAs instead of under them.
+struct SkBwdFArgs {
+  const uint16_t* P;      // [B][Nc] bf16 tile-local softmax (sk_sim_kernel), gold column 0
+  const uint16_t* Qb;     // [B][d]
+  const uint16_t* C;      // [Nc][d]
+  int B, Nc, d;
+  const float* tile_lse;  // [ceil(nt/4)][B][4]
+  const float* gold;      // [B] gold logits
+  const int64_t* y;
+  int64_t y_offset;
+  int nt;                 // statistics tiles of 128 columns
+  int tiles_per_rank, p_rows_c, p_n_ctx;  // remapped tiles (SkSimArgs::tiles_per_rank), else 0: tile t = columns [128 t, ...)
+  float grad_scale;       // 1 / (Nq T): d loss / d S
+  float h_scale;
+  const float* d_scale;
+  void* dC;               // [Nc][d] fp32, or bf16 (dc_bf16)
+  int dc_bf16;
+  int stamp_period, stamp_row;
+  float* loss_sum;        // [1] out: loss_scale * sum of the row losses (dC unit 0)
+  float loss_scale;
+  float* row_loss;        // [B] out or nullptr
+  float* row_lse;         // [B] out or nullptr
+  int ksteps, nslices;    // dQ: 64-context steps per slice (tile space), slices
+  float* part;            // [nslices][B][d]
+  float* dQ;              // nslices == 1
+  int ndq_pad;
+  int nt_store;
+};
+
+constexpr int SK_FT = 8;                            // statistics tiles a dQ unit may touch ((ksteps + 1) / 2 + 1 <= SK_FT: sk_fused_ok)
+constexpr int SK_FX = (SK_FT * 128 + 2 * 128) * 4;  // bytes of a dQ unit's tables behind its ring: f[SK_FT][128], g[128], y[128]
+inline size_t sk_bwdf_lds() { return (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2 + SK_FX; }
+constexpr int SK_FDC_TAB = SK_COLS * SK_DC_TS * 4;  // byte offset of a dC unit's tables (behind its fp32 epilogue tile)
+
+__device__ __forceinline__ f32x4 sk_ld16_hidden(const void* ptr) {
+  f32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+__device__ __forceinline__ float sk_ld4_hidden(const void* ptr) {
+  float r;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+typedef unsigned sk_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sk_u32x2 sk_ld8_hidden(const void* ptr) {
+  sk_u32x2 r;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+// LDS stores next to LDS-DMAs in flight: asm, for the reason given at sk_sim_kernel's q chunk (hipcc would drain the queue first)
+__device__ __forceinline__ void sk_lds_st32(void* lds_ptr, unsigned v) {
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  const unsigned addr = (unsigned)(uintptr_t)(lds_u32*)lds_ptr;
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ float sk_bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float sk_bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+// first column of statistics tile t
+__device__ __forceinline__ int sk_tile_col(const SkBwdFArgs& p, int t) {
+  return p.tiles_per_rank > 0 ? (t / p.tiles_per_rank) * p.p_rows_c + (t % p.tiles_per_rank) * SK_COLS : t * SK_COLS;
+}
+// 64-context step (tile space) that holds global column n, or -1 (a header row of the packed layout, or beyond Nc)
+__device__ __forceinline__ int sk_step_of_col(const SkBwdFArgs& p, int n) {
+  if (n < 0 || n >= p.Nc) return -1;
+  if (p.tiles_per_rank == 0) return n >> 6;
+  const int r = n / p.p_rows_c, j = n - r * p.p_rows_c;
+  return j < p.p_n_ctx ? ((r * p.tiles_per_rank + (j >> 7)) << 1) + ((j >> 6) & 1) : -1;
+}
+
+// The statistics of ONE row per thread pair (row = tid >> 1, half = tid & 1: groups half, half + 2, ... of four tile values).
+// issue() before the unit's DMAs, finish() after the counted wait: the row's logsumexp, identical bits in both lanes of the pair.
+template <int NG>
+struct SkRowStats {
+  f32x4 sv[NG];
+  __device__ __forceinline__ void issue(const float* tile_lse, int nt, int B, int prow, int ph) {
+    const int ng = (nt + 3) >> 2;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) sv[u] = sk_ld16_hidden(tile_lse + ((size_t)min(ph + 2 * u, ng - 1) * B + prow) * 4);
+  }
+  __device__ __forceinline__ float finish(int nt, int ph) const {
+    float mx = -INFINITY;
+    float v[NG][4];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int t = (ph + 2 * u) * 4;  // (groups beyond the last re-read the last group: t >= nt there)
+      v[u][0] = t + 0 < nt ? sv[u][0] : -INFINITY;
+      v[u][1] = t + 1 < nt ? sv[u][1] : -INFINITY;
+      v[u][2] = t + 2 < nt ? sv[u][2] : -INFINITY;
+      v[u][3] = t + 3 < nt ? sv[u][3] : -INFINITY;
+      mx = fmaxf(mx, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
+    }
+    mx = fmaxf(mx, ss_dpp<0xB1>(mx));  // the other half of the row (lane ^ 1)
+    float sm = 0.f;
+    if (mx != -INFINITY) {
+#pragma unroll
+      for (int u = 0; u < NG; ++u) sm += (__expf(v[u][0] - mx) + __expf(v[u][1] - mx)) + (__expf(v[u][2] - mx) + __expf(v[u][3] - mx));
+    }
+    // (a + b == b + a: both lanes of the pair hold the same bits)
+    sm += ss_dpp<0xB1>(sm);
+    return mx + logf(sm);
+  }
+};
+
+// dQ unit (fused): (slice of 64-context steps in tile space) x (64 columns of d), all B rows
+template <int NG>
+__device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
+  constexpr int IA = SK_QA * 2 / 1024 / 4;  // 4
+  constexpr int IB = SK_QB * 2 / 1024 / 4;  // 2
+  constexpr int PER = IA + IB;
+  constexpr int SLOT = SK_QA + SK_QB;
+  constexpr int NGOLD = 8;                  // gold-row loads per thread (one per epilogue item)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ndt = p.d / SK_QN;
+  const int dt = unit % ndt, ks = unit / ndt;
+  const int c0 = dt * SK_QN;
+  const int nk = p.tiles_per_rank > 0 ? 2 * p.nt : (p.Nc + 63) / 64;
+  const int s0 = ks * p.ksteps;
+  const int ns = min(p.ksteps, nk - s0);
+  const int t0 = s0 >> 1;
+  if (ns <= 0) {  // a remapped tiling with fewer steps than the plan's slices cover: this slice is empty, its slab is zero
+    float* const out0 = p.part + (size_t)ks * p.B * p.d;
+    for (int e = tid; e < p.B * (SK_QN / 4); e += SK_THREADS)
+      *reinterpret_cast<float4*>(out0 + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  float* const fs = reinterpret_cast<float*>(sk_smem + SK_QSLOTS * SLOT);  // [SK_FT][128]: f of (local tile, row)
+  float* const gv = fs + SK_FT * 128;                                       // [128]: g of the row, 0 when its gold column is not in this slice
+  int* const yl = reinterpret_cast<int*>(gv + 128);                          // [128]: gold column (global), or -1 (not in this slice)
+
+  // ---- hidden loads first: they return under the DMAs issued behind them
+  const int prow = min(tid >> 1, p.B - 1), ph = tid & 1;
+  SkRowStats<NG> st;
+  st.issue(p.tile_lse, p.nt, p.B, prow, ph);
+  float lt[SK_FT / 2];
+#pragma unroll
+  for (int u = 0; u < SK_FT / 2; ++u) {
+    const int t = min(t0 + ph + 2 * u, p.nt - 1);
+    lt[u] = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
+  }
+  const float gl = sk_ld4_hidden(p.gold + prow);
+  const float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);  // low word of the int64 label
+
+  // ---- ring DMAs: per-lane source coordinates (one instruction = 1 KiB = 8 rows of 128 bytes)
+  unsigned arow[IA];
+  int akin[IA], bkr[IB];
+  unsigned bcol[IB];
+#pragma unroll
+  for (int j = 0; j < IA; ++j) {
+    const int row = (wave * IA + j) * 8 + (lane >> 3);
+    arow[j] = (unsigned)min(row, p.B - 1) * (unsigned)p.Nc;
+    akin[j] = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
+  }
+#pragma unroll
+  for (int j = 0; j < IB; ++j) {
+    const int krow = (wave * IB + j) * 8 + (lane >> 3), pos = lane & 7;
+    bkr[j] = krow;
+    bcol[j] = (unsigned)(c0 + ((((pos >> 1) ^ sk_swz64(krow)) << 4) + (pos & 1) * 8));
+  }
+  auto step_col = [&](int s) {  // first context of step s of this unit
+    const int gs = s0 + s;
+    return sk_tile_col(p, gs >> 1) + (gs & 1) * 64;
+  };
+  auto issue = [&](int s, int slot) {
+    uint16_t* As = sk_smem + slot * SLOT;
+    uint16_t* Bs = As + SK_QA;
+    const int k0 = step_col(s);
+#pragma unroll
+    for (int j = 0; j < IA; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.P + arow[j] + min(k0 + akin[j], p.Nc - 8)), (g2_lds_ptr*)(As + (wave * IA + j) * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(k0 + bkr[j], p.Nc - 1) * (unsigned)p.d + bcol[j]),
+                                       (g2_lds_ptr*)(Bs + (wave * IB + j) * 512), 16, 0, 0);
+  };
+  const int npre = min(ns, SK_QSLOTS);
+#pragma unroll
+  for (int s = 0; s < SK_QSLOTS; ++s)
+    if (s < ns) issue(s, s);
+
+  // ---- the hidden loads have landed when at most the DMAs issued behind them are outstanding
+  sk_wait_younger<PER>(npre);
+  __builtin_amdgcn_sched_barrier(0);
+  const float lse = st.finish(p.nt, ph);
+  {
+    const int row = tid >> 1;
+    if (row < p.B) {
+#pragma unroll
+      for (int u = 0; u < SK_FT / 2; ++u) {
+        const int tl = ph + 2 * u;
+        // exp(-inf - lse) == 0: a tile without an unmasked column contributes nothing
+        const float f = t0 + tl < p.nt ? __expf(lt[u] - lse) * p.grad_scale : 0.f;
+        sk_lds_st32(fs + tl * 128 + row, __float_as_uint(f));
+      }
+      if (ph == 0) {
+        const int yg = __float_as_int(yf) + (int)p.y_offset;
+        const int gstep = sk_step_of_col(p, yg);
+        const bool mine = gstep >= s0 && gstep < s0 + ns;
+        sk_lds_st32(gv + row, __float_as_uint(mine ? (__expf(gl - lse) - 1.0f) * p.grad_scale : 0.f));
+        sk_lds_st32(yl + row, (unsigned)(mine ? yg : -1));
+      }
+    }
+  }
+  sk_barrier();
+  // gold rows C[y_i][c0 + 4 cq ..] for the eight (row, cq) items this thread stores in the epilogue: unconditional (a row without a
+  // gold column here reads row 0 and multiplies by g = 0), so that every wave has the same number of loads in its queue
+  const int erow0 = tid >> 4, ecq = tid & 15;
+  sk_u32x2 gq[NGOLD];
+#pragma unroll
+  for (int it = 0; it < NGOLD; ++it) {
+    const int yy = yl[min(erow0 + it * 16, p.B - 1)];
+    gq[it] = sk_ld8_hidden(p.C + (size_t)max(yy, 0) * p.d + c0 + ecq * 4);
+  }
+
+  const int i16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  for (int s = 0; s < ns; ++s) {
+    // slot s has landed when only what was issued behind it is outstanding: the later slots' DMAs, and -- for the slots of the
+    // prologue -- the gold-row loads
+    {
+      const int younger = min(s + SK_QSLOTS - 1, ns - 1) - s;
+      if (s < SK_QSLOTS) {
+        switch (younger) {
+          case 0: sk_wait_vm<NGOLD>(); break;
+          case 1: sk_wait_vm<NGOLD + PER>(); break;
+          default: sk_wait_vm<NGOLD + 2 * PER>(); break;
+        }
+      } else {
+        sk_wait_younger<PER>(younger);
+      }
+    }
+    const int slot = s % SK_QSLOTS;
+    uint16_t* As = sk_smem + slot * SLOT;
+    const uint16_t* Bs = As + SK_QA;
+    const int kvalid = p.tiles_per_rank > 0 ? 64 : p.Nc - (s0 + s) * 64;  // < 64 only in the ragged last step of an unmapped layout
+    if (kvalid < 64) {
+      sk_barrier();
+      for (int e = tid; e < SK_MAXB * 8; e += SK_THREADS) {
+        const int row = e >> 3, ch = e & 7;
+        if (ch * 8 >= kvalid) *reinterpret_cast<uint4*>(As + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+    sk_barrier();
+    bf16x8 af[2][2];
+    bf16x4 lo[2][4], hi[2][4];
+    f32x4 fr[2];
+    const int tl = ((s0 + s) >> 1) - t0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) fr[a] = *reinterpret_cast<const f32x4*>(fs + tl * 128 + wave * 32 + a * 16 + g4 * 4);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = wave * 32 + a * 16 + i16;
+        af[kk][a] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int k = kk * 32 + g4 * 8 + (i16 >> 2);
+        const unsigned addr = (unsigned)(uintptr_t)(lds_bf16x4*)(Bs + k * SK_QN + ((b ^ sk_swz64(k)) << 4) + (i16 & 3) * 4);
+        asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(lo[kk][b]), "=&v"(hi[kk][b]) : "v"(addr));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 tmp[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 bf[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        bf16x8 r;
+        r[0] = lo[kk][b][0]; r[1] = lo[kk][b][1]; r[2] = lo[kk][b][2]; r[3] = lo[kk][b][3];
+        r[4] = hi[kk][b][0]; r[5] = hi[kk][b][1]; r[6] = hi[kk][b][2]; r[7] = hi[kk][b][3];
+        bf[b] = r;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          tmp[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : tmp[a][b], 0, 0, 0);
+    }
+    // the step's 64 contexts lie in ONE statistics tile: sum += f(row, tile) * (P x C)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaf(fr[a][r], tmp[a][b][r], acc[a][b][r]);
+    if (s + SK_QSLOTS < ns) {
+      sk_barrier();
+      issue(s + SK_QSLOTS, slot);
+    }
+  }
+  sk_wait_vm<0>();  // (the gold rows: older than every DMA of the loop, long landed)
+  __builtin_amdgcn_sched_barrier(0);
+  sk_barrier();
+  // ---- partial tile [128][64] fp32 through LDS -> 16-byte stores, 256 bytes per row; the gold term in fp32 on the way out
+  constexpr int TS = SK_QN + 4;
+  float* const T = reinterpret_cast<float*>(sk_smem);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(wave * 32 + a * 16 + g4 * 4 + r) * TS + b * 16 + i16] = acc[a][b][r];
+  sk_barrier();
+  const bool fin = p.nslices == 1;
+  float* out = fin ? p.dQ : p.part + (size_t)ks * p.B * p.d;
+  const float sc = fin ? p.h_scale * (p.d_scale ? *p.d_scale : 1.0f) : 1.0f;
+#pragma unroll
+  for (int it = 0; it < NGOLD; ++it) {
+    const int row = erow0 + it * 16;
+    if (row < p.B) {
+      float4 v = *reinterpret_cast<const float4*>(T + row * TS + ecq * 4);
+      const float g = gv[row];
+      v.x = fmaf(g, sk_bf_lo(gq[it][0]), v.x) * sc;
+      v.y = fmaf(g, sk_bf_hi(gq[it][0]), v.y) * sc;
+      v.z = fmaf(g, sk_bf_lo(gq[it][1]), v.z) * sc;
+      v.w = fmaf(g, sk_bf_hi(gq[it][1]), v.w) * sc;
+      if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + ecq * 4));
+      else *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + ecq * 4) = v;
+    }
+  }
+}
+
+// dC unit (fused): statistics tile t (128 contexts) x 128 columns of d
+template <int NG>
+__device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
+  constexpr size_t kImg = (size_t)SK_MAXB * SK_COLS;
+  uint16_t* const Gs = sk_smem;         // [128 k = query row][128 m = context]: P
+  uint16_t* const Qs = sk_smem + kImg;  // [128 k = query row][128 n = d column]: Q, rows scaled by f in place
+  char* const tab = reinterpret_cast<char*>(sk_smem) + SK_FDC_TAB;
+  float* const fi = reinterpret_cast<float*>(tab);  // [128] f of (row, this tile)
+  float* const gv = fi + 128;                       // [128] g of the row
+  float* const rl = gv + 128;                       // [128] row loss
+  int* const head = reinterpret_cast<int*>(rl + 128);  // [128] first row whose gold column is context m of this tile, or >= 128
+  int* const nxt = head + 128;                         // [128] next row with the same gold column (built only when two rows share one)
+  int* const ym = nxt + 128;                           // [128] gold column relative to the tile, or -1
+  int* const dupf = ym + 128;                          // [1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ndt = (p.d + SK_DN - 1) / SK_DN;
+  const int dt = unit % ndt, t = unit / ndt;
+  const int n0 = sk_tile_col(p, t), c0 = dt * SK_DN;
+  const int kmax = p.B;
+  const int nvalid = p.tiles_per_rank > 0 ? SK_COLS : min(SK_COLS, p.Nc - n0);  // contexts of this tile
+
+  if (tid < SK_COLS) head[tid] = 0x7fffffff;  // (no DMA in flight yet: a plain store)
+  if (tid == 0) dupf[0] = 0;
+  const int prow = min(tid >> 1, p.B - 1), ph = tid & 1;
+  SkRowStats<NG> st;
+  st.issue(p.tile_lse, p.nt, p.B, prow, ph);
+  const float lt = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
+  const float gl = sk_ld4_hidden(p.gold + prow);
+  const float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
+  const int nins = kmax / 4 / 4;  // per wave and image (B % 32 == 0: 2, 4, 6 or 8)
+  for (int j = 0; j < nins; ++j) {
+    const int krow = (wave * nins + j) * 4 + (lane >> 4), pos = lane & 15;
+    const int col = ((((pos >> 1) ^ mswz(krow))) << 4) + (pos & 1) * 8;
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.P + (size_t)krow * p.Nc + min(n0 + col, p.Nc - 8)),
+                                     (g2_lds_ptr*)(Gs + (wave * nins + j) * 4 * SK_COLS), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.Qb + (size_t)krow * p.d + min(c0 + col, p.d - 8)),
+                                     (g2_lds_ptr*)(Qs + (wave * nins + j) * 4 * SK_DN), 16, 0, 0);
+  }
+  sk_wait_younger<4>(nins >> 1);  // 2 * nins DMAs behind the hidden loads
+  __builtin_amdgcn_sched_barrier(0);
+  const float lse = st.finish(p.nt, ph);
+  const float f = __expf(lt - lse) * p.grad_scale;
+  const int yrel = __float_as_int(yf) + (int)p.y_offset - n0;  // gold column relative to this tile
+  const bool mine = yrel >= 0 && yrel < nvalid;
+  const float g = (__expf(gl - lse) - 1.0f) * p.grad_scale;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // the images have landed; head[] is initialised
+  {
+    const int row = tid >> 1;
+    if (ph == 0 && row < p.B) {
+      fi[row] = f;
+      gv[row] = g;
+      rl[row] = lse - gl;
+      ym[row] = mine ? yrel : -1;
+      if (mine) atomicMin(&head[yrel], row);
+      if (unit == 0) {
+        if (p.row_loss) p.row_loss[row] = lse - gl;
+        if (p.row_lse) p.row_lse[row] = lse;
+      }
+    } else if (ph == 0) {
+      rl[row] = 0.f;
+      ym[row] = -1;
+    }
+  }
+  __syncthreads();
+  {
+    // Q rows x f (in place, both bf16): row k of the image is 256 contiguous bytes whatever the column swizzle; one half row per thread
+    const int row = tid >> 1;
+    if (row < kmax) {
+      const float fr = fi[row];
+      uint4* base = reinterpret_cast<uint4*>(Qs + row * SK_DN + ph * 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        uint4 w = base[j];
+        w.x = pk_bf16(sk_bf_lo(w.x) * fr, sk_bf_hi(w.x) * fr);
+        w.y = pk_bf16(sk_bf_lo(w.y) * fr, sk_bf_hi(w.y) * fr);
+        w.z = pk_bf16(sk_bf_lo(w.z) * fr, sk_bf_hi(w.z) * fr);
+        w.w = pk_bf16(sk_bf_lo(w.w) * fr, sk_bf_hi(w.w) * fr);
+        base[j] = w;
+      }
+    }
+    if (ph == 0 && row < p.B && mine && head[yrel] != row) dupf[0] = 1;  // two rows with one gold column
+  }
+  // loss numerator (every unit that stamps it, and unit 0 which publishes it): fixed order
+  const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
+  const bool last_of_rank = p.tiles_per_rank > 0 && t % p.tiles_per_rank == p.tiles_per_rank - 1;
+  const bool stamp = dt == 0 && p.stamp_period > 0 && !p.dc_bf16;
+  float lsum = 0.f;
+  if (stamp || unit == 0) {
+    lsum = sk_loss_sum(rl, SK_MAXB, lane) * p.loss_scale;
+    if (unit == 0 && tid == 0) p.loss_sum[0] = lsum;
+  }
+  // gold rows of Q for the sixteen (context, 4 columns) items this thread stores: plain loads (no DMA is in flight any more)
+  const int em0 = tid >> 5, ecq = tid & 31;
+  uint2 gq[16];
+  int gh[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int h = head[em0 + it * 8];
+    gh[it] = h;
+    gq[it] = *reinterpret_cast<const uint2*>(p.Qb + (size_t)(h < SK_MAXB ? h : 0) * p.d + min(c0 + ecq * 4, p.d - 4));
+  }
+  __syncthreads();
+  if (dupf[0] != 0) {  // rare: chain the rows that share a gold column, ascending
+    if (tid < p.B) {
+      int nx = 0x7fffffff;
+      const int mym = ym[tid];
+      if (mym >= 0)
+        for (int i2 = tid + 1; i2 < p.B; ++i2)
+          if (ym[i2] == mym) { nx = i2; break; }
+      nxt[tid] = nx;
+    }
+    __syncthreads();
+  }
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kk = 0; kk < kmax / 32; ++kk) {
+    bf16x8 af[4], bf[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) af[a] = load_frag<128, 64, false, true>(Gs, wm * 64 + a * 16, kk, lane);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bf[b] = load_frag<128, 64, false, true>(Qs, wn * 64 + b * 16, kk, lane);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+  }
+  __syncthreads();  // the images are dead: the fp32 tile takes their place (the tables lie behind it)
+  float* const T = reinterpret_cast<float*>(sk_smem);
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(wm * 64 + a * 16 + g4 * 4 + r) * SK_DC_TS + wn * 64 + b * 16 + i16] = acc[a][b][r];
+  __syncthreads();
+  // Every gold-row load retires HERE, in a form the compiler sees (vmcnt(0) only).  They are consumed under conditions below; left
+  // "pending" on the other paths they reach -- in hipcc's linearised view of this kernel -- the dQ unit's code, which then guards
+  // their registers with s_waitcnt vmcnt(13) / vmcnt(0) in front of its DMA issue: waits that at run time hit the dQ unit's own
+  // hidden statistics loads (seen in the ISA; one L2 round trip per dQ unit before its first DMA).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  const bool dups = dupf[0] != 0;
+  // one output row = 128 fp32; item (context m, column quad cq): tile value + g_i * q_i of the rows i whose gold column is m
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int mrow = em0 + it * 8, m = n0 + mrow;
+    if (mrow < nvalid && c0 + ecq * 4 < p.d) {
+      float4 v = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + ecq * 4);
+      int h = gh[it];
+      if (h < SK_MAXB) {
+        const float gg = gv[h];
+        v.x = fmaf(gg, sk_bf_lo(gq[it].x), v.x);
+        v.y = fmaf(gg, sk_bf_hi(gq[it].x), v.y);
+        v.z = fmaf(gg, sk_bf_lo(gq[it].y), v.z);
+        v.w = fmaf(gg, sk_bf_hi(gq[it].y), v.w);
+        if (dups) {
+          for (h = nxt[h]; h < SK_MAXB; h = nxt[h]) {
+            const uint2 q2 = *reinterpret_cast<const uint2*>(p.Qb + (size_t)h * p.d + c0 + ecq * 4);
+            const float g2 = gv[h];
+            v.x = fmaf(g2, sk_bf_lo(q2.x), v.x);
+            v.y = fmaf(g2, sk_bf_hi(q2.x), v.y);
+            v.z = fmaf(g2, sk_bf_lo(q2.y), v.z);
+            v.w = fmaf(g2, sk_bf_hi(q2.y), v.w);
+          }
+        }
+      }
+      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+      if (p.dc_bf16) {
+        uint16_t* const out = static_cast<uint16_t*>(p.dC);
+        const sk_u32x2 w = {pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
+        if (p.nt_store) __builtin_nontemporal_store(w, reinterpret_cast<sk_u32x2*>(out + (size_t)m * p.d + c0 + ecq * 4));
+        else *reinterpret_cast<sk_u32x2*>(out + (size_t)m * p.d + c0 + ecq * 4) = w;
+      } else {
+        float* const out = static_cast<float*>(p.dC);
+        if (stamp && ecq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+        if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)m * p.d + c0 + ecq * 4));
+        else *reinterpret_cast<float4*>(out + (size_t)m * p.d + c0 + ecq * 4) = v;
+      }
+    }
+  }
+  if (last_of_rank) {
+    // the header rows behind this rank's real rows belong to no tile: zero gradient rows, and the loss stamp of the packed step
+    const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (t / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
+    for (int e = tid; e < hdr * 32; e += SK_THREADS) {
+      const int m = h0 + (e >> 5), cq = e & 31;
+      if (c0 + cq * 4 < p.d) {
+        if (p.dc_bf16) {
+          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.dC) + (size_t)m * p.d + c0 + cq * 4) = make_uint2(0u, 0u);
+        } else {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+          *reinterpret_cast<float4*>(static_cast<float*>(p.dC) + (size_t)m * p.d + c0 + cq * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NG>
+__global__ __launch_bounds__(SK_THREADS, 2) void sk_bwdf_kernel(SkBwdFArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
+  const int b = blockIdx.x;
+  const int ndq = p.nslices * (p.d / SK_QN);
+  if (b < p.ndq_pad) {
+    if (b >= ndq) return;  // padding
+    sk_dq_unit_f<NG>(p, sk_xcd_order(b, ndq), sk_smem);
+  } else {
+    sk_dc_unit_f<NG>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
   }
 }
 

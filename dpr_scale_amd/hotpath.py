@@ -69,6 +69,7 @@ class HipKernels:
         self.lib = _lib.lib
         self._ws = {}
         self._nslabs = {}
+        self._wg = {}
 
     # -- plumbing --------------------------------------------------------------------------------------
     @staticmethod
@@ -91,6 +92,21 @@ class HipKernels:
 
     def empty(self, shape, dtype, like):
         return torch.empty(shape, dtype=dtype, device=like.device)
+
+    def _g_buffer(self, want_G, B, Nc, d, dev):
+        """The dScores buffer of the one-call steps: True -> always (the plan then materialises G); "auto" -> only where the shape's
+        plan needs one (dprhot_step_wants_g; elsewhere the step never writes the dScores: one launch less at cfg3 per rank);
+        False -> none (raises at shapes that need it)."""
+        if want_G is True or (want_G == "auto" and self._wants_g(B, Nc, d)):
+            return torch.empty((B, Nc), dtype=_BF16, device=dev)
+        return None
+
+    def _wants_g(self, B, Nc, d):
+        key = (B, Nc, d, self._lib.options_epoch())
+        w = self._wg.get(key)
+        if w is None:
+            w = self._wg[key] = self._lib.step_wants_g(B, Nc, d)
+        return w
 
     # -- ops -------------------------------------------------------------------------------------------
     def cast_bf16(self, src, dst):
@@ -178,7 +194,7 @@ class HipKernels:
             self._stream()), "dprhot_inbatch_fwd_f32")
         return row_loss, row_lse, loss_sum, G, S
 
-    def inbatch_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale):
+    def inbatch_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, want_G=True):
         """Forward AND backward in one library call (dprhot_inbatch_step_f32; two launches at the BASELINE training
         shapes).  Gradients come back for grad_output = 1: returns (row_loss, row_lse, loss_sum, G, dQ, dC_part)."""
         self._require_gpu(q, c, Qb, Cb, y, colmask)
@@ -192,7 +208,7 @@ class HipKernels:
         row_loss = torch.empty(B, dtype=f32, device=dev)
         row_lse = torch.empty(B, dtype=f32, device=dev)
         loss_sum = torch.empty(1, dtype=f32, device=dev)
-        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        G = self._g_buffer(want_G, B, Nc, d, dev)
         dQ = torch.empty((B, d), dtype=f32, device=dev)
         dC = torch.empty((Nc, d), dtype=f32, device=dev)
         ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
@@ -202,7 +218,7 @@ class HipKernels:
             _ptr(ws), ws.numel(), self._stream()), "dprhot_inbatch_step_f32")
         return row_loss, row_lse, loss_sum, G, dQ, dC
 
-    def inbatch_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale):
+    def inbatch_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale, want_G=True):
         """World size > 1: everything between the all-gather and the reduce-scatter in one library call.  `gathered` is
         the all-gathered packed buffer; the mask is read from it, and dC_part carries this rank's loss numerator at
         [k * rows_c + n_ctx][0] of every chunk k (see include/dprhot.h).  Returns (row_loss, row_lse, loss_sum, G, dQ,
@@ -217,7 +233,7 @@ class HipKernels:
         row_loss = torch.empty(B, dtype=f32, device=dev)
         row_lse = torch.empty(B, dtype=f32, device=dev)
         loss_sum = torch.empty(1, dtype=f32, device=dev)
-        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        G = self._g_buffer(want_G, B, Nc, d, dev)
         dQ = torch.empty((B, d), dtype=f32, device=dev)
         dC = torch.empty((Nc, d), dtype=f32, device=dev)
         ws = self._workspace(dev, self._lib.workspace_bytes(B, Nc, d))
@@ -229,14 +245,14 @@ class HipKernels:
 
     def _dq_slabs(self, B, Nc, d, dev):
         """Caller-owned buffer for the split-K partial sums of dQ, or None when this shape's plan leaves none."""
-        key = (B, Nc, d)
+        key = (B, Nc, d, self._lib.options_epoch())  # the plan depends on process-wide options (dprhot_set_option)
         n = self._nslabs.get(key)
         if n is None:
             n = self._nslabs[key] = self._lib.train_dq_slabs(B, Nc, d)
         return torch.empty((n, B, d), dtype=torch.float32, device=dev) if n > 0 else None
 
     def train_step_f32(self, q, c, Qb, Cb, y, y_offset, colmask, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32,
-                       defer_dq=False):
+                       defer_dq=False, want_G=True):
         """The operator's step (dprhot_train_step_f32): forward AND backward in one library call, the loss already multiplied by
         loss_scale, the gradients scaled by the DEVICE scalar d_scale (the grad_output backward() is expected to deliver).
         Returns (row_loss, row_lse, loss_out [2], G, dQ, dC_part); loss_out[0] is the loss.  defer_dq: where the plan splits dQ over
@@ -252,7 +268,7 @@ class HipKernels:
         row_loss = torch.empty(B, dtype=f32, device=dev)
         row_lse = torch.empty(B, dtype=f32, device=dev)
         loss_out = torch.empty(2, dtype=f32, device=dev)
-        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        G = self._g_buffer(want_G, B, Nc, d, dev)
         dQ = torch.empty((B, d), dtype=f32, device=dev)
         dC = torch.empty((Nc, d), dtype=dc_dtype, device=dev)
         part = self._dq_slabs(B, Nc, d, dev) if defer_dq else None
@@ -264,7 +280,7 @@ class HipKernels:
         return row_loss, row_lse, loss_out, G, (dQ if part is None else (dQ, part)), dC
 
     def train_step_packed_f32(self, q, gathered, Qb, W, rank, n_ctx, y, inv_T, grad_scale, loss_scale, d_scale, dc_dtype=torch.float32,
-                              defer_dq=False):
+                              defer_dq=False, want_G=True):
         """World size > 1 (dprhot_train_step_packed_f32): as train_step_f32 on the all-gathered packed buffer."""
         self._require_gpu(q, gathered, Qb, y, d_scale)
         B, d = Qb.shape
@@ -276,7 +292,7 @@ class HipKernels:
         row_loss = torch.empty(B, dtype=f32, device=dev)
         row_lse = torch.empty(B, dtype=f32, device=dev)
         loss_out = torch.empty(2, dtype=f32, device=dev)
-        G = torch.empty((B, Nc), dtype=_BF16, device=dev)
+        G = self._g_buffer(want_G, B, Nc, d, dev)
         dQ = torch.empty((B, d), dtype=f32, device=dev)
         dC = torch.empty((Nc, d), dtype=dc_dtype, device=dev)
         part = self._dq_slabs(B, Nc, d, dev) if defer_dq else None
@@ -596,12 +612,13 @@ class InBatchContrastive(torch.autograd.Function):
             used = _ExpectedGradScale.get(q.device)
             try:
                 row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
-                                                                                       1.0 / Nq, used, dc_dtype, defer_dq=True)
+                                                                                       1.0 / Nq, used, dc_dtype, defer_dq=True, want_G="auto")
             except Exception as e:  # a plan without a bf16 dC epilogue: fp32 partials, rounded to the wire format in backward
                 if dc_dtype == torch.float32 or "dc_kind" not in str(e):
                     raise
                 row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
-                                                                                       1.0 / Nq, used, torch.float32, defer_dq=True)
+                                                                                       1.0 / Nq, used, torch.float32, defer_dq=True,
+                                                                                       want_G="auto")
             eager, loss_is_mean = (dQ, dC_part), True
         elif W > 1 and packed_step:  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale)
@@ -611,7 +628,7 @@ class InBatchContrastive(torch.autograd.Function):
             # backward() only checks the grad_output it was given against the one the gradients were scaled by
             used = _ExpectedGradScale.get(q.device)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
-                                                                            inv_T, grad_scale, 1.0 / Nq, used, defer_dq=True)
+                                                                            inv_T, grad_scale, 1.0 / Nq, used, defer_dq=True, want_G="auto")
             eager, loss_is_mean = (dQ, dC_part), True
         elif q_f32 and wants_grad and hasattr(kn, "inbatch_step_f32"):  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx,
@@ -632,6 +649,8 @@ class InBatchContrastive(torch.autograd.Function):
         ctx.in_dtypes = (q.dtype, c.dtype)
         ctx.eager, ctx.used = eager, used
         ctx.spare = (Qb, Cb, G) if (eager is not None and used is not None) else None
+        # (G is None where the step never materialised the dScores: a second backward through a retained graph recomputes them)
+        ctx.regen = (pos_idx, y_off, None if (W > 1 and packed_step) else colmask, inv_T, grad_scale) if ctx.spare is not None and G is None else None
         ctx.pending = pending if W > 1 else None
         if eager is None:
             ctx.save_for_backward(Qb, Cb, G)
@@ -661,6 +680,13 @@ class InBatchContrastive(torch.autograd.Function):
             # a second backward through a retained graph: the first one gave its gradient tensors away; the backward GEMMs run
             # again on the operands the step left behind (exact, rare)
             Qb, Cb, G = ctx.spare
+            if G is None:
+                pos_idx, y_off, colmask, inv_T, grad_scale = ctx.regen
+                if colmask is None:
+                    colmask = kn.empty((Cb.shape[0],), torch.uint8, Cb)
+                    kn.unpack_mask(Cb, W, n_ctx, colmask)
+                G = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale)[3]
+                ctx.spare = (Qb, Cb, G)
             dQ, dC_part = kn.inbatch_bwd(G, Qb, Cb, 1.0, go, need_dq, need_dc)
             go = None
         elif ctx.eager is not None:

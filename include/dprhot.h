@@ -195,11 +195,17 @@ int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprh
 
 /* One training step -- forward and backward of dpr_task.py:197-212 -- in a single call, for callers that know a
  * backward will follow (autograd: any input requires grad).  Arguments as dprhot_inbatch_fwd_f32 followed by those
- * of dprhot_inbatch_bwd; loss_sum, G, dQ and dC_part are required.  dQ / dC_part are scaled by
+ * of dprhot_inbatch_bwd; loss_sum, dQ and dC_part are required, G unless dprhot_step_wants_g says 0.  dQ / dC_part are scaled by
  * h_scale * (d_scale ? *d_scale : 1): pass the autograd grad_output there if it is known at forward time, or 1 and
  * multiply later.  At the latency-bound shapes (B <= 32, Nc <= 1152, d % 16 == 0) this is TWO launches -- the sim GEMM,
  * then one kernel doing softmax-CE, dScores and both backward GEMMs from an LDS-resident G; otherwise it equals
  * dprhot_inbatch_fwd_f32 + dprhot_inbatch_bwd (three launches). */
+/* Whether the step entry points below need a G buffer at this shape: *h_wants = 1 -- the plan materialises the dScores (G required);
+ * 0 -- G may be NULL, and passing NULL (with S_out NULL) selects the form of the step that never writes them: the few-rows plan's sim
+ * launch then leaves every 128-column tile's own softmax (bf16) and the backward units derive the row logsumexp and one factor per
+ * (row, tile) themselves -- three launches instead of four at BASELINE cfg3 per rank (dpr_task.py:197-212 and its backward).  A
+ * non-NULL G is always honoured (and costs the dScores launch). */
+int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants);
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,
                             const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale,
                             float h_scale, const float* d_scale, float* S_out, float* row_loss, float* row_lse,
@@ -214,7 +220,7 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
  *   - dC_part [W * rows_c, d] is what the caller reduce-scatters; in every rank chunk k its element
  *     [k * rows_c + n_ctx][0] (first mask row, a dead gradient) carries THIS rank's loss numerator, so the rank's
  *     reduce-scatter output holds the global sum of the loss numerators at [n_ctx][0]: no all-reduce for the loss.
- * loss_sum still receives the local numerator.  G is required (as in dprhot_inbatch_step_f32). */
+ * loss_sum still receives the local numerator.  G as in dprhot_inbatch_step_f32 (dprhot_step_wants_g(B, W * rows_c, d)). */
 int dprhot_inbatch_step_packed_f32(const float* q, const dprhot_bf16* gathered, dprhot_bf16* Qb, int B, int W, int rank,
                                    int n_ctx, int d, const int64_t* y, float inv_T, float grad_scale, float h_scale,
                                    const float* d_scale, float* row_loss, float* row_lse, float* loss_sum,

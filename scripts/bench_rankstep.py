@@ -21,7 +21,10 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[], help="name=value: dprhot_set_option before anything runs (A/B of the plans)")
+    ap.add_argument("--with-g", action="store_true", help="ask for the dScores (G != NULL): the plan that materialises them")
     a = ap.parse_args()
+    if a.with_g:
+        os.environ["DPRHOT_BENCH_G"] = "1"
     for kv in a.opt:
         k, v = kv.split("=")
         _lib.set_option(k, int(v))
@@ -39,7 +42,7 @@ def main():
         algo = (4 * bd + 2 * nd + 4 * bn) + 6 * bn + (2 * bn + 2 * nd + 4 * bd) + (2 * bn + 2 * bd + 4 * nd)  # SURVEY 8(d), 3-kernel design
         print(json.dumps({"B": B, "K": K, "d": d, "W": W, "Nc": hp.Nc, "step_us": round(us, 2), "loss_sum": float(hp.loss_sum.item()),
                           "algorithmic_MB": round(algo / 1e6, 2), "hbm_frac": round(algo / us * 1e-3 / 8000.0, 4),
-                          "skinny": not _lib.get_option("no_skinny")}), flush=True)
+                          "skinny": not _lib.get_option("no_skinny"), "G_materialised": bool(hp.want_g)}), flush=True)
         del hp
         torch.cuda.empty_cache()
 
