@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -146,9 +146,10 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
     {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
     {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
-    {"sk_fused", 1, "0 keeps the dScores launch of the few-rows plan (sk_g_kernel) where the caller passes G == NULL (A/B of the three-launch step)"},
+    {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured no slower (B x Nc >= 2^20: cfg3 per rank), 2 = wherever the plan exists (tests), 0 = never"},
+    {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward): 1 dC units leave at once, 2 dQ units leave at once, 4 dQ units load no gold rows"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1};
+int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0};
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -432,10 +433,16 @@ SkPlan sk_plan(int B, int Nc, int d) {
 // the row logsumexp and the per-tile factors itself).  nts = statistics tiles, nk = 64-context steps of the dQ units (tile space: the
 // packed layout's remapped tiles skip the header rows).  128-column statistics tiles only (a dC unit is one tile), at most 128 of
 // them, the dQ slices as the plan cut them and short enough for a unit's factor table (SK_FT tiles).
+// Where it is chosen (option sk_fused = 1): B x Nc >= 2^20 -- measured, three alternating runs on one box (profiles/r04_fused_ab.txt): cfg3
+// per rank (128 x 8256 x 768) 28.7-29.3 us against 29.3-29.6 with the dScores launch; 64 x 8256 x 512 22.6-22.9 against 21.5-21.8 and
+// 128 x 4128 x 768 24.5-24.7 against 23.2-23.3 (fewer units per launch: the longer units of this form are not covered by the launch
+// it saves).  What it always buys is accuracy: the gold terms stay in fp32 (gradients 3e-5 of max |grad| from an fp64 reference instead of 1e-3).
 struct SkFused { bool ok; int ksteps; };
-SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk) {
+SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk, int B = 0, int Nc = 0) {
   SkFused f{false, 0};
-  if (!sk.ok || sk.scols != SK_COLS || nts > 128 || sk.nslices < 1) return f;
+  const int mode = opt(OPT_SK_FUSED);
+  if (mode == 0 || (mode == 1 && (long)B * Nc < (1l << 20))) return f;
+  if (!sk.ok || sk.scols != SK_COLS || nts > 128 || sk.nslices < 1 || sk.nslices > 64) return f;
   f.ksteps = cdiv(nk, sk.nslices);  // (a tiling with fewer steps may leave the last slices empty: their units write zero slabs)
   f.ok = (f.ksteps + 1) / 2 + 1 <= SK_FT;
   return f;
@@ -602,8 +609,8 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
               g_packed.n_ctx, g_packed.row_bytes, tpr};
   // G == NULL (nobody wants the dScores): three launches -- the sim launch leaves the tile-local softmax in the logit workspace
   const int nk_f = remap ? 2 * nts : cdiv(Nc, 64);
-  const SkFused fz = sk_fused_plan(sk, nts, nk_f);
-  const bool fused = G == nullptr && S_out == nullptr && fz.ok && opt(OPT_SK_FUSED) != 0;
+  const SkFused fz = sk_fused_plan(sk, nts, nk_f, B, Nc);
+  const bool fused = G == nullptr && S_out == nullptr && fz.ok;
   if (G == nullptr && !fused) return fail(DPRHOT_E_INVALID, "few-rows step: G == NULL needs the fused-dScores plan (dprhot_step_wants_g)");
   if (fused) {
     a.S = nullptr;
@@ -624,11 +631,12 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   }
   if (rc) return rc;
   if (fused) {
-    float* part = g_dq_part != nullptr ? g_dq_part : reinterpret_cast<float*>(ws + wl.dq_part);
+    if (g_dq_part != nullptr) return fail(DPRHOT_E_INVALID, "few-rows step without dScores: dQ is finished by the step itself (dprhot_train_dq_slabs = 0)");
+    float* part = reinterpret_cast<float*>(ws + wl.dq_part);
     const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = nts * (d / SK_DN);
     SkBwdFArgs b{a.P, Qb, Cb, B, Nc, d, tile_lse, gold, y, y_offset, nts, tpr, g_packed.rows_c, g_packed.n_ctx, grad_scale, h_scale, d_scale,
                  dC_part, g_dc_bf16 ? 1 : 0, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, loss_sum, g_loss_scale,
-                 row_loss, row_lse, fz.ksteps, sk.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0};
+                 row_loss, row_lse, fz.ksteps, sk.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0, opt(OPT_SK_DBG)};
     const size_t lds = sk_bwdf_lds();
     static AttrOnce attr_done[2];
     if (nts <= 64) {
@@ -645,9 +653,10 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       hipLaunchKernelGGL(sk_bwdf_kernel<16>, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
     }
     HIP_TRY(hipGetLastError());
-    if (g_dq_part == nullptr && sk.nslices > 1) {
-      const size_t n4 = (size_t)B * d / 4;
-      hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, sk.nslices, n4, h_scale, d_scale, dQ);
+    {
+      const int parts = cdiv(d / 4, 128);
+      SkFinArgs f{part, sk.nslices, fz.ksteps, nk_f, B, d, tile_lse, nts, gold, y, y_offset, Cb, grad_scale, h_scale, d_scale, dQ, parts};
+      hipLaunchKernelGGL(sk_dq_finish_kernel, dim3((unsigned)(B * parts)), dim3(128), 0, st, f);
       HIP_TRY(hipGetLastError());
     }
     return DPRHOT_OK;
@@ -1334,7 +1343,7 @@ int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants) {
   // 0 where the few-rows plan takes the fused-dScores form -- judged on the plain column tiling: the packed layout's remapped tiles
   // are never more and their slices never longer.  A pure function of the shape, like every plan here.
   const SkPlan sk = sk_plan(B, Nc, d);
-  *h_wants = (opt(OPT_SK_FUSED) != 0 && sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64)).ok) ? 0 : 1;
+  *h_wants = sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc).ok ? 0 : 1;
   return DPRHOT_OK;
 }
 
@@ -1469,14 +1478,18 @@ int dprhot_train_dq_slabs(int B, int Nc, int d, int* h_nslabs) {
   if (int rc = check_shape(B, Nc, d)) return rc;
   const SkPlan sk = sk_plan(B, Nc, d);
   *h_nslabs = sk.ok && sk.nslices > 1 ? sk.nslices : 0;  // the other plans (and a one-slice few-rows plan) do not split dQ or combine it themselves
+  // where the step can run without the dScores (dprhot_step_wants_g = 0) its slabs are slice-normalised and need the row statistics to
+  // be combined: the step's own finishing launch does that, nothing is left to the caller
+  if (sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc).ok) *h_nslabs = 0;
   return DPRHOT_OK;
 }
 
 static int train_dq_part_ok(const float* dq_part, int B, int Nc, int d) {
   if (dq_part == nullptr) return DPRHOT_OK;
   REQUIRE(aligned16(dq_part), "dq_part must be 16-byte aligned");
-  const SkPlan sk = sk_plan(B, Nc, d);
-  if (!sk.ok || sk.nslices <= 1) return fail(DPRHOT_E_INVALID, "train_step: dq_part given but B=%d Nc=%d d=%d leaves no slabs (dprhot_train_dq_slabs = 0)", B, Nc, d);
+  int n = 0;
+  if (int rc = dprhot_train_dq_slabs(B, Nc, d, &n)) return rc;
+  if (n == 0) return fail(DPRHOT_E_INVALID, "train_step: dq_part given but B=%d Nc=%d d=%d leaves no slabs (dprhot_train_dq_slabs = 0)", B, Nc, d);
   return DPRHOT_OK;
 }
 

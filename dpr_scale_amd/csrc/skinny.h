@@ -776,14 +776,15 @@ struct SkBwdFArgs {
   float* row_loss;        // [B] out or nullptr
   float* row_lse;         // [B] out or nullptr
   int ksteps, nslices;    // dQ: 64-context steps per slice (tile space), slices
-  float* part;            // [nslices][B][d]
-  float* dQ;              // nslices == 1
+  float* part;            // [nslices][B][d] slice-normalised slabs (finished by sk_dq_finish_kernel)
+  float* dQ;              // (unused: the finishing launch writes dQ)
   int ndq_pad;
   int nt_store;
+  int dbg = 0;            // TIMING EXPERIMENTS ONLY (option sk_dbg): 1 dC units leave at once, 2 dQ units leave at once, 
 };
 
 constexpr int SK_FT = 8;                            // statistics tiles a dQ unit may touch ((ksteps + 1) / 2 + 1 <= SK_FT: sk_fused_ok)
-constexpr int SK_FX = (SK_FT * 128 + 2 * 128) * 4;  // bytes of a dQ unit's tables behind its ring: f[SK_FT][128], g[128], y[128]
+constexpr int SK_FX = (SK_FT * 128 + 2 * 128) * 4;  // bytes of a dQ unit's table behind its ring: w[SK_FT][128] (+ 1 KiB spare)
 inline size_t sk_bwdf_lds() { return (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2 + SK_FX; }
 constexpr int SK_FDC_TAB = SK_COLS * SK_DC_TS * 4;  // byte offset of a dC unit's tables (behind its fp32 epilogue tile)
 
@@ -834,6 +835,11 @@ struct SkRowStats {
 #pragma unroll
     for (int u = 0; u < NG; ++u) sv[u] = sk_ld16_hidden(tile_lse + ((size_t)min(ph + 2 * u, ng - 1) * B + prow) * 4);
   }
+  // (guide section 5.7 item 3: makes the loaded registers opaque HERE, behind the caller's counted wait -- no consumer is scheduled above it)
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int u = 0; u < NG; ++u) asm volatile("" : "+v"(sv[u]));
+  }
   __device__ __forceinline__ float finish(int nt, int ph) const {
     float mx = -INFINITY;
     float v[NG][4];
@@ -858,14 +864,23 @@ struct SkRowStats {
   }
 };
 
-// dQ unit (fused): (slice of 64-context steps in tile space) x (64 columns of d), all B rows
+// dQ unit (fused): (slice of 64-context steps in tile space) x (64 columns of d), all B rows.
+// The unit does NOT need the row logsumexp.  Its slab is normalised to the slice's own reference m = max of the slice's tile values:
+//     slab_i = sum_{t in slice} exp(lse_it - m_i) * (sum_{j in t} P_ij C_j)
+// (one 4-byte load and one exponential per thread and tile), and the finishing launch -- which exists anyway to add the slabs up --
+// multiplies slab s by exp(m_is - lse_i) * scale and adds the gold term g_i C[y_i] (sk_dq_finish_kernel: 65 tile values per ROW there,
+// not per unit).  Measured forms of this unit that derived the row logsumexp themselves (per-workgroup stamps, dQ units alone on the
+// chip): 15.5-16.1 us against 10.8 for sk_dq_unit -- the statistics round trip and 32 exponentials per thread sit in front of, or
+// inside, a latency-chained loop whichever way they are scheduled (before the first step: prologue 3.5 us; under step 0's MFMAs: the
+// ring runs dry behind them), and the launch came out exactly as long as the two launches it replaced (29.4 us per step both ways).
+// The factor FMAs of step s run under the MFMAs of step s + 1 (two scratch accumulators), and a slot is refilled as soon as every
+// wave holds its fragments.
 template <int NG>
 __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
   constexpr int IA = SK_QA * 2 / 1024 / 4;  // 4
   constexpr int IB = SK_QB * 2 / 1024 / 4;  // 2
   constexpr int PER = IA + IB;
   constexpr int SLOT = SK_QA + SK_QB;
-  constexpr int NGOLD = 8;                  // gold-row loads per thread (one per epilogue item)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ndt = p.d / SK_QN;
   const int dt = unit % ndt, ks = unit / ndt;
@@ -874,28 +889,23 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   const int s0 = ks * p.ksteps;
   const int ns = min(p.ksteps, nk - s0);
   const int t0 = s0 >> 1;
+  float* const out = p.part + (size_t)ks * p.B * p.d;
   if (ns <= 0) {  // a remapped tiling with fewer steps than the plan's slices cover: this slice is empty, its slab is zero
-    float* const out0 = p.part + (size_t)ks * p.B * p.d;
     for (int e = tid; e < p.B * (SK_QN / 4); e += SK_THREADS)
-      *reinterpret_cast<float4*>(out0 + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(out + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  float* const fs = reinterpret_cast<float*>(sk_smem + SK_QSLOTS * SLOT);  // [SK_FT][128]: f of (local tile, row)
-  float* const gv = fs + SK_FT * 128;                                       // [128]: g of the row, 0 when its gold column is not in this slice
-  int* const yl = reinterpret_cast<int*>(gv + 128);                          // [128]: gold column (global), or -1 (not in this slice)
+  float* const fs = reinterpret_cast<float*>(sk_smem + SK_QSLOTS * SLOT);  // [SK_FT][128]: weight of (local tile, row)
+  DPRHOT_TMB(2, 0);
 
-  // ---- hidden loads first: they return under the DMAs issued behind them
+  // ---- hidden loads first (older than every DMA of this wave): the tile values of this slice, row tid >> 1, tiles t0 + (tid & 1) + 2u
   const int prow = min(tid >> 1, p.B - 1), ph = tid & 1;
-  SkRowStats<NG> st;
-  st.issue(p.tile_lse, p.nt, p.B, prow, ph);
   float lt[SK_FT / 2];
 #pragma unroll
   for (int u = 0; u < SK_FT / 2; ++u) {
     const int t = min(t0 + ph + 2 * u, p.nt - 1);
     lt[u] = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
   }
-  const float gl = sk_ld4_hidden(p.gold + prow);
-  const float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);  // low word of the int64 label
 
   // ---- ring DMAs: per-lane source coordinates (one instruction = 1 KiB = 8 rows of 128 bytes)
   unsigned arow[IA];
@@ -929,67 +939,36 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(k0 + bkr[j], p.Nc - 1) * (unsigned)p.d + bcol[j]),
                                        (g2_lds_ptr*)(Bs + (wave * IB + j) * 512), 16, 0, 0);
   };
-  const int npre = min(ns, SK_QSLOTS);
 #pragma unroll
   for (int s = 0; s < SK_QSLOTS; ++s)
     if (s < ns) issue(s, s);
-
-  // ---- the hidden loads have landed when at most the DMAs issued behind them are outstanding
-  sk_wait_younger<PER>(npre);
-  __builtin_amdgcn_sched_barrier(0);
-  const float lse = st.finish(p.nt, ph);
-  {
-    const int row = tid >> 1;
-    if (row < p.B) {
-#pragma unroll
-      for (int u = 0; u < SK_FT / 2; ++u) {
-        const int tl = ph + 2 * u;
-        // exp(-inf - lse) == 0: a tile without an unmasked column contributes nothing
-        const float f = t0 + tl < p.nt ? __expf(lt[u] - lse) * p.grad_scale : 0.f;
-        sk_lds_st32(fs + tl * 128 + row, __float_as_uint(f));
-      }
-      if (ph == 0) {
-        const int yg = __float_as_int(yf) + (int)p.y_offset;
-        const int gstep = sk_step_of_col(p, yg);
-        const bool mine = gstep >= s0 && gstep < s0 + ns;
-        sk_lds_st32(gv + row, __float_as_uint(mine ? (__expf(gl - lse) - 1.0f) * p.grad_scale : 0.f));
-        sk_lds_st32(yl + row, (unsigned)(mine ? yg : -1));
-      }
-    }
-  }
-  sk_barrier();
-  // gold rows C[y_i][c0 + 4 cq ..] for the eight (row, cq) items this thread stores in the epilogue: unconditional (a row without a
-  // gold column here reads row 0 and multiplies by g = 0), so that every wave has the same number of loads in its queue
-  const int erow0 = tid >> 4, ecq = tid & 15;
-  sk_u32x2 gq[NGOLD];
-#pragma unroll
-  for (int it = 0; it < NGOLD; ++it) {
-    const int yy = yl[min(erow0 + it * 16, p.B - 1)];
-    gq[it] = sk_ld8_hidden(p.C + (size_t)max(yy, 0) * p.d + c0 + ecq * 4);
-  }
+  // (Measured and not kept: warming this XCD's L2 for the later steps -- one lane per 128-byte line of their operands into a register
+  //  nobody reads, issued right behind the first three slots' DMAs, counted in the waits of steps 0..2.  The loop did not get faster
+  //  (10.3 against 10.2 us by the stamps: the step is not waiting for far memory) and the prologue grew from 1.4 to 3.5 us.)
+  DPRHOT_TMB(2, 1);
 
   const int i16 = lane & 15, g4 = lane >> 4;
-  f32x4 acc[2][4];
+  f32x4 acc[2][4], tA[2][4], tB[2][4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < 4; ++b) acc[a][b] = tA[a][b] = tB[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  for (int s = 0; s < ns; ++s) {
-    // slot s has landed when only what was issued behind it is outstanding: the later slots' DMAs, and -- for the slots of the
-    // prologue -- the gold-row loads
-    {
-      const int younger = min(s + SK_QSLOTS - 1, ns - 1) - s;
-      if (s < SK_QSLOTS) {
-        switch (younger) {
-          case 0: sk_wait_vm<NGOLD>(); break;
-          case 1: sk_wait_vm<NGOLD + PER>(); break;
-          default: sk_wait_vm<NGOLD + 2 * PER>(); break;
-        }
-      } else {
-        sk_wait_younger<PER>(younger);
-      }
+  auto add_scaled = [&](int s, const f32x4 (&tm)[2][4]) {  // sum += w(row, tile of step s) * (P x C of step s)
+    const int tl = ((s0 + s) >> 1) - t0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const f32x4 fr = *reinterpret_cast<const f32x4*>(fs + tl * 128 + wave * 32 + a * 16 + g4 * 4);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaf(fr[r], tm[a][b][r], acc[a][b][r]);
     }
+  };
+  // one step: FIRST = step 0 (forms the weight table); cur receives this step's product, prev holds the previous step's
+  auto body = [&](auto first_tag, int s, f32x4 (&cur)[2][4], const f32x4 (&prev)[2][4]) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    sk_wait_younger<PER>(min(s + SK_QSLOTS - 1, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
     const int slot = s % SK_QSLOTS;
     uint16_t* As = sk_smem + slot * SLOT;
     const uint16_t* Bs = As + SK_QA;
@@ -1001,13 +980,9 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
         if (ch * 8 >= kvalid) *reinterpret_cast<uint4*>(As + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
-    sk_barrier();
+    sk_barrier();  // (step 1: also publishes the table step 0 wrote)
     bf16x8 af[2][2];
     bf16x4 lo[2][4], hi[2][4];
-    f32x4 fr[2];
-    const int tl = ((s0 + s) >> 1) - t0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) fr[a] = *reinterpret_cast<const f32x4*>(fs + tl * 128 + wave * 32 + a * 16 + g4 * 4);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -1024,7 +999,12 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 tmp[2][4];
+    // The slot is free as soon as every wave holds its fragments: refill it now (the ring is a latency chain: a DMA issued late is
+    // data late, two steps on)
+    if (s + SK_QSLOTS < ns) {
+      sk_barrier();
+      issue(s + SK_QSLOTS, slot);
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 bf[4];
@@ -1039,24 +1019,46 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          tmp[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : tmp[a][b], 0, 0, 0);
+#if defined(SK_EXP) && (SK_EXP & 1)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], acc[a][b], 0, 0, 0);
+#else
+          cur[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cur[a][b], 0, 0, 0);
+#endif
     }
-    // the step's 64 contexts lie in ONE statistics tile: sum += f(row, tile) * (P x C)
+    if constexpr (FIRST) {
+      // under the MFMAs: the slice's reference per row and the weights of its tiles (published by the next barrier of this workgroup)
+      asm volatile("" : "+v"(lt[0]), "+v"(lt[1]), "+v"(lt[2]), "+v"(lt[3]));
+      const int tlast = min((s0 + ns - 1) >> 1, p.nt - 1) - t0;  // last local tile of this slice
+      float m = -INFINITY;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int u = 0; u < SK_FT / 2; ++u) m = fmaxf(m, ph + 2 * u <= tlast ? lt[u] : -INFINITY);
+      m = fmaxf(m, ss_dpp<0xB1>(m));  // the other half of the row's tiles (lane ^ 1)
+      const int row = tid >> 1;
+      if (row < p.B) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaf(fr[a][r], tmp[a][b][r], acc[a][b][r]);
-    if (s + SK_QSLOTS < ns) {
-      sk_barrier();
-      issue(s + SK_QSLOTS, slot);
+        for (int u = 0; u < SK_FT / 2; ++u) {
+          const int tl = ph + 2 * u;
+          // a tile (or a whole slice) without an unmasked column weighs 0
+          const float w = (tl <= tlast && lt[u] != -INFINITY) ? __expf(lt[u] - m) : 0.f;
+          sk_lds_st32(fs + tl * 128 + row, __float_as_uint(w));
+        }
+      }
+    } else {
+#if !defined(SK_EXP) || !(SK_EXP & 1)
+      add_scaled(s - 1, prev);
+#endif
     }
+  };
+  body(std::true_type{}, 0, tA, tB);
+  for (int s = 1; s < ns; s += 2) {
+    body(std::false_type{}, s, tB, tA);
+    if (s + 1 < ns) body(std::false_type{}, s + 1, tA, tB);
   }
-  sk_wait_vm<0>();  // (the gold rows: older than every DMA of the loop, long landed)
-  __builtin_amdgcn_sched_barrier(0);
-  sk_barrier();
-  // ---- partial tile [128][64] fp32 through LDS -> 16-byte stores, 256 bytes per row; the gold term in fp32 on the way out
+  sk_barrier();  // every wave is done with the ring (and, when the slice is one step long, the table is published here)
+  if ((ns - 1) & 1) add_scaled(ns - 1, tB);
+  else add_scaled(ns - 1, tA);
+  DPRHOT_TMB(2, 2);
+  // ---- slab tile [128][64] fp32 through LDS -> 16-byte stores, 256 bytes per row
   constexpr int TS = SK_QN + 4;
   float* const T = reinterpret_cast<float*>(sk_smem);
 #pragma unroll
@@ -1066,26 +1068,22 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(wave * 32 + a * 16 + g4 * 4 + r) * TS + b * 16 + i16] = acc[a][b][r];
   sk_barrier();
-  const bool fin = p.nslices == 1;
-  float* out = fin ? p.dQ : p.part + (size_t)ks * p.B * p.d;
-  const float sc = fin ? p.h_scale * (p.d_scale ? *p.d_scale : 1.0f) : 1.0f;
 #pragma unroll
-  for (int it = 0; it < NGOLD; ++it) {
-    const int row = erow0 + it * 16;
+  for (int it = 0; it < 8; ++it) {
+    const int e = tid + it * SK_THREADS, row = e >> 4, cq = e & 15;
     if (row < p.B) {
-      float4 v = *reinterpret_cast<const float4*>(T + row * TS + ecq * 4);
-      const float g = gv[row];
-      v.x = fmaf(g, sk_bf_lo(gq[it][0]), v.x) * sc;
-      v.y = fmaf(g, sk_bf_hi(gq[it][0]), v.y) * sc;
-      v.z = fmaf(g, sk_bf_lo(gq[it][1]), v.z) * sc;
-      v.w = fmaf(g, sk_bf_hi(gq[it][1]), v.w) * sc;
-      if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + ecq * 4));
-      else *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + ecq * 4) = v;
+      const float4 v = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
+      if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
+      else *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + cq * 4) = v;
     }
   }
+  DPRHOT_TMB(2, 3);
 }
 
-// dC unit (fused): statistics tile t (128 contexts) x 128 columns of d
+// dC unit (fused): statistics tile t (128 contexts) x 128 columns of d.
+// The thread pair that derives row i's logsumexp also owns row i of the Q image: it scales the row by f in place and KEEPS the
+// unscaled values; after the GEMM it adds g_i * q_i to the output row of its gold column (one row of the fp32 tile per gold column:
+// no lookup tables, no second trip to Q).  Rows that share a gold column (cnt > 1: rare) are added one after the other instead.
 template <int NG>
 __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
   constexpr size_t kImg = (size_t)SK_MAXB * SK_COLS;
@@ -1095,10 +1093,9 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   float* const fi = reinterpret_cast<float*>(tab);  // [128] f of (row, this tile)
   float* const gv = fi + 128;                       // [128] g of the row
   float* const rl = gv + 128;                       // [128] row loss
-  int* const head = reinterpret_cast<int*>(rl + 128);  // [128] first row whose gold column is context m of this tile, or >= 128
-  int* const nxt = head + 128;                         // [128] next row with the same gold column (built only when two rows share one)
-  int* const ym = nxt + 128;                           // [128] gold column relative to the tile, or -1
-  int* const dupf = ym + 128;                          // [1]
+  int* const ym = reinterpret_cast<int*>(rl + 128);  // [128] gold column relative to the tile, or -1
+  int* const cnt = ym + 128;                         // [128] rows whose gold column is context m of this tile
+  int* const dupf = cnt + 128;                       // [1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ndt = (p.d + SK_DN - 1) / SK_DN;
   const int dt = unit % ndt, t = unit / ndt;
@@ -1106,14 +1103,15 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   const int kmax = p.B;
   const int nvalid = p.tiles_per_rank > 0 ? SK_COLS : min(SK_COLS, p.Nc - n0);  // contexts of this tile
 
-  if (tid < SK_COLS) head[tid] = 0x7fffffff;  // (no DMA in flight yet: a plain store)
+  DPRHOT_TMB(1, 0);
+  if (tid < SK_COLS) cnt[tid] = 0;  // (no DMA in flight yet: a plain store)
   if (tid == 0) dupf[0] = 0;
   const int prow = min(tid >> 1, p.B - 1), ph = tid & 1;
   SkRowStats<NG> st;
   st.issue(p.tile_lse, p.nt, p.B, prow, ph);
-  const float lt = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
-  const float gl = sk_ld4_hidden(p.gold + prow);
-  const float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
+  float lt = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
+  float gl = sk_ld4_hidden(p.gold + prow);
+  float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
   const int nins = kmax / 4 / 4;  // per wave and image (B % 32 == 0: 2, 4, 6 or 8)
   for (int j = 0; j < nins; ++j) {
     const int krow = (wave * nins + j) * 4 + (lane >> 4), pos = lane & 15;
@@ -1123,51 +1121,68 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
     __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.Qb + (size_t)krow * p.d + min(c0 + col, p.d - 8)),
                                      (g2_lds_ptr*)(Qs + (wave * nins + j) * 4 * SK_DN), 16, 0, 0);
   }
+  DPRHOT_TMB(1, 1);
   sk_wait_younger<4>(nins >> 1);  // 2 * nins DMAs behind the hidden loads
   __builtin_amdgcn_sched_barrier(0);
+  st.pin();
+  asm volatile("" : "+v"(lt), "+v"(gl), "+v"(yf));
   const float lse = st.finish(p.nt, ph);
   const float f = __expf(lt - lse) * p.grad_scale;
   const int yrel = __float_as_int(yf) + (int)p.y_offset - n0;  // gold column relative to this tile
-  const bool mine = yrel >= 0 && yrel < nvalid;
+  const int row = tid >> 1;
+  const bool mine = row < p.B && yrel >= 0 && yrel < nvalid;
   const float g = (__expf(gl - lse) - 1.0f) * p.grad_scale;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // the images have landed; head[] is initialised
+  __syncthreads();  // the images have landed; cnt[] is initialised
+  DPRHOT_TMB(1, 2);
+  // Tables first; the rows that have a gold column in this tile keep their unscaled half row (the gold term needs it).
+  // (A pass in which every thread scaled its own half row read the image at a 128-byte lane stride: 8-way bank conflicts on every
+  //  b128 access, 2.1 us per unit by the stamps.)
+  uint4 raw[8];
   {
-    const int row = tid >> 1;
-    if (ph == 0 && row < p.B) {
-      fi[row] = f;
-      gv[row] = g;
-      rl[row] = lse - gl;
-      ym[row] = mine ? yrel : -1;
-      if (mine) atomicMin(&head[yrel], row);
-      if (unit == 0) {
-        if (p.row_loss) p.row_loss[row] = lse - gl;
-        if (p.row_lse) p.row_lse[row] = lse;
+    const uint4* base = reinterpret_cast<const uint4*>(Qs + min(row, kmax - 1) * SK_DN + ph * 64);
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = base[j];
+    }
+    if (ph == 0) {
+      if (row < p.B) {
+        fi[row] = f;
+        gv[row] = g;
+        rl[row] = lse - gl;
+        ym[row] = mine ? yrel : -1;
+        if (mine) atomicAdd(&cnt[yrel], 1);
+        if (unit == 0) {
+          if (p.row_loss) p.row_loss[row] = lse - gl;
+          if (p.row_lse) p.row_lse[row] = lse;
+        }
+      } else {
+        fi[row] = 0.f;
+        rl[row] = 0.f;
+        ym[row] = -1;
       }
-    } else if (ph == 0) {
-      rl[row] = 0.f;
-      ym[row] = -1;
     }
   }
   __syncthreads();
   {
-    // Q rows x f (in place, both bf16): row k of the image is 256 contiguous bytes whatever the column swizzle; one half row per thread
-    const int row = tid >> 1;
-    if (row < kmax) {
-      const float fr = fi[row];
-      uint4* base = reinterpret_cast<uint4*>(Qs + row * SK_DN + ph * 64);
+    // Q rows x f in place (both bf16): 16-byte chunk c of the image belongs to row c >> 4 whatever the column swizzle; consecutive
+    // lanes take consecutive chunks
+    uint4* const img = reinterpret_cast<uint4*>(Qs);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        uint4 w = base[j];
-        w.x = pk_bf16(sk_bf_lo(w.x) * fr, sk_bf_hi(w.x) * fr);
-        w.y = pk_bf16(sk_bf_lo(w.y) * fr, sk_bf_hi(w.y) * fr);
-        w.z = pk_bf16(sk_bf_lo(w.z) * fr, sk_bf_hi(w.z) * fr);
-        w.w = pk_bf16(sk_bf_lo(w.w) * fr, sk_bf_hi(w.w) * fr);
-        base[j] = w;
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int c = tid + j * SK_THREADS;
+      const float fr = fi[c >> 4];
+      uint4 w = img[c];
+      w.x = pk_bf16(sk_bf_lo(w.x) * fr, sk_bf_hi(w.x) * fr);
+      w.y = pk_bf16(sk_bf_lo(w.y) * fr, sk_bf_hi(w.y) * fr);
+      w.z = pk_bf16(sk_bf_lo(w.z) * fr, sk_bf_hi(w.z) * fr);
+      w.w = pk_bf16(sk_bf_lo(w.w) * fr, sk_bf_hi(w.w) * fr);
+      img[c] = w;
     }
-    if (ph == 0 && row < p.B && mine && head[yrel] != row) dupf[0] = 1;  // two rows with one gold column
   }
+  __syncthreads();
+  const bool solo = mine && cnt[yrel] == 1;
+  if (mine && !solo) dupf[0] = 1;  // two rows with one gold column (read behind the next barrier)
   // loss numerator (every unit that stamps it, and unit 0 which publishes it): fixed order
   const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
   const bool last_of_rank = p.tiles_per_rank > 0 && t % p.tiles_per_rank == p.tiles_per_rank - 1;
@@ -1177,29 +1192,7 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
     lsum = sk_loss_sum(rl, SK_MAXB, lane) * p.loss_scale;
     if (unit == 0 && tid == 0) p.loss_sum[0] = lsum;
   }
-  // gold rows of Q for the sixteen (context, 4 columns) items this thread stores: plain loads (no DMA is in flight any more)
-  const int em0 = tid >> 5, ecq = tid & 31;
-  uint2 gq[16];
-  int gh[16];
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int h = head[em0 + it * 8];
-    gh[it] = h;
-    gq[it] = *reinterpret_cast<const uint2*>(p.Qb + (size_t)(h < SK_MAXB ? h : 0) * p.d + min(c0 + ecq * 4, p.d - 4));
-  }
-  __syncthreads();
-  if (dupf[0] != 0) {  // rare: chain the rows that share a gold column, ascending
-    if (tid < p.B) {
-      int nx = 0x7fffffff;
-      const int mym = ym[tid];
-      if (mym >= 0)
-        for (int i2 = tid + 1; i2 < p.B; ++i2)
-          if (ym[i2] == mym) { nx = i2; break; }
-      nxt[tid] = nx;
-    }
-    __syncthreads();
-  }
-
+  DPRHOT_TMB(1, 3);
   const int wm = wave >> 1, wn = wave & 1;
   const int i16 = lane & 15, g4 = lane >> 4;
   f32x4 acc[4][4];
@@ -1219,6 +1212,7 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
       for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
   __syncthreads();  // the images are dead: the fp32 tile takes their place (the tables lie behind it)
+  DPRHOT_TMB(1, 4);
   float* const T = reinterpret_cast<float*>(sk_smem);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -1227,47 +1221,59 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(wm * 64 + a * 16 + g4 * 4 + r) * SK_DC_TS + wn * 64 + b * 16 + i16] = acc[a][b][r];
   __syncthreads();
-  // Every gold-row load retires HERE, in a form the compiler sees (vmcnt(0) only).  They are consumed under conditions below; left
-  // "pending" on the other paths they reach -- in hipcc's linearised view of this kernel -- the dQ unit's code, which then guards
-  // their registers with s_waitcnt vmcnt(13) / vmcnt(0) in front of its DMA issue: waits that at run time hit the dQ unit's own
-  // hidden statistics loads (seen in the ISA; one L2 round trip per dQ unit before its first DMA).
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  const bool dups = dupf[0] != 0;
-  // one output row = 128 fp32; item (context m, column quad cq): tile value + g_i * q_i of the rows i whose gold column is m
+  if (solo) {  // the only row with this gold column: g * q added to that output row in fp32, this thread's 64 columns
+    float* const trow0 = T + yrel * SK_DC_TS;
 #pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int mrow = em0 + it * 8, m = n0 + mrow;
-    if (mrow < nvalid && c0 + ecq * 4 < p.d) {
-      float4 v = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + ecq * 4);
-      int h = gh[it];
-      if (h < SK_MAXB) {
-        const float gg = gv[h];
-        v.x = fmaf(gg, sk_bf_lo(gq[it].x), v.x);
-        v.y = fmaf(gg, sk_bf_hi(gq[it].x), v.y);
-        v.z = fmaf(gg, sk_bf_lo(gq[it].y), v.z);
-        v.w = fmaf(gg, sk_bf_hi(gq[it].y), v.w);
-        if (dups) {
-          for (h = nxt[h]; h < SK_MAXB; h = nxt[h]) {
-            const uint2 q2 = *reinterpret_cast<const uint2*>(p.Qb + (size_t)h * p.d + c0 + ecq * 4);
-            const float g2 = gv[h];
-            v.x = fmaf(g2, sk_bf_lo(q2.x), v.x);
-            v.y = fmaf(g2, sk_bf_hi(q2.x), v.y);
-            v.z = fmaf(g2, sk_bf_lo(q2.y), v.z);
-            v.w = fmaf(g2, sk_bf_hi(q2.y), v.w);
-          }
-        }
+    for (int j = 0; j < 8; ++j) {
+      // 16-byte chunk j of this thread's half of image row `row` holds the columns of 32-byte group ((4 ph + j / 2) ^ mswz(row))
+      float* const trow = trow0 + ((((ph << 2) | (j >> 1)) ^ mswz(row)) << 4) + (j & 1) * 8 - j * 8;
+      float4 a = *reinterpret_cast<const float4*>(trow + j * 8), b = *reinterpret_cast<const float4*>(trow + j * 8 + 4);
+      a.x = fmaf(g, sk_bf_lo(raw[j].x), a.x); a.y = fmaf(g, sk_bf_hi(raw[j].x), a.y);
+      a.z = fmaf(g, sk_bf_lo(raw[j].y), a.z); a.w = fmaf(g, sk_bf_hi(raw[j].y), a.w);
+      b.x = fmaf(g, sk_bf_lo(raw[j].z), b.x); b.y = fmaf(g, sk_bf_hi(raw[j].z), b.y);
+      b.z = fmaf(g, sk_bf_lo(raw[j].w), b.z); b.w = fmaf(g, sk_bf_hi(raw[j].w), b.w);
+      *reinterpret_cast<float4*>(trow + j * 8) = a;
+      *reinterpret_cast<float4*>(trow + j * 8 + 4) = b;
+    }
+  }
+  if (dupf[0] != 0) {  // rows that share a gold column: one after the other, ascending (bit-reproducible)
+    for (int i = 0; i < p.B; ++i) {
+      const int m = ym[i];
+      if (m >= 0 && cnt[m] > 1) {  // (uniform: every thread reads the same table entries)
+        if (tid < SK_DN && c0 + tid < p.d) T[m * SK_DC_TS + tid] = fmaf(gv[i], sk_bf_lo((unsigned)p.Qb[(size_t)i * p.d + c0 + tid]), T[m * SK_DC_TS + tid]);
+        __syncthreads();
       }
-      v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-      if (p.dc_bf16) {
-        uint16_t* const out = static_cast<uint16_t*>(p.dC);
-        const sk_u32x2 w = {pk_bf16(v.x, v.y), pk_bf16(v.z, v.w)};
-        if (p.nt_store) __builtin_nontemporal_store(w, reinterpret_cast<sk_u32x2*>(out + (size_t)m * p.d + c0 + ecq * 4));
-        else *reinterpret_cast<sk_u32x2*>(out + (size_t)m * p.d + c0 + ecq * 4) = w;
-      } else {
-        float* const out = static_cast<float*>(p.dC);
-        if (stamp && ecq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
-        if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)m * p.d + c0 + ecq * 4));
-        else *reinterpret_cast<float4*>(out + (size_t)m * p.d + c0 + ecq * 4) = v;
+    }
+  }
+  __syncthreads();
+  DPRHOT_TMB(1, 5);
+  if (p.dc_bf16) {  // 8 values per lane: whole 256-byte rows of bf16
+    uint16_t* const out = static_cast<uint16_t*>(p.dC);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int e = tid + it * SK_THREADS, mrow = e >> 4, c8 = e & 15;
+      const int m = n0 + mrow;
+      if (mrow < nvalid && c0 + c8 * 8 < p.d) {
+        const float4 a = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + c8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + c8 * 8 + 4);
+        typedef unsigned sk_u4 __attribute__((ext_vector_type(4)));
+        const sk_u4 w = {pk_bf16(a.x * sc, a.y * sc), pk_bf16(a.z * sc, a.w * sc), pk_bf16(b.x * sc, b.y * sc), pk_bf16(b.z * sc, b.w * sc)};
+        if (p.nt_store) __builtin_nontemporal_store(w, reinterpret_cast<sk_u4*>(out + (size_t)m * p.d + c0 + c8 * 8));
+        else *reinterpret_cast<sk_u4*>(out + (size_t)m * p.d + c0 + c8 * 8) = w;
+      }
+    }
+  } else {
+    float* const out = static_cast<float*>(p.dC);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int e = tid + it * SK_THREADS, mrow = e >> 5, cq = e & 31;
+      const int m = n0 + mrow;
+      if (mrow < nvalid && c0 + cq * 4 < p.d) {
+        float4 v = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + cq * 4);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+        if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)m * p.d + c0 + cq * 4));
+        else *reinterpret_cast<float4*>(out + (size_t)m * p.d + c0 + cq * 4) = v;
       }
     }
   }
@@ -1289,15 +1295,85 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   }
 }
 
+// Finishing launch of the fused plan: dQ = scale * ( sum_s exp(m_is - lse_i) * slab_s  +  g_i * C[y_i] ), slabs in slice order
+// (bit-reproducible).  One workgroup per (row, 128 float4 of the row): the row's logsumexp from its nt tile values (every wave
+// derives it: 2 KB, no barrier), the slices' references m_is from the same values -- exactly the maxima the dQ units used -- and the
+// gold row of C.  The slab loads are in flight before any of that is consumed.
+struct SkFinArgs {
+  const float* part;      // [nslices][B][d] slice-normalised slabs (sk_dq_unit_f)
+  int nslices, ksteps, nk;
+  int B, d;
+  const float* tile_lse;
+  int nt;
+  const float* gold;
+  const int64_t* y;
+  int64_t y_offset;
+  const uint16_t* C;      // [Nc][d]
+  float grad_scale, h_scale;
+  const float* d_scale;
+  float* dQ;
+  int parts;              // workgroups per row
+};
+
+__global__ __launch_bounds__(128) void sk_dq_finish_kernel(SkFinArgs p) {
+  __shared__ float s_e[64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int row = blockIdx.x / p.parts, part = blockIdx.x - row * p.parts;
+  const int nq = p.d >> 2, q4 = part * 128 + tid;
+  const bool ok = q4 < nq;
+  const size_t slab4 = (size_t)p.B * nq, o4 = (size_t)row * nq + (ok ? q4 : 0);
+  const float4* const part4 = reinterpret_cast<const float4*>(p.part);
+  constexpr int CH = 16;
+  float4 v[CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u) v[u] = part4[(size_t)min(u, p.nslices - 1) * slab4 + o4];
+  const int yg = reinterpret_cast<const int*>(p.y)[2 * row] + (int)p.y_offset;
+  const uint2 cg = *reinterpret_cast<const uint2*>(p.C + (size_t)yg * p.d + (ok ? q4 : 0) * 4);
+  const float gl = p.gold[row];
+  const float lse = sk_row_lse(p.tile_lse, p.nt, p.B, row, lane);
+  if (tid < p.nslices) {
+    const int s0 = tid * p.ksteps, ns = min(p.ksteps, p.nk - s0);
+    float m = -INFINITY;
+    if (ns > 0) {
+      const int tlo = s0 >> 1, thi = min((s0 + ns - 1) >> 1, p.nt - 1);
+      for (int t = tlo; t <= thi; ++t) m = fmaxf(m, p.tile_lse[((size_t)(t >> 2) * p.B + row) * 4 + (t & 3)]);
+    }
+    s_e[tid] = m == -INFINITY ? 0.f : __expf(m - lse) * p.grad_scale;
+  }
+  __syncthreads();
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int base = 0; base < p.nslices; base += CH) {
+    if (base > 0) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) v[u] = part4[(size_t)min(base + u, p.nslices - 1) * slab4 + o4];
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const float e = base + u < p.nslices ? s_e[base + u] : 0.f;
+      a.x = fmaf(e, v[u].x, a.x); a.y = fmaf(e, v[u].y, a.y); a.z = fmaf(e, v[u].z, a.z); a.w = fmaf(e, v[u].w, a.w);
+    }
+  }
+  if (ok) {
+    const float g = (__expf(gl - lse) - 1.0f) * p.grad_scale;
+    const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
+    a.x = fmaf(g, sk_bf_lo(cg.x), a.x) * sc;
+    a.y = fmaf(g, sk_bf_hi(cg.x), a.y) * sc;
+    a.z = fmaf(g, sk_bf_lo(cg.y), a.z) * sc;
+    a.w = fmaf(g, sk_bf_hi(cg.y), a.w) * sc;
+    reinterpret_cast<float4*>(p.dQ)[(size_t)row * nq + q4] = a;
+  }
+}
+
 template <int NG>
 __global__ __launch_bounds__(SK_THREADS, 2) void sk_bwdf_kernel(SkBwdFArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
   const int b = blockIdx.x;
   const int ndq = p.nslices * (p.d / SK_QN);
   if (b < p.ndq_pad) {
-    if (b >= ndq) return;  // padding
+    if (b >= ndq || (p.dbg & 2)) return;  // padding
     sk_dq_unit_f<NG>(p, sk_xcd_order(b, ndq), sk_smem);
   } else {
+    if (p.dbg & 1) return;
     sk_dc_unit_f<NG>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
   }
 }

@@ -10,6 +10,7 @@ __device__ unsigned long long g_dprhot_tmb[4 * 4096 * 8];
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 128, K = argc > 2 ? atoi(argv[2]) : 8, d = argc > 3 ? atoi(argv[3]) : 768, W = 8;
+  const bool no_g = argc > 4 && atoi(argv[4]) != 0;  // 1: G == NULL -- the plan without the dScores launch (round 4)
   const int n_ctx = B * K;
   int rows_c; dprhot_packed_rows(n_ctx, d, &rows_c);
   const int Nc = W * rows_c;
@@ -35,7 +36,7 @@ int main(int argc, char** argv) {
     hipMemsetAsync(nullptr, 0, 0, nullptr);
     unsigned long long* dptr; CK(hipGetSymbolAddress((void**)&dptr, HIP_SYMBOL(g_dprhot_tmb)));
     CK(hipMemset(dptr, 0, t.size() * 8));
-    int rc = dprhot_inbatch_step_packed_f32(q, Cb, Qb, B, W, 3, n_ctx, d, y, 1.f, 1.f / (W * B), 1.f, go, loss, lse, sum, G, dq, dc, ws, wsb, nullptr);
+    int rc = dprhot_inbatch_step_packed_f32(q, Cb, Qb, B, W, 3, n_ctx, d, y, 1.f, 1.f / (W * B), 1.f, go, loss, lse, sum, no_g ? nullptr : G, dq, dc, ws, wsb, nullptr);
     if (rc) { printf("rc=%d %s\n", rc, dprhot_last_error()); return 1; }
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(t.data(), dptr, t.size() * 8, hipMemcpyDeviceToHost));

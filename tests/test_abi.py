@@ -79,7 +79,17 @@ def test_argument_validation_is_host_side():
                                             null, null, 2, null, 0, null) == -1
     assert lib.dprhot_rescale_grads(null, 8, null, 0, null, 0, 2, null, null, null, null) == -1
     n = ctypes.c_int(-1)
-    assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and 1 <= n.value <= 64  # cfg3 per rank: split-K slabs
+    # cfg3 per rank: the step can run without the dScores (round 4) and then finishes dQ itself -- nothing deferred, G optional; with
+    # that plan switched off it is the split-K slabs of round 3 again
+    w = ctypes.c_int(-1)
+    assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and n.value == 0
+    assert lib.dprhot_step_wants_g(128, 8256, 768, ctypes.byref(w)) == 0 and w.value == 0
+    assert lib.dprhot_set_option(b"sk_fused", 0) == 0
+    assert lib.dprhot_train_dq_slabs(128, 8256, 768, ctypes.byref(n)) == 0 and 1 <= n.value <= 64
+    assert lib.dprhot_step_wants_g(128, 8256, 768, ctypes.byref(w)) == 0 and w.value == 1
+    assert lib.dprhot_set_option(b"sk_fused", 1) == 0
+    assert lib.dprhot_step_wants_g(32, 256, 768, ctypes.byref(w)) == 0 and w.value == 1             # cfg2: G is written by the fused small step
+    assert lib.dprhot_step_wants_g(128, 1032, 768, ctypes.byref(w)) == 0 and w.value == 1           # narrow sim units: the four-launch plan
     assert lib.dprhot_train_dq_slabs(32, 256, 768, ctypes.byref(n)) == 0 and n.value == 0          # cfg2: dQ comes out whole
     # the few-rows plan's measured boundaries ("Mid-size steps"), seen through the slab count: split-K slabs where
     # the plan applies with more than 512 contexts, none where its dQ units are unsplit or another plan has the shape

@@ -436,10 +436,11 @@ def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
             go2 = torch.full((1,), 2.0, device=dev)
             _, _, _, _, dq_def, dcp2 = kn.train_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), inv_T,
                                                                 inv_T / (W * B), 1.0 / (W * B), d_scale, dt, defer_dq=True)
-            assert isinstance(dq_def, tuple) and dq_def[1].shape[0] == kn._lib.train_dq_slabs(B, W * rows_c, d) >= 1
+            nsl = kn._lib.train_dq_slabs(B, W * rows_c, d)  # 0 where the step finishes dQ itself (the plan without a dScores launch)
+            assert (isinstance(dq_def, tuple) and dq_def[1].shape[0] == nsl) if nsl else not isinstance(dq_def, tuple)
             out2 = kn.rescale_grads(dq_def, dcp2, go2, d_scale)
             assert out2.tolist() == [2.0, 2.0]
-            assert rel(dq_def[0].cpu().numpy() / 2.0, dq_own) <= 1e-5
+            assert rel((dq_def[0] if nsl else dq_def).cpu().numpy() / 2.0, dq_own) <= 1e-5
             assert rel(dcp2.float().cpu().numpy() / 2.0, dcp.float().cpu().numpy() / go) <= (1e-6 if wire == "fp32" else 8e-3)
     assert abs(loss - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
     assert rel(dq_own, g["dq_own"]) <= GRAD_RTOL
