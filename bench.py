@@ -768,7 +768,10 @@ def main():
             wd0.daemon = True
             wd0.start()
             from dpr_scale_amd import dist as D
-            comm = D.enable_direct_comm(dev)  # collective: all ranks get one, or all stay on torch.distributed (what the task calls)
+            # (opt-in in the product since round 4 -- DPRHOT_DIRECT_RCCL=1 -- because next to DDP's own communicator it is untested on
+            #  more than one GPU; this loop has no second communicator in flight and keeps its own watchdog above)
+            os.environ["DPRHOT_DIRECT_RCCL"] = "1"
+            comm = D.enable_direct_comm(dev)  # collective: all ranks get one, or all stay on torch.distributed
             if comm is not None:
                 hp = HotPathStep(B, K, d, T, W, rank, dev, comm=comm, dist_mode=DM)
                 els = measure(hp.step)

@@ -44,6 +44,13 @@ def world(group=None):
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def force_dist():
+    """DPRHOT_FORCE_DIST=1 with an initialised process group: the multi-rank code path (packed layout, ONE all-gather started under the
+    query tower, reduce-scatter under the query-tower backward) also at world size 1 -- the way to put the collectives and their
+    overlap on a timeline on a one-GPU box (scripts/overlap_trace.py).  Never set in production."""
+    return os.environ.get("DPRHOT_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def _is_nccl(group):
     return dist.get_backend(group) == "nccl"
 
@@ -68,12 +75,49 @@ def enable_direct_comm(device, group=None):
     on the path's all-gather, reduce-scatter and loss all-reduce are issued through the C ABI communicator -- synchronous ones on the
     caller's stream (no hand-over to RCCL's stream and back), asynchronous ones on one side HIP stream with an event either way.
     Returns the communicator, or None when any rank could not build it (every rank then keeps torch.distributed).
-    DPRHOT_DIRECT_RCCL=0 skips it."""
+
+    OPT-IN: DPRHOT_DIRECT_RCCL=1.  A second RCCL communicator whose kernels run next to torch.distributed's (DDP's bucket all-reduces
+    on its own stream) has only ever run on one physical GPU here; two communicators whose kernels reach the device in a different
+    order on different ranks is a known deadlock pattern, so it stays off until it has run on a multi-GPU box.
+    The set-up runs under a watchdog (DPRHOT_DIRECT_TIMEOUT_S, default 60 s): a communicator that does not come up in time on this
+    rank is abandoned -- the set-up is collective, so it then times out on every rank alike, and every rank keeps torch.distributed."""
     k = _gkey(group)
     if k not in _DIRECT:
-        off = os.environ.get("DPRHOT_DIRECT_RCCL", "1") == "0"
-        _DIRECT[k] = (None if off else try_direct_comm(device, group)) or False
+        on = os.environ.get("DPRHOT_DIRECT_RCCL", "0") == "1"
+        _DIRECT[k] = (_with_watchdog(lambda alive: try_direct_comm(device, group, alive),
+                                     float(os.environ.get("DPRHOT_DIRECT_TIMEOUT_S", "60"))) if on else None) or False
     return direct_comm(group)
+
+
+def _with_watchdog(fn, timeout_s):
+    """fn(alive) on a helper thread; None if it has not returned after timeout_s.  `alive()` turns False at the timeout: a set-up that
+    comes back late sees it before its next collective stage, releases what it built and stops (it never touches torch.distributed
+    again, so it cannot get between the caller's collectives)."""
+    import threading
+
+    state = {"alive": True, "out": None}
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def run():
+        try:
+            if dev is not None:
+                torch.cuda.set_device(dev)
+            out = fn(lambda: state["alive"])
+            if state["alive"]:
+                state["out"] = out
+            elif out is not None:
+                out.close()
+        except Exception:
+            state["out"] = None
+
+    t = threading.Thread(target=run, name="dprhot-direct-comm-setup", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        state["alive"] = False
+        print(f"dpr_scale_amd.dist: the direct RCCL communicator did not come up within {timeout_s:.0f} s; keeping torch.distributed", flush=True)
+        return None
+    return state["out"]
 
 
 def disable_direct_comm(group=None):
@@ -229,18 +273,22 @@ class DirectComm:
             self.h = None
 
 
-def try_direct_comm(device, group=None):
+def try_direct_comm(device, group=None, alive=None):
     """COLLECTIVE over `group` (an initialised nccl group): every rank gets a DirectComm, or every rank gets None.
     Each stage is agreed on through torch.distributed before the next collective stage starts, and the new
-    communicator has to reproduce torch.distributed's all-gather and reduce-scatter on test data before it is used."""
+    communicator has to reproduce torch.distributed's all-gather and reduce-scatter on test data before it is used.
+    `alive` (enable_direct_comm's watchdog): once it returns False no further collective is issued from here."""
     W, r = world(group)
     if not (dist.is_available() and dist.is_initialized()) or not _is_nccl(group):
         return None
+    alive = alive or (lambda: True)
 
     def all_ok(flag):
+        if not alive():
+            return False
         t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        return bool(t.item())
+        return bool(t.item()) and alive()
 
     try:
         uid = DirectComm.new_unique_id()  # every rank probes the library; only rank 0's id is used

@@ -28,15 +28,19 @@ class _ExpectedGradScale:
     _cur = {}
 
     @classmethod
-    def get(cls, dev):
-        t = cls._cur.get(dev)
+    def get(cls, dev, site=None):
+        """`site`: what tells the operator's call sites of one model apart -- the step's shape (B, Nc, d).  CITADEL's router loss and the
+        main loss receive different constant upstream factors in the same step; one shared prediction made each of them mispredict
+        the other every step (and pay the full rescale pass)."""
+        k = (dev, site)
+        t = cls._cur.get(k)
         if t is None:
-            t = cls._cur[dev] = torch.ones(1, dtype=torch.float32, device=dev)
+            t = cls._cur[k] = torch.ones(1, dtype=torch.float32, device=dev)
         return t
 
     @classmethod
-    def publish(cls, dev, t):
-        cls._cur[dev] = t
+    def publish(cls, dev, t, site=None):
+        cls._cur[(dev, site)] = t
 
 
 def _fp32_g_mode():
@@ -449,6 +453,25 @@ class HipKernels:
 _DEFAULT = None
 
 
+def _load_opx():
+    """csrc/opx.cpp, built next to libdprhot.so by `make -C dpr_scale_amd/csrc` / __graft_entry__.build(); DPRHOT_OPX=0 keeps the
+    Python host path (A/B).  Optional: without it the operator is the same operator, ~150 us per step slower on the host."""
+    if os.environ.get("DPRHOT_OPX", "1") == "0":
+        return None
+    try:
+        from . import _lib, _opx
+    except ImportError:
+        return None
+    _opx.init(_lib.LIB_PATH)
+    return _opx
+
+
+try:
+    _OPX = _load_opx()
+except Exception:  # pragma: no cover - a broken optional extension must not take the operator down
+    _OPX = None
+
+
 def default_kernels():
     global _DEFAULT
     if _DEFAULT is None:
@@ -476,7 +499,7 @@ class ContextGather:
     def __init__(self, c, ctx_mask, group=None, kernels=None):
         kn = kernels if kernels is not None else default_kernels()
         W, r = D.world(group)
-        assert W > 1, "ContextGather is for world size > 1"
+        assert W > 1 or D.force_dist(), "ContextGather is for world size > 1"
         n_ctx, d = c.shape
         m8 = ctx_mask.view(torch.uint8) if ctx_mask.dtype == torch.bool else ctx_mask.to(torch.uint8)
         self.rows_c = kn.packed_rows(n_ctx, d)
@@ -540,6 +563,25 @@ class InBatchContrastive(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, c, pos_idx, ctx_mask, temperature, group, kernels, gather=None, pending=None):
+        ctx.fast = None
+        if _OPX is not None and kernels is None and gather is None and q.is_cuda and c.is_cuda and (group is False or D.world(group)[0] == 1):
+            # The step a single-GPU run issues every iteration (dpr_task.py:197-212): host side in C++ (csrc/opx.cpp).  Taken when
+            # nothing needs the general code below: fp32 contiguous encoder outputs, a whole number of 8-column groups, a byte mask.
+            n_ctx, d = c.shape
+            if (q.dtype == torch.float32 and c.dtype == torch.float32 and q.is_contiguous() and c.is_contiguous() and n_ctx % 8 == 0 and d % 8 == 0
+                    and q.shape[1] == d and ctx_mask.is_contiguous() and ctx_mask.element_size() == 1 and pos_idx.dtype == torch.int64
+                    and pos_idx.is_contiguous() and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and not _fp32_g_mode()
+                    and not (D.force_dist() and group is not False)):
+                B = q.shape[0]
+                inv_T = 1.0 / float(temperature)
+                site = (B, n_ctx, d)
+                used = _ExpectedGradScale.get(q.device, site)
+                loss_out, row_lse, dQ, dC, Qb, Cb, G, part = _OPX.train_step(q, c, pos_idx, ctx_mask, inv_T, inv_T / B, 1.0 / B, used,
+                                                                             default_kernels()._lib.options_epoch())
+                ctx.fast = (dQ, dC, part, used, site)
+                ctx.regen = (Qb, Cb, G, pos_idx, ctx_mask, inv_T, inv_T / B)
+                ctx.row_lse = row_lse
+                return loss_out[0]
         kn = kernels if kernels is not None else default_kernels()
         W, r = (1, 0) if group is False else D.world(group)  # group=False: single-device strategy, never gather
         B, d = q.shape
@@ -553,7 +595,8 @@ class InBatchContrastive(torch.autograd.Function):
         Qb = kn.empty((B, d), _BF16, q)
 
         wants_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        if W == 1:
+        multi = W > 1 or (group is not False and D.force_dist())  # (forced: the multi-rank code path on a one-rank world, for timelines)
+        if not multi:
             # columns = this rank's contexts (padded to a multiple of 8 with masked zero rows)
             rows_c = _pad_cols(n_ctx)
             Nc = rows_c
@@ -600,16 +643,16 @@ class InBatchContrastive(torch.autograd.Function):
         used = None
         S_dbg = None
         loss_is_mean = False  # the kernel already multiplied the numerator by 1 / Nq
-        dc_dtype = _dc_wire_dtype() if W > 1 else torch.float32
-        if W == 1 and _fp32_g_mode() and wants_grad:
+        dc_dtype = _dc_wire_dtype() if multi else torch.float32
+        if not multi and _fp32_g_mode() and wants_grad:
             if q_f32:
                 row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
                                                                            inv_T, grad_scale, want_logits=True)
             else:
                 row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale, want_logits=True)
-        elif W > 1 and packed_step and hasattr(kn, "train_step_packed_f32"):
+        elif multi and packed_step and hasattr(kn, "train_step_packed_f32"):
             # forward and backward of this rank's rows in ONE library call; gradients scaled by the grad_output the last backward saw
-            used = _ExpectedGradScale.get(q.device)
+            used = _ExpectedGradScale.get(q.device, (B, Nc, d))
             try:
                 row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
                                                                                        1.0 / Nq, used, dc_dtype, defer_dq=True, want_G="auto")
@@ -620,13 +663,13 @@ class InBatchContrastive(torch.autograd.Function):
                                                                                        1.0 / Nq, used, torch.float32, defer_dq=True,
                                                                                        want_G="auto")
             eager, loss_is_mean = (dQ, dC_part), True
-        elif W > 1 and packed_step:  # (stand-in kernels of the CPU tests)
+        elif multi and packed_step:  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale)
             eager = (dQ, dC_part)
         elif q_f32 and wants_grad and hasattr(kn, "train_step_f32"):
             # a backward will follow: forward and backward in ONE library call (two launches at the BASELINE shapes);
             # backward() only checks the grad_output it was given against the one the gradients were scaled by
-            used = _ExpectedGradScale.get(q.device)
+            used = _ExpectedGradScale.get(q.device, (B, Nc, d))
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
                                                                             inv_T, grad_scale, 1.0 / Nq, used, defer_dq=True, want_G="auto")
             eager, loss_is_mean = (dQ, dC_part), True
@@ -640,18 +683,21 @@ class InBatchContrastive(torch.autograd.Function):
         else:
             row_loss, row_lse, loss_sum, G, _ = kn.inbatch_fwd(Qb, Cb, pos_idx, y_off, colmask, inv_T, grad_scale)
         loss_sum = loss_sum[:1]
-        if W > 1:
+        if multi:
             D.all_reduce_sum(loss_sum, group)  # (of the means when loss_is_mean: the sum over ranks is the global mean)
         loss = (loss_sum if loss_is_mean else loss_sum / Nq).reshape(())
 
         ctx.kn, ctx.group = kn, group
         ctx.dims = (W, r, B, d, n_ctx, rows_c)
+        ctx.site = (B, Nc, d)
+        ctx.multi = multi
+        ctx.direct_ctx_grad = gather is not None  # c came straight from defer_context_grad (the task's own flow)
         ctx.in_dtypes = (q.dtype, c.dtype)
         ctx.eager, ctx.used = eager, used
         ctx.spare = (Qb, Cb, G) if (eager is not None and used is not None) else None
         # (G is None where the step never materialised the dScores: a second backward through a retained graph recomputes them)
-        ctx.regen = (pos_idx, y_off, None if (W > 1 and packed_step) else colmask, inv_T, grad_scale) if ctx.spare is not None and G is None else None
-        ctx.pending = pending if W > 1 else None
+        ctx.regen = (pos_idx, y_off, None if (multi and packed_step) else colmask, inv_T, grad_scale) if ctx.spare is not None and G is None else None
+        ctx.pending = pending if multi else None
         if eager is None:
             ctx.save_for_backward(Qb, Cb, G)
         ctx.row_lse = row_lse
@@ -660,6 +706,25 @@ class InBatchContrastive(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.fast is not None or getattr(ctx, "fast_done", False):
+            need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+            go = grad_out if (grad_out.dtype == torch.float32 and grad_out.is_contiguous()) else grad_out.detach().float().contiguous()
+            if ctx.fast is not None:
+                # computed in forward for grad_output = *used: ONE launch compares and only rescales when the scale really changed; the
+                # tensors are handed to autograd and forgotten (see the general path below)
+                dQ, dC, part, used, site = ctx.fast
+                ctx.fast, ctx.fast_done = None, True
+                _, nxt = _OPX.rescale(dQ, part, dC, go, used, need_dq, need_dc)
+                _ExpectedGradScale.publish(go.device, nxt, site)
+            else:
+                # a second backward through a retained graph: the backward GEMMs run again on the operands the step left behind
+                kn = default_kernels()
+                Qb, Cb, G, pos_idx, mask, inv_T, grad_scale = ctx.regen
+                if G is None:
+                    G = kn.inbatch_fwd(Qb, Cb, pos_idx, 0, mask.view(torch.uint8) if mask.dtype == torch.bool else mask, inv_T, grad_scale)[3]
+                    ctx.regen = (Qb, Cb, G, pos_idx, mask, inv_T, grad_scale)
+                dQ, dC = kn.inbatch_bwd(G, Qb, Cb, 1.0, go.reshape(1), need_dq, need_dc)
+            return (dQ if need_dq else None), (dC if need_dc else None), None, None, None, None, None, None, None
         kn, group = ctx.kn, ctx.group
         W, r, B, d, n_ctx, rows_c = ctx.dims
         need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -674,7 +739,7 @@ class InBatchContrastive(torch.autograd.Function):
             if isinstance(dQ, tuple):
                 dQ = dQ[0]  # (the slabs have been added up into it)
             ctx.used = None
-            _ExpectedGradScale.publish(go.device, out2[1:2])
+            _ExpectedGradScale.publish(go.device, out2[1:2], ctx.site)
             go = None
         elif ctx.spare is not None:
             # a second backward through a retained graph: the first one gave its gradient tensors away; the backward GEMMs run
@@ -713,7 +778,7 @@ class InBatchContrastive(torch.autograd.Function):
         if need_dq:
             dq = (dQ if go is None else dQ * go).to(ctx.in_dtypes[0])
         if need_dc:
-            if W == 1:
+            if not ctx.multi:
                 dc = dC_part[:n_ctx]
                 dc = (dc if go is None else dc * go).to(ctx.in_dtypes[1])
             else:
@@ -724,13 +789,24 @@ class InBatchContrastive(torch.autograd.Function):
                 if dC_part.dtype != wire:
                     dC_part = dC_part.to(wire)  # half the bytes on the links (and in RCCL's reduction)
                 widen = wire != ctx.in_dtypes[1] and ctx.in_dtypes[1] == torch.float32 and hasattr(kn, "widen")
-                if ctx.pending is not None and (wire == ctx.in_dtypes[1] or widen):
+                if ctx.pending is not None and ctx.direct_ctx_grad and (wire == ctx.in_dtypes[1] or widen):
                     # reduce-scatter on RCCL's stream; whoever consumes dc (defer_context_grad, after the query-tower backward has
-                    # been enqueued) waits for it -- and, on a half-width wire, widens the result into the fp32 gradient there
+                    # been enqueued) waits for it -- and, on a half-width wire, widens the result into the fp32 gradient there.
+                    # Only in the task's own flow (c IS the output of defer_context_grad: `gather` given), where autograd hands this
+                    # very tensor to that node.  Should anything still sit in between (another consumer of c, a hook), the tensor that
+                    # arrives there is a different one: the half-width wire therefore returns ZEROS here (whatever autograd adds to
+                    # them stays right) and post() adds the widened rows to whatever arrives instead of overwriting it.
                     ctx.pending.work = D.reduce_scatter_rows(dC_part, mine, group, async_op=True)
                     if widen:
-                        dc = kn.empty((n_ctx, d), torch.float32, mine)  # filled by pending.post, after the wait
-                        ctx.pending.post = lambda g, kn=kn, mine=mine: kn.widen(mine, g)
+                        dc = torch.zeros((n_ctx, d), dtype=torch.float32, device=mine.device)  # filled by pending.post, after the wait
+
+                        def post(g, kn=kn, mine=mine, dc=dc):
+                            if g.data_ptr() == dc.data_ptr() and g.shape == dc.shape and g.is_contiguous():
+                                kn.widen(mine, g)
+                            else:
+                                g.add_(kn.widen(mine, torch.empty_like(dc)).to(g.dtype))
+
+                        ctx.pending.post = post
                     else:
                         dc = mine[:n_ctx]
                 else:

@@ -126,9 +126,9 @@ class DenseRetrieverTask(LightningModule):
         ring).  The wire format is the reference's fp16 by default (same flag, same numbers on the wire; the sum itself
         is fp32 here); DPRHOT_GRAD_WIRE=bf16 trades mantissa for fp32's exponent range, DPRHOT_GRAD_MODE=ring selects the
         reference's decomposition."""
-        if self._is_distributed() and hotpath.D.world(None)[0] > 1:
-            # the path's three collectives through the C ABI communicator (collective set-up with a self-check against
-            # torch.distributed; every rank keeps torch.distributed if any rank cannot build it)
+        if self._is_distributed() and (hotpath.D.world(None)[0] > 1 or hotpath.D.force_dist()):
+            # opt-in (DPRHOT_DIRECT_RCCL=1): the path's three collectives through the C ABI communicator (collective set-up under a
+            # watchdog, with a self-check against torch.distributed; every rank keeps torch.distributed if any rank cannot build it)
             try:
                 dev = next(self.parameters()).device
             except StopIteration:
@@ -206,7 +206,7 @@ class DenseRetrieverTask(LightningModule):
     def training_step(self, batch, batch_idx):
         pos, mask = batch["pos_ctx_indices"], batch["ctx_mask"]
         T = self.softmax_temperature
-        if (self.in_batch_negatives and self._is_distributed() and hotpath.D.world(None)[0] > 1
+        if (self.in_batch_negatives and self._is_distributed() and (hotpath.D.world(None)[0] > 1 or hotpath.D.force_dist())
                 and type(self).forward is DenseRetrieverTask.forward and self.context_tower_first):
             # Multi-GPU (reference :163-195).  Context tower FIRST: its rows go into the one all-gather, which then
             # runs on RCCL's stream underneath the query tower; in backward the reduce-scatter of dC overlaps the

@@ -37,7 +37,12 @@ def test_direct_comm_one_rank_group_agrees_with_torch_distributed():
         # the communicator -- synchronously on the caller's stream, or on the side stream behind an event (async_op=True), for
         # both wire formats of the backward
         assert D.direct_comm() is None
-        assert D.enable_direct_comm(dev) is not None and D.direct_comm() is not None
+        # opt-in: without DPRHOT_DIRECT_RCCL=1 the task's call is a no-op and the path stays on torch.distributed
+        os.environ.pop("DPRHOT_DIRECT_RCCL", None)
+        assert D.enable_direct_comm(dev) is None and D.direct_comm() is None
+        D.disable_direct_comm()
+        os.environ["DPRHOT_DIRECT_RCCL"] = "1"
+        assert D.enable_direct_comm(dev) is not None and D.direct_comm() is not None  # (set-up on the watchdog's helper thread)
         for dt in (torch.float32, torch.bfloat16):
             part = torch.randn(264, 768, device=dev).to(dt)
             mine = torch.full_like(part, 7.0)
