@@ -52,11 +52,13 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--driver", choices=["auto", "graph", "graph10", "eager"], default="eager",
-                    help="issue mechanism behind `value`: eager (default) = one C-ABI call per step, what a binding and the Lightning "
-                         "task do; graph / graph10 = HIP graphs of 1 / 10 steps; auto = the fastest of the three.  The mechanisms not "
-                         "chosen are measured too and reported in other_driver")
-    ap.add_argument("--only", default="", help="comma list of the extra blocks to run (default: all): operator, torch_gpu, scale, rank, "
-                                               "router, grad_hook, cpu, e2e; `step` = none of them (the contract line alone)")
+                    help="issue mechanism behind `value`: eager (default) = one C-ABI call per step from a prepared argument block, what a C / "
+                         "C++ binding of include/dprhot.h pays (the Python autograd operator pays more on the host: `operator` block); "
+                         "graph / graph10 = HIP graphs of 1 / 10 steps; auto = the fastest of the three.  The mechanisms not chosen are "
+                         "measured too and reported in other_driver")
+    ap.add_argument("--only", default="", help="comma list of the extra blocks to run (default: all but e2e5): operator, torch_gpu, scale, rank, "
+                                               "router, grad_hook, cpu, e2e, model (scaling_model), e2e5 (BASELINE configs[4]: bert-large "
+                                               "towers, seq 512, B 64 -- minutes); `step` = none of them (the contract line alone)")
     ap.add_argument("--no-scale-roofline", action="store_true", help="skip the extra 8192x8192 per-kernel roofline block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=31, help="timed regions of --steps steps each; the median is reported")
@@ -64,7 +66,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the short end-to-end (bert-base towers) block")
     ap.add_argument("--no-rank-roofline", action="store_true", help="skip the cfg3-per-rank (128 x 8256 x 768) block")
     a = ap.parse_args()
-    blocks = {"operator", "torch_gpu", "scale", "rank", "router", "grad_hook", "cpu", "e2e"}
+    blocks = {"operator", "torch_gpu", "scale", "rank", "router", "grad_hook", "cpu", "e2e", "model", "e2e5"}
     if a.only:
         want = {x.strip() for x in a.only.split(",") if x.strip()}
         unknown = want - blocks - {"step"}
@@ -72,7 +74,7 @@ def parse():
             ap.error(f"--only: unknown block(s) {sorted(unknown)}")
         a.blocks = want & blocks
     else:
-        a.blocks = set(blocks)
+        a.blocks = set(blocks) - {"e2e5"}
     for flag, names in (("no_scale_roofline", ("scale",)), ("no_cpu_baseline", ("cpu",)), ("no_e2e", ("e2e",)),
                         ("no_rank_roofline", ("rank", "router"))):
         if getattr(a, flag):
@@ -325,7 +327,10 @@ def cpu_baseline_reference(B, K, d, T, budget_s=6.0):
     return {"value": B / med, "unit": "query-passage pairs/s", "cores": nth, "kind": "reference-ops",
             "formulation": "the reference's own ops in its own library (torch CPU, fp32), dpr_task.py:197-212 line by line: mask.repeat, "
                            "matmul, masked fill, /T, CrossEntropyLoss, autograd backward (oracle/torch_steps.py, pinned to the reference's "
-                           "fixtures bit for bit; /root/reference itself does not exist on the GPU box)",
+                           "fixtures bit for bit; /root/reference itself does not exist on the GPU box).  SURVEY.md section 6 probed 1.78 ms "
+                           "per step for the reference CLASS at this shape: training_step there also builds the [Nq, Nc] mask with a Python "
+                           "loop, splices and concatenates the gathered lists and logs -- host bookkeeping around the same ops; this leg "
+                           "times the ops alone (the part the hot path replaces), so it is the faster, stricter baseline",
             "sample": f"median of {n} steps of the same B={B} K={K} d={d} workload ({med * 1e3:.3f} ms/step, torch {torch.__version__}, "
                       f"{nth} threads)"}
 
@@ -588,6 +593,94 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
         out["traffic_over_algorithmic"] = None if not out["traffic"] else round(out["traffic"] / algo, 3)
     del hp
     torch.cuda.empty_cache()
+    return out
+
+
+XGMI_LINK_GBS = 153.0   # per direction and link, 7 links per GPU (MI355X_MICROARCH.md / BASELINE.md)
+XGMI_LAT_US = 5.0       # assumed small-message latency of one RCCL hop (UNMEASURED here: one-GPU boxes)
+
+
+def scaling_model(dev, d=768, B=128, K=8):
+    """A MODEL, not a measurement (hard part 2; section 8 e): what BASELINE configs[2] -- batch 128 per GPU, K = 8,
+    RCCL all-gather of the context rows -- does to the hot path at 2 / 4 / 8 GPUs, built from (a) the per-rank step MEASURED on this GPU
+    at the column count N ranks produce, (b) the host cost of the path's collectives MEASURED on a one-rank RCCL world (the same
+    bench.py with DPRHOT_FORCE_DIST=1 in a child process), (c) the xGMI message model 7 links x 153 GB/s per direction for a ring
+    and for the all-pairs exchange.  Every entry says "modelled": true.  What it warns about: the hot-path-only line DROPS per GPU
+    beyond one GPU -- every rank scores its 128 rows against N x 1032 columns (10 -> 29 us) and pays two collectives -- while the
+    end-to-end step, two bert-base towers of >100 ms, hides both under the towers."""
+    import subprocess
+
+    from dpr_scale_amd import _lib
+    out = {"modelled": True, "what": "hot path only (no towers), batch 128 per GPU, K = 8, d = 768: per-rank step measured on ONE MI355X, collectives modelled",
+           "link_model": f"{XGMI_LINK_GBS} GB/s per direction per xGMI link, 7 links per GPU, {XGMI_LAT_US} us per hop (assumed); ring = N - 1 sequential hops "
+                         "over one link, all-pairs = N - 1 links at once (dist.py DPRHOT_PATH_COLLECTIVES=allpairs)"}
+    host = None
+    try:
+        env = dict(os.environ, DPRHOT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29771")
+        base = [sys.executable, os.path.abspath(__file__), "--only", "step", "--steps", "100", "--repeats", "5", "--batch", str(B), "--negatives", str(K - 1)]
+        forced = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1])
+        env.pop("DPRHOT_FORCE_DIST")
+        plain = json.loads(subprocess.run(base, env=env, capture_output=True, text=True, timeout=240).stdout.strip().splitlines()[-1])
+        host = {"one_rank_world_step_us": round(forced["ms_per_step"] * 1e3, 2), "single_process_step_us": round(plain["ms_per_step"] * 1e3, 2),
+                "collectives": forced["config"].get("collectives")}
+        host["launch_cost_of_the_collectives_us"] = round(host["one_rank_world_step_us"] - host["single_process_step_us"], 2)
+    except Exception as e:
+        host = {"error": repr(e)}
+    out["measured_one_rank_collectives"] = host
+    coll_host = host.get("launch_cost_of_the_collectives_us", 20.0) if isinstance(host, dict) else 20.0
+    rows = []
+    for N in (1, 2, 4, 8):
+        hp = HotPathStep(B, K, d, 1.0, N, 0, dev, dist_mode=N > 1)
+        if N > 1:
+            hp.k_pack()
+            for r in range(N):
+                hp.Cb[r * hp.rows_c:(r + 1) * hp.rows_c].copy_(hp.send)
+        torch.cuda.synchronize()
+        step_us = time_kernel(hp, hp.k_step, reps=20, iters=10)
+        pack_us = time_kernel(hp, hp.k_pack, reps=20, iters=10) if N > 1 else 0.0
+        msg_ag = hp.rows_c * d * 2.0                 # one rank's packed block, bf16
+        chunk = {"fp32": hp.rows_c * d * 4.0, "bf16": hp.rows_c * d * 2.0}
+        link = XGMI_LINK_GBS * 1e3                   # bytes per us
+        e = {"n_gpus": N, "modelled": N > 1, "global_batch": N * B, "global_negatives_per_query": N * B * K - 1, "per_rank_columns": hp.Nc,
+             "per_rank_step_us_measured": round(step_us, 2), "pack_us_measured": round(pack_us, 2)}
+        if N > 1:
+            ag = {"ring": (N - 1) * (XGMI_LAT_US + msg_ag / link), "allpairs": XGMI_LAT_US + msg_ag / link}
+            rs = {w: {"ring": (N - 1) * (XGMI_LAT_US + chunk[w] / link), "allpairs": XGMI_LAT_US + chunk[w] / link + N * chunk[w] / 5.0e6} for w in chunk}
+            e["all_gather_us"] = {k: round(v, 1) for k, v in ag.items()}
+            e["reduce_scatter_us"] = {w: {k: round(v, 1) for k, v in rs[w].items()} for w in rs}
+            exposed = {f"{kind}_{w}_wire": pack_us + coll_host + ag[kind] + step_us + rs[w][kind] for kind in ("ring", "allpairs") for w in chunk}
+            e["hot_path_step_us_collectives_exposed"] = {k: round(v, 1) for k, v in exposed.items()}
+            e["hot_path_pairs_per_s_collectives_exposed"] = {k: round(N * B / v * 1e6, 0) for k, v in exposed.items()}
+            e["hot_path_pairs_per_s_collectives_hidden_under_the_towers"] = round(N * B / (pack_us + coll_host + step_us) * 1e6, 0)
+        else:
+            e["hot_path_pairs_per_s"] = round(B / step_us * 1e6, 0)
+        rows.append(e)
+        del hp
+        torch.cuda.empty_cache()
+    out["per_n"] = rows
+    one = rows[0]["hot_path_pairs_per_s"]
+    out["per_gpu_relative_to_one_gpu"] = {str(r["n_gpus"]): round(r["hot_path_pairs_per_s_collectives_hidden_under_the_towers"] / r["n_gpus"] / one, 3)
+                                          for r in rows[1:]}
+    out["reading"] = ("the hot-path-only weak-scaling line falls per GPU as N grows (each rank's 128 rows meet N x 1032 columns and two collectives); "
+                      "the training step it sits in is two encoder towers of > 100 ms per step, under which both collectives run (end_to_end / "
+                      "end_to_end_forced_dist, profiles/r04_overlap_*)")
+    return out
+
+
+def hipblaslt_same_box(dev, d=768):
+    """Context for roofline_at_scale, never a target: the library GEMM (torch.matmul, bf16, hipBLASLt / rocBLAS) at the same shapes on the
+    same box -- a bare C = A x B^T with fp32 accumulate and a bf16 result, no mask, no softmax statistics, no epilogue of the path."""
+    out = {}
+    for name, M, N in (("8192x8192", 8192, 8192), ("128x8192", 128, 8192)):
+        A = torch.randn(M, d, device=dev).to(torch.bfloat16)
+        Bm = torch.randn(N, d, device=dev).to(torch.bfloat16)
+        Bt = Bm.t()
+        for _ in range(5):
+            torch.matmul(A, Bt)
+        us = _event_us(lambda: torch.matmul(A, Bt), 50)
+        fl = 2.0 * M * N * d
+        out[name] = {"us": round(us, 2), "tflops": round(fl / us * 1e-6, 1), "frac_of_bf16_peak": round(fl / us * 1e-6 / MFMA_PEAK_TFLOPS, 4),
+                     "what": f"torch.matmul bf16 [{M},{d}] x [{d},{N}] -> bf16 (writes {M * N * 2 / 1e6:.0f} MB)"}
     return out
 
 
@@ -867,6 +960,9 @@ def main():
             extra("grad_hook", lambda: grad_hook_block(dev))
         if not DM and "scale" in a.blocks:
             out["roofline_at_scale"] = roofline_at_scale(dev, d)
+            extra("hipblaslt_same_box", lambda: hipblaslt_same_box(dev, d))
+        if not DM and "model" in a.blocks and d % 128 == 0 and not os.environ.get("DPRHOT_FORCE_DIST"):
+            extra("scaling_model", lambda: scaling_model(dev, d))
         if not DM and "rank" in a.blocks and d % 128 == 0:
             try:
                 out["roofline_cfg3_rank"] = roofline_cfg3_rank(dev, d)
@@ -903,7 +999,29 @@ def main():
         except Exception as e:  # extra info only
             if out is not None:
                 out["end_to_end"] = {"error": repr(e)}
+        if W == 1 and not DM and out is not None:
+            # the same step through DenseRetrieverTask's MULTI-GPU branch on a one-rank RCCL world (scripts/overlap_trace.py in a child
+            # process): packed layout, the all-gather started under the query tower, the reduce-scatter under its backward
+            try:
+                import subprocess
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "overlap_trace.py"), "--B", str(B), "--K", str(K), "--steps", "5"],
+                                   capture_output=True, text=True, timeout=200, env=dict(os.environ, MASTER_PORT="29773"))
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                out["end_to_end_forced_dist"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:
+                out["end_to_end_forced_dist"] = {"error": repr(e)}
         wd.cancel()
+    if "e2e5" in a.blocks and W == 1 and not DM and out is not None:
+        # BASELINE configs[4] on one GPU: bert-large towers (d = 1024), seq 512, B = 64, K = 2 (conf/dragon_aws.yaml:19-35), through the
+        # task's multi-GPU branch on a one-rank world; the hot path inside it is the 64 x 136 step
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "overlap_trace.py"), "--large", "--B", "64", "--K", "2", "--seq", "512",
+                                "--steps", "3", "--warmup", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_PORT="29775"))
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["end_to_end_cfg5"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:
+            out["end_to_end_cfg5"] = {"error": repr(e)}
     # RCCL prints its version banner through C stdio (fully buffered on a pipe: it would surface at process exit, AFTER a
     # line printed from Python).  Every rank pushes its buffers out before the last barrier; rank 0 prints after it, so
     # the JSON line is the last line on the shared stdout.

@@ -57,6 +57,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_sim_rank": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
+    "dprhot_sim_rank_loss": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_sim_stats_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p,
                                      c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_inbatch_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,

@@ -1179,6 +1179,47 @@ int dprhot_sim_rank(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, i
   return DPRHOT_OK;
 }
 
+// compute_rank_metrics AND the cross-entropy of the same scores (dpr_task.py:224-227, :296-299) in one call: at no-logits shapes ONE
+// pass of the similarity GEMM whose epilogue counts and keeps the strip statistics (Epi8CountStats); elsewhere the scores go to the
+// workspace once and both readers stream them.
+int dprhot_sim_rank_loss(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                         const uint8_t* colmask, float inv_T, int64_t* rank, float* row_loss, float* row_lse, float* loss_sum,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(Q && C && y && rank && loss_sum, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  REQUIRE(aligned16(Q) && aligned16(C), "pointers must be 16-byte aligned");
+  const WsLayout wl = ws_layout(B, Nc, d);
+  if (workspace == nullptr || workspace_bytes < wl.total)
+    return fail(DPRHOT_E_WORKSPACE, "sim_rank_loss needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  if (!nl_ok(B, Nc, d)) {
+    if (int rc = dprhot_sim_rank(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, rank, workspace, workspace_bytes, stream)) return rc;
+    return dprhot_inbatch_fwd(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, 1.0f, nullptr, row_loss, row_lse, loss_sum, nullptr, workspace,
+                              workspace_bytes, stream);
+  }
+  float* gold = reinterpret_cast<float*>(ws + wl.gold);
+  int* count = reinterpret_cast<int*>(ws + wl.rloss);  // (the row losses take this place once the ranks have been read out of it)
+  Epi8CountStats epi;
+  static_cast<Epi8Base&>(epi) = g8_base(Q, B, Nc, y, y_offset, colmask, inv_T, nullptr);
+  epi.gold_val = gold;
+  epi.count = count;
+  epi.part_m = reinterpret_cast<float*>(ws + wl.part_m);
+  epi.part_s = reinterpret_cast<float*>(ws + wl.part_s);
+  epi.npart = cdiv(Nc, G2_B) * 4;
+  hipLaunchKernelGGL(g8_gold_kernel, dim3(cdiv(B, 32)), dim3(64), 0, st, Q, C, B, Nc, d, y, y_offset, epi.sim, inv_T, gold);
+  HIP_TRY(hipMemsetAsync(count, 0, (size_t)B * sizeof(int), st));
+  GemmArgs a8{Q, C, B, Nc, d, d, d, d};
+  if (int rc = launch_g8(a8, epi, st)) return rc;
+  hipLaunchKernelGGL(g8_rank_finish_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, count, B, rank);
+  hipLaunchKernelGGL(g8_lse_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart, gold, B,
+                     reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss, reinterpret_cast<float*>(ws + wl.rloss));
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
                        const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss, float* row_lse,
                        float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {

@@ -677,6 +677,93 @@ struct Epi8Count : Epi8Base {
   }
 };
 
+// Validation in ONE pass over the scores (dpr_task.py:224-227 per batch, :296-299 per epoch: compute_rank_metrics AND self.loss on the
+// same score matrix): the count of Epi8Count and the strip statistics of Epi8Stats from the same accumulators -- the Nq x Nc GEMM runs
+// once instead of twice (round 3: 1.80 ms for the two passes at 8192 x 65536 against 1.62 ms through a stored 2 GiB score matrix).  The
+// gold logit both need is gold_val (g8_gold_kernel: bit-identical to this GEMM's element), so neither half looks for it in the tile.
+struct Epi8CountStats : Epi8Base {
+  const float* gold_val;  // [M]
+  int* count;             // [M], zeroed by the caller
+  float* part_m;
+  float* part_s;
+  int npart;
+  __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const {
+    if (e >= 512 && e < 768) return gold_val + min(m0 + e - 512, sim.M - 1);
+    return base_src(m0, n0, e);
+  }
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    meta_fix(t);
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float madd[8][4];
+    col_madd(t, madd);
+    const float s2 = sim.inv_T * kG8Log2e;
+    const f32x2 s2v = {s2, s2};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int lrow = t.wm * 128 + a * 32 + i;
+      const int m = t.m0 + lrow;
+      const float gv = __int_as_float(g8_lds_read(t.meta + 512 + lrow));
+      // ---- rank: exactly Epi8Count's comparisons (the logit as the store would round it)
+      int c = 0;
+      bool tie = false;
+      f32x2 v[8][2];  // log2 units, for the statistics
+      float mx = -INFINITY;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float sv = fmaf(acc.v[a][b][q * 4 + j], sim.inv_T, madd[b * 4 + q][j]);
+            c += sv > gv ? 1 : 0;
+            tie |= sv == gv;
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x2 x = {acc.v[a][b][q * 4 + u * 2], acc.v[a][b][q * 4 + u * 2 + 1]};
+            const f32x2 md = {madd[b * 4 + q][u * 2], madd[b * 4 + q][u * 2 + 1]};
+            v[b * 4 + q][u] = x * s2v + md;
+            mx = fmaxf(mx, fmaxf(v[b * 4 + q][u][0], v[b * 4 + q][u][1]));
+          }
+        }
+      if (__ballot(tie) != 0ull) {
+        const int ycol = g8_lds_read(t.meta + 256 + lrow);
+        const int nbase = t.n0 + t.wn * 64 + h * 4;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float sv = fmaf(acc.v[a][b][q * 4 + j], sim.inv_T, madd[b * 4 + q][j]);
+              c += (sv == gv && nbase + b * 32 + q * 8 + j < ycol) ? 1 : 0;
+            }
+      }
+      c = g8_isum_x32(c);
+      if (h == 0 && m < sim.M && c != 0) atomicAdd(count + m, c);
+      // ---- loss: exactly Epi8Stats' strip statistics
+      mx = g8_max_x32(mx);
+      const float mref = mx == -INFINITY ? 0.f : mx;
+      const f32x2 mr = {mref, mref};
+      f32x2 sm2 = {0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f32x2 dd = v[cc][u] - mr;
+          const f32x2 e = {__builtin_amdgcn_exp2f(dd[0]), __builtin_amdgcn_exp2f(dd[1])};
+          sm2 += e;
+        }
+      const float sm = g8_sum_x32(sm2[0] + sm2[1]);
+      if (h == 0 && m < sim.M) {
+        const size_t at = (size_t)m * npart + t.bx * (t.ncol >> 6) + t.wn;
+        part_m[at] = mx * kG8Ln2;
+        part_s[at] = sm;
+      }
+    }
+  }
+};
+
 // Retrieval epilogue (run_retrieval_pytorch.py:149-150 without the score matrix; EpiFilter of gemm_bf16.h on this kernel): a score
 // only leaves the tile when it ranks ahead of the row's current k-th best (score desc, passage id asc); such scores are appended to
 // the row's candidate list, which the top-k merge kernel folds into the state.  The thresholds arrive with the tile's input words.

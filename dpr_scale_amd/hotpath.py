@@ -424,6 +424,19 @@ class HipKernels:
                                                  _ptr(rank), _ptr(ws), ws.numel(), self._stream()), "dprhot_sim_rank")
         return rank
 
+    def sim_rank_loss(self, Qb, Cb, y, colmask=None, inv_T=1.0, y_offset=0):
+        """(rank [B] int64, loss_sum [1]) of the scores Qb x Cb^T * inv_T -- dprhot_sim_rank_loss: one GEMM pass at large shapes."""
+        self._require_gpu(Qb, Cb, y, colmask)
+        B, d = Qb.shape
+        Nc = Cb.shape[0]
+        rank = torch.empty(B, dtype=torch.int64, device=Qb.device)
+        loss_sum = torch.empty(1, dtype=torch.float32, device=Qb.device)
+        ws = self._workspace(Qb.device, self._lib.workspace_bytes(B, Nc, d))
+        self._lib.check(self.lib.dprhot_sim_rank_loss(_ptr(Qb), B, _ptr(Cb), Nc, d, _ptr(y), int(y_offset), _ptr(colmask), float(inv_T),
+                                                      _ptr(rank), None, None, _ptr(loss_sum), _ptr(ws), ws.numel(), self._stream()),
+                        "dprhot_sim_rank_loss")
+        return rank, loss_sum
+
     def topk(self, S, k):
         self._require_gpu(S)
         rows, cols = S.shape
@@ -1007,8 +1020,11 @@ def rank_and_loss(q, c, labels, colmask=None, inv_T=1.0, kernels=None):
         Cb[Nc:].zero_()
         m8[Nc:] = 1
     y = torch.as_tensor(labels, dtype=torch.long, device=q.device)
-    ranks = kn.sim_rank(Qb, Cb, y, m8, inv_T)
-    _, _, loss_sum, _, _ = kn.inbatch_fwd(Qb, Cb, y, 0, m8, inv_T, 1.0, want_logits=False, want_G=False)
+    if hasattr(kn, "sim_rank_loss"):  # ONE pass of the Nq x Nc GEMM: count and softmax statistics in the same epilogue
+        ranks, loss_sum = kn.sim_rank_loss(Qb, Cb, y, m8, inv_T)
+    else:
+        ranks = kn.sim_rank(Qb, Cb, y, m8, inv_T)
+        _, _, loss_sum, _, _ = kn.inbatch_fwd(Qb, Cb, y, 0, m8, inv_T, 1.0, want_logits=False, want_G=False)
     return ranks, (loss_sum / q.shape[0]).reshape(())
 
 

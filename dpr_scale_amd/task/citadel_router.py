@@ -52,8 +52,15 @@ class RouterScoring:
         materialised score matrix."""
         from .dpr_task import HotCrossEntropyLoss
 
-        return type(self).sim_score is RouterScoring.sim_score and isinstance(getattr(self, "loss", None),
-                                                                              (HotCrossEntropyLoss, torch.nn.CrossEntropyLoss))
+        loss = getattr(self, "loss", None)
+        if type(self).sim_score is not RouterScoring.sim_score or not isinstance(loss, (HotCrossEntropyLoss, torch.nn.CrossEntropyLoss)):
+            return False
+        # the fused operator computes the PLAIN mean cross-entropy: a configured torch loss with class weights, label smoothing,
+        # another reduction or an ignore_index in use keeps the materialised path (the reference calls self.loss as configured)
+        if isinstance(loss, torch.nn.CrossEntropyLoss) and not isinstance(loss, HotCrossEntropyLoss):
+            return (loss.weight is None and float(getattr(loss, "label_smoothing", 0.0)) == 0.0 and loss.reduction == "mean"
+                    and loss.ignore_index == -100)
+        return True
 
     def router_loss(self, query_repr, context_repr, mask, pos_ctx_indices, teacher_scores):
         """citadel_task.py:249-262."""

@@ -180,6 +180,14 @@ int dprhot_sim_rank(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, i
                     const uint8_t* colmask, float inv_T, int64_t* rank, void* workspace, size_t workspace_bytes,
                     void* stream);
 
+/* Both halves of validation from the embeddings in one call (dpr_task.py:224-227, :296-299: compute_rank_metrics and self.loss read
+ * the same score matrix): rank as dprhot_sim_rank, row_loss / row_lse (either may be NULL) and loss_sum = sum_i (lse_i - S[i][y_i]) as
+ * dprhot_inbatch_fwd with grad_scale unused.  At no-logits shapes the similarity GEMM runs ONCE: its epilogue counts and keeps the
+ * softmax statistics (no score matrix); smaller problems compose the two existing calls. */
+int dprhot_sim_rank_loss(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
+                         const uint8_t* colmask, float inv_T, int64_t* rank, float* row_loss, float* row_lse, float* loss_sum,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same forward reading the encoder outputs as they are (fp32), so that no separate cast launch and no extra
  * round trip through HBM is needed: q [B,d] fp32; c [Nc,d] fp32 when the rank holds every column (world size
  * 1), or NULL when Cb is the already gathered bf16 buffer (world size > 1: the all-gather ships bf16).

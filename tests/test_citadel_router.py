@@ -104,6 +104,26 @@ def test_router_loss_hip_at_vocabulary_width(name):
     assert np.array_equal(fin, np.isfinite(s1)) and np.abs(s1[fin] - z["S_pair"][fin]).max() <= 1e-5 * np.abs(z["S_pair"][fin]).max()
 
 
+@pytest.mark.gpu
+def test_router_loss_at_the_bench_shape_against_the_router_oracle():
+    """The shape bench.py's `router` block times -- 128 queries x 1024 contexts x 30528 vocabulary columns -- against the pinned
+    restatement of citadel_task.py:249-262 (oracle/router_oracle.py, fp64 on the host): in-batch cross-entropy of the router vectors
+    and its gradients.  (The four reference-written fixtures are small batches; this is the size the timing is quoted at.)"""
+    from dpr_scale_amd import hotpath
+
+    dev = torch.device("cuda:0")
+    B, M, d = 128, 8, 30528
+    q, c, mask, pos, teacher = R.synth_router(11, B, M, d=d)
+    want_loss, want_dq, want_dc = R.router_step(q, c, mask, pos, teacher, in_batch=True, teacher_coef=0.0)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    tq, tc = t(q).requires_grad_(True), t(c).requires_grad_(True)
+    loss = hotpath.inbatch_contrastive_loss(tq, tc, t(pos), t(mask), 1.0, group=False)
+    loss.backward()
+    assert abs(loss.item() - want_loss) <= 1e-3 * max(1.0, abs(want_loss))
+    for got, want in ((tq.grad.cpu().numpy(), want_dq), (tc.grad.cpu().numpy(), want_dc)):
+        assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max()
+
+
 def _gather_worker(rank, W, port, seed, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"

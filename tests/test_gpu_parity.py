@@ -1057,6 +1057,24 @@ def test_score_free_rank_is_bit_exact(B, Nc, d, kn, dev):
     assert torch.equal(got[sub], ref_rank)
 
 
+@pytest.mark.parametrize("B,Nc,d", NL_SHAPES + [(64, 1000, 64)])
+def test_one_pass_rank_and_loss_equals_the_two_passes(B, Nc, d, kn, dev):
+    """dprhot_sim_rank_loss (validation: ranks AND cross-entropy from ONE pass of the similarity GEMM at no-logits shapes -- count and
+    softmax statistics in the same epilogue) against dprhot_sim_rank + dprhot_inbatch_fwd: ranks bit-exact (ties included), loss to
+    1e-6; and against the stored score matrix."""
+    Nc8 = (Nc + 7) // 8 * 8
+    Qb, Cb, y, m8 = _nl_problem(B, Nc8, d, 29, dev, dup=True)
+    rank1, loss1 = kn.sim_rank_loss(Qb, Cb, y, m8, 1.0)
+    rank2 = kn.sim_rank(Qb, Cb, y, m8, 1.0)
+    _, _, loss2, _, _ = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 1.0, 1.0, want_logits=False, want_G=False)
+    assert torch.equal(rank1, rank2)
+    assert abs(loss1.item() - loss2.item()) <= 1e-6 * max(1.0, abs(loss2.item()))
+    S = kn.sim(Qb, Cb, m8, 1.0)
+    assert torch.equal(rank1, kn.rank_of_gold(S, y))
+    ref = torch.nn.functional.cross_entropy(S, y, reduction="sum")
+    assert abs(loss1.item() - ref.item()) <= 1e-4 * max(1.0, abs(ref.item()))
+
+
 def test_rank_and_loss_helper_matches_score_matrix_path(kn, dev):
     from dpr_scale_amd import hotpath
 
