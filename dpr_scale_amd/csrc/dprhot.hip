@@ -881,19 +881,31 @@ int dprhot_pairwise_bwd(const float* g, const float* q, const float* c, int B, i
   return DPRHOT_OK;
 }
 
-static void launch_topk(const TopkArgs& p, int rows, hipStream_t st) {
-  if (p.k <= TK_KSMALL) hipLaunchKernelGGL((topk_stream_kernel<1024, TK_KSMALL, 4>), dim3(rows), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((topk_stream_kernel<4096, TK_KMAX, 8>), dim3(rows), dim3(256), 0, st, p);
+static int launch_topk(const TopkArgs& p, int rows, hipStream_t st) {
+  if (p.k <= TK_KSMALL) {
+    hipLaunchKernelGGL((topk_stream_kernel<1024, TK_KSMALL, 4>), dim3(rows), dim3(256), tk_lds_bytes(1024), st, p);
+  } else if (p.k <= TK_KMAX) {
+    hipLaunchKernelGGL((topk_stream_kernel<4096, TK_KMAX, 8>), dim3(rows), dim3(256), tk_lds_bytes(4096), st, p);
+  } else {  // 1024 < k <= 4096: 8192 slots
+    auto kern = topk_stream_kernel<8192, TK_KWIDE, 8>;
+    static AttrOnce attr_done;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tk_lds_bytes(8192)));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(rows), dim3(256), tk_lds_bytes(8192), st, p);
+  }
+  return DPRHOT_OK;
 }
 
 int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values,
                        int64_t* indices, int first, void* stream) {
   REQUIRE(S && values && indices, "NULL pointer");
-  REQUIRE(rows > 0 && cols > 0 && ld >= cols && k > 0 && k <= TK_KMAX, "bad shape rows=%d cols=%d ld=%lld k=%d", rows, cols,
+  REQUIRE(rows > 0 && cols > 0 && ld >= cols && k > 0 && k <= TK_KWIDE, "bad shape rows=%d cols=%d ld=%lld k=%d", rows, cols,
           (long long)ld, k);
   REQUIRE(col_offset >= 0, "negative col_offset");
   TopkArgs p{S, rows, cols, (long long)ld, (long long)col_offset, k, values, indices, first ? 1 : 0, nullptr, nullptr};
-  launch_topk(p, rows, (hipStream_t)stream);
+  if (int rc = launch_topk(p, rows, (hipStream_t)stream)) return rc;
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
 }

@@ -745,6 +745,8 @@ constexpr int TK_KMAX = 1024;        // run_retrieval_pytorch.py takes any --top
 // two sizes of the kernel: sort size P (LDS: 12 bytes per slot), state slots KM, candidate slots P - KM.  k <= 256 runs on
 // 12 KB of LDS (every row of a 1024-query batch resident at once), k <= 1024 on 48 KB (three rows per CU)
 constexpr int TK_KSMALL = 256;
+constexpr int TK_KWIDE = 4096;       // the wide instantiation: 8192 sort slots (96 KB of LDS, one row per CU)
+constexpr size_t tk_lds_bytes(int P) { return (size_t)P * (sizeof(float) + sizeof(long long)); }
 
 struct TopkArgs {
   const float* S;  // [rows][ld]
@@ -860,8 +862,11 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
   // candidate lists up to TK_NSORT entries are merged by counting, longer ones streamed through the buffer
   constexpr int TK_NSORT = TK_P <= 1024 ? 256 : 2048;
   static_assert(TK_KM + TK_NSORT <= TK_P && TK_KM + 257 <= TK_P, "scratch areas behind the state");
-  __shared__ float sv[TK_P];
-  __shared__ long long si[TK_P];
+  // 12 bytes per slot: 12 / 48 KB for the two sizes of round 1-3, 96 KB for the wide one (k <= 4096: run_retrieval_pytorch.py:149
+  // accepts any --topk) -- dynamic LDS, one allocation (tk_lds_bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
+  float* const sv = reinterpret_cast<float*>(tk_smem);
+  long long* const si = reinterpret_cast<long long*>(tk_smem + (size_t)TK_P * sizeof(float));
   __shared__ int s_cnt, s_win2[2];  // window counters alternate: the reset of one never races the adds into the other
   const int row = blockIdx.x, tid = threadIdx.x, k = p.k;
   const float* Srow = p.S + (size_t)row * p.ld;
@@ -987,7 +992,8 @@ __global__ __launch_bounds__(256, TK_P <= 1024 ? 4 : 2) void topk_stream_kernel(
         need = hist[257];
         total = (k - need) + hist[258];  // strictly ahead of the bin + the bin itself
         __syncthreads();
-        if (total <= 2048 || (pass == 3 && total <= TK_P)) { ok = true; break; }
+        // (the wide kernel's k alone exceeds 2048: it collects as soon as the candidates fit its 8192 slots)
+        if (total <= (TK_P <= 4096 ? 2048 : TK_P) || (pass == 3 && total <= TK_P)) { ok = true; break; }
       }
       if (ok) {
         if (tid == 0) s_cnt = 0;

@@ -1044,7 +1044,8 @@ class CorpusSearch:
     The [nq, n] score matrix never exists: each `chunk` of passages is scored on the bf16 MFMA path and folded
     into the running top-k on the device (dprhot_search)."""
 
-    KMAX = 1024  # largest k of the streaming top-k kernels (include/dprhot.h); run_retrieval_pytorch.py:149 accepts any --topk
+    KMAX = 1024   # largest k of dprhot_search (GEMM with the filter epilogue); run_retrieval_pytorch.py:149 accepts any --topk
+    KWIDE = 4096  # largest k of the streaming top-k kernel (dprhot_topk_update: 8192 sort slots in 96 KB of LDS)
 
     def __init__(self, query_embs, k, chunk=None, kernels=None):
         self.kn = kernels if kernels is not None else default_kernels()
@@ -1061,8 +1062,24 @@ class CorpusSearch:
         self.ws = None if self.wide_k else self.kn.search_workspace(nq, self.chunk, query_embs)
         self.first = True
 
+    def _add_wide_native(self, Cb, first_id):
+        """1024 < k <= 4096: the scores of a chunk from the MFMA path (dprhot_sim_fwd), folded into the running top-k by the streaming
+        kernel's wide instantiation (dprhot_topk_update: radix select from an empty state, then a threshold filter + bitonic merges in
+        LDS) -- no torch sort anywhere.  Chunks of 65536 passages: the score matrix of a chunk is nq x 256 KiB."""
+        n, d = Cb.shape
+        step = min(self.chunk, 65536)
+        for j0 in range(0, n, step):
+            cols = min(step, n - j0)
+            pad = (-cols) % 8
+            blk = Cb[j0:j0 + cols]
+            if pad:
+                blk = torch.cat([blk, torch.zeros((pad, d), dtype=_BF16, device=Cb.device)], 0)
+            S = self.kn.sim(self.Qb, blk.contiguous(), None, 1.0)
+            self.kn.topk_update(S, cols, first_id + j0, self.values, self.indices, self.first)
+            self.first = False
+
     def _add_wide(self, Cb, first_id):
-        """k beyond the kernels' 1024: the scores still come from the MFMA path chunk by chunk (dprhot_sim_fwd), the selection is
+        """k beyond 4096: the scores still come from the MFMA path chunk by chunk (dprhot_sim_fwd), the selection is
         torch's: the chunk's own top-k, then state + chunk sorted in the same total order (score desc, id asc) -- two stable sorts,
         ids first -- so that the result equals dprhot_topk of the whole matrix for any k.  Exact and rarely used (the reference's
         recipes stop at --topk 1000); not a hand-written kernel."""
@@ -1094,6 +1111,8 @@ class CorpusSearch:
             Cb = self.kn.empty((n, d), _BF16, corpus_embs)
             self.kn.cast_bf16(corpus_embs, Cb)
         if self.wide_k:
+            if self.k <= self.KWIDE and hasattr(self.kn, "topk_update"):
+                return self._add_wide_native(Cb, first_id)
             return self._add_wide(Cb, first_id)
         n8 = n // 8 * 8
         if n8:

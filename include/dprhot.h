@@ -236,8 +236,8 @@ int dprhot_inbatch_step_packed_f32(const float* q, const dprhot_bf16* gathered, 
                                    void* stream);
 
 /* Brute-force retrieval epilogue (run_retrieval_pytorch.py:149-150): per row, the k largest scores and
- * their column indices, descending, ties by lower column index.  k <= 1024 (the reference's recipes use --topk 100 and 1000),
- * k <= cols. */
+ * their column indices, descending, ties by lower column index.  k <= 4096 (the reference's recipes use --topk 100 and 1000; up to
+ * 256 and up to 1024 run on 12 / 48 KB of LDS per row, beyond that on 96 KB: 8192 sort slots), k <= cols. */
 int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_t* indices, void* stream);
 
 /* The same as a streaming update, for a corpus that is scored in pieces (the shard loop of

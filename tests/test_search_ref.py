@@ -56,14 +56,13 @@ def test_search_on_the_hip_path_equals_the_reference(chunk, shard):
     _check(v.cpu().numpy(), i.cpu().numpy(), q, c, z, meta["k"])
 
 
-def _wide_k_check(kernels, dev):
+def _wide_k_check(kernels, dev, k=1500, n=3000, chunk=1024, shard=1301):
     from dpr_scale_amd.hotpath import CorpusSearch
 
-    q, c = O.synth_search(7, 9, 3000, 32)
-    k = 1500
-    s = CorpusSearch(torch.from_numpy(q).to(dev), k, chunk=1024, kernels=kernels)
-    for lo in range(0, 3000, 1301):
-        s.add(torch.from_numpy(c[lo:lo + 1301]).to(dev), lo)
+    q, c = O.synth_search(7, 9, n, 32)
+    s = CorpusSearch(torch.from_numpy(q).to(dev), k, chunk=chunk, kernels=kernels)
+    for lo in range(0, n, shard):
+        s.add(torch.from_numpy(c[lo:lo + shard]).to(dev), lo)
     v, i = s.result()
     S = q.astype(np.float64) @ c.astype(np.float64).T
     for r in range(q.shape[0]):
@@ -79,5 +78,22 @@ def test_topk_beyond_the_kernel_limit_with_the_standin_kernels():
 
 
 @pytest.mark.gpu
-def test_topk_beyond_the_kernel_limit_on_the_hip_path():
-    _wide_k_check(None, torch.device("cuda:0"))
+@pytest.mark.parametrize("k,n,chunk,shard", [(1500, 3000, 1024, 1301), (4096, 20000, 8192, 7001), (1025, 70000, 65536, 70000)])
+def test_topk_beyond_the_kernel_limit_on_the_hip_path(k, n, chunk, shard):
+    """1024 < k <= 4096 on hand-written kernels only: MFMA scoring + the streaming top-k kernel's wide instantiation (8192 sort slots
+    in LDS).  No torch sort runs (the profiler sees none), and the result is the reference's total order."""
+    from torch.profiler import ProfilerActivity, profile
+
+    dev = torch.device("cuda:0")
+    _wide_k_check(None, dev, k, n, chunk, shard)  # warm-up + the check itself
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        _wide_k_check(None, dev, k, n, chunk, shard)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert any("topk_stream_kernel" in x for x in names), names
+    assert not any(("sort" in x.lower() or "radix" in x.lower()) and "dprhot" not in x for x in names), [x for x in names if "sort" in x.lower()]
+
+
+@pytest.mark.gpu
+def test_topk_beyond_the_wide_kernel_keeps_the_exact_torch_path():
+    _wide_k_check(None, torch.device("cuda:0"), k=5000, n=12000, chunk=8192, shard=5003)
