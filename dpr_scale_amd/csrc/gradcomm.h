@@ -159,46 +159,15 @@ __global__ __launch_bounds__(256) void grad_unpack_kernel(const void* __restrict
   const size_t n8 = n / 8;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if constexpr (KIND != GC_FP32) {
-    // A thread's 8 values become two float4: stored as they are, each store instruction writes 16 bytes out of every 32 (half of
-    // every line per instruction: 130 us for 660 MB, 0.62 of the HBM rate where the pack leg and the shard sum reach 0.71-0.87).
-    // Neighbouring lanes trade halves first (one DPP move per value): the even lane keeps both low halves, the odd lane both high
-    // ones, and every store instruction of the wave covers 1 KiB without holes.  The condition is the wave's last lane's.
-    const size_t lane = threadIdx.x & 63;
-    for (; c - lane + 63 + (GC_U - 1) * stride < n8; c += GC_U * stride) {
-      float v[GC_U][8];
+  // (Round 4, measured and not kept: a thread's 8 values become two float4, so each store instruction writes 16 bytes out of every 32;
+  //  letting neighbouring lanes trade halves first -- one DPP move per value, every store instruction of the wave then covers 1 KiB
+  //  without holes -- took this leg from 130 to 145-147 us for 110 M elements: the half-dense stores were not what holds it at 0.62.)
+  for (; c + (GC_U - 1) * stride < n8; c += GC_U * stride) {
+    float v[GC_U][8];
 #pragma unroll
-      for (int u = 0; u < GC_U; ++u) gc_load8<KIND>(full, c + u * stride, v[u]);
+    for (int u = 0; u < GC_U; ++u) gc_load8<KIND>(full, c + u * stride, v[u]);
 #pragma unroll
-      for (int u = 0; u < GC_U; ++u) {
-        const bool odd = lane & 1;
-        float4 a, b;
-        float give[4], got[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) give[e] = odd ? v[u][e] : v[u][4 + e];  // what the neighbour stores: my low half (odd) / high half (even)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          got[e] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give[e]), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
-        const size_t ce = (c + u * stride) & ~(size_t)1;  // the pair's even chunk
-        if (!odd) {
-          a = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);  // float4 2 ce
-          b = make_float4(got[0], got[1], got[2], got[3]);      // float4 2 ce + 2: the odd chunk's low half
-        } else {
-          a = make_float4(got[0], got[1], got[2], got[3]);      // float4 2 ce + 1: the even chunk's high half
-          b = make_float4(v[u][4], v[u][5], v[u][6], v[u][7]);  // float4 2 ce + 3
-        }
-        reinterpret_cast<float4*>(bucket)[2 * ce + (odd ? 1 : 0)] = a;
-        reinterpret_cast<float4*>(bucket)[2 * ce + 2 + (odd ? 1 : 0)] = b;
-      }
-    }
-  } else {
-    for (; c + (GC_U - 1) * stride < n8; c += GC_U * stride) {
-      float v[GC_U][8];
-#pragma unroll
-      for (int u = 0; u < GC_U; ++u) gc_load8<KIND>(full, c + u * stride, v[u]);
-#pragma unroll
-      for (int u = 0; u < GC_U; ++u) gc_store8<GC_FP32>(bucket, c + u * stride, v[u]);
-    }
+    for (int u = 0; u < GC_U; ++u) gc_store8<GC_FP32>(bucket, c + u * stride, v[u]);
   }
   for (; c < n8; c += stride) {
     float v[8];
