@@ -923,21 +923,29 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     bkr[j] = krow;
     bcol[j] = (unsigned)(c0 + ((((pos >> 1) ^ sk_swz64(krow)) << 4) + (pos & 1) * 8));
   }
-  auto step_col = [&](int s) {  // first context of step s of this unit
-    const int gs = s0 + s;
-    return sk_tile_col(p, gs >> 1) + (gs & 1) * 64;
-  };
-  auto issue = [&](int s, int slot) {
+  // first context of the NEXT step to be issued, kept incrementally (a division per refill sat in the loop's critical path):
+  // + 64 per step, + the header rows where a rank's tiles end (remapped tiles only)
+  const int spr = 2 * p.tiles_per_rank;  // steps per rank
+  int nxt_col, nxt_left;                  // column of the next step to issue; steps left in its rank (remapped tiles)
+  {
+    const int gs = s0;
+    nxt_col = sk_tile_col(p, gs >> 1) + (gs & 1) * 64;
+    nxt_left = spr > 0 ? spr - gs % spr : 0x7fffffff;
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // (provably uniform: the DMA destinations then reach m0 without a v_readfirstlane each)
+  auto issue = [&](int s, int slot) {  // (steps are issued in order: s is the next one)
     uint16_t* As = sk_smem + slot * SLOT;
     uint16_t* Bs = As + SK_QA;
-    const int k0 = step_col(s);
+    const int k0 = nxt_col;
+    nxt_col += 64;
+    if (--nxt_left == 0) { nxt_col += p.p_rows_c - p.p_n_ctx; nxt_left = spr; }
 #pragma unroll
     for (int j = 0; j < IA; ++j)
-      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.P + arow[j] + min(k0 + akin[j], p.Nc - 8)), (g2_lds_ptr*)(As + (wave * IA + j) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.P + arow[j] + min(k0 + akin[j], p.Nc - 8)), (g2_lds_ptr*)(As + (wave_u * IA + j) * 512), 16, 0, 0);
 #pragma unroll
     for (int j = 0; j < IB; ++j)
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(k0 + bkr[j], p.Nc - 1) * (unsigned)p.d + bcol[j]),
-                                       (g2_lds_ptr*)(Bs + (wave * IB + j) * 512), 16, 0, 0);
+                                       (g2_lds_ptr*)(Bs + (wave_u * IB + j) * 512), 16, 0, 0);
   };
 #pragma unroll
   for (int s = 0; s < SK_QSLOTS; ++s)
@@ -965,10 +973,18 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
         for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaf(fr[r], tm[a][b][r], acc[a][b][r]);
     }
   };
+#ifdef DPRHOT_TIMING
+  unsigned long long tk_[5] = {0, 0, 0, 0, 0}, tl_ = wall_clock64();  // thread 0's view of a step: wait | barrier | LDS reads | barrier + refill | MFMA issue + FMAs
+#define SK_LT(i) do { const unsigned long long t_ = wall_clock64(); tk_[i] += t_ - tl_; tl_ = t_; } while (0)
+#else
+#define SK_LT(i) do {} while (0)
+#endif
   // one step: FIRST = step 0 (forms the weight table); cur receives this step's product, prev holds the previous step's
   auto body = [&](auto first_tag, int s, f32x4 (&cur)[2][4], const f32x4 (&prev)[2][4]) {
     constexpr bool FIRST = decltype(first_tag)::value;
+    SK_LT(4);
     sk_wait_younger<PER>(min(s + SK_QSLOTS - 1, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
+    SK_LT(0);
     const int slot = s % SK_QSLOTS;
     uint16_t* As = sk_smem + slot * SLOT;
     const uint16_t* Bs = As + SK_QA;
@@ -981,6 +997,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       }
     }
     sk_barrier();  // (step 1: also publishes the table step 0 wrote)
+    SK_LT(1);
     bf16x8 af[2][2];
     bf16x4 lo[2][4], hi[2][4];
 #pragma unroll
@@ -997,14 +1014,15 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
         asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(lo[kk][b]), "=&v"(hi[kk][b]) : "v"(addr));
       }
     }
+    f32x4 frp[2];  // the PREVIOUS step's weights (its FMAs ride in this step's MFMA gaps)
+    if constexpr (!FIRST) {
+      const int tlp = ((s0 + s - 1) >> 1) - t0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) frp[a] = *reinterpret_cast<const f32x4*>(fs + tlp * 128 + wave * 32 + a * 16 + g4 * 4);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    // The slot is free as soon as every wave holds its fragments: refill it now (the ring is a latency chain: a DMA issued late is
-    // data late, two steps on)
-    if (s + SK_QSLOTS < ns) {
-      sk_barrier();
-      issue(s + SK_QSLOTS, slot);
-    }
+    SK_LT(2);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 bf[4];
@@ -1024,6 +1042,35 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 #else
           cur[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cur[a][b], 0, 0, 0);
 #endif
+#if !defined(SK_EXP) || !(SK_EXP & 1)
+      if constexpr (!FIRST) {
+        // half of the previous step's factor FMAs per k slice: sum += w * (P x C of step s - 1)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[kk][b][r] = fmaf(frp[kk][r], prev[kk][b][r], acc[kk][b][r]);
+      }
+#endif
+    }
+    if constexpr (!FIRST) {
+      // one MFMA, one FMA pair: the vector ALU work sits in the matrix pipe's issue gaps instead of behind the last MFMA
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+      // (the sums are made opaque HERE: otherwise the FMAs are sunk past the refill below, where nothing covers them)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));
+    }
+    SK_LT(3);
+    // The matrix pipe is busy for another ~0.1 us: the barrier and the slot's refill run under it (this wave's fragments are in
+    // registers; the barrier says everybody's are)
+    if (s + SK_QSLOTS < ns) {
+      sk_barrier();
+      issue(s + SK_QSLOTS, slot);
     }
     if constexpr (FIRST) {
       // under the MFMAs: the slice's reference per row and the weights of its tiles (published by the next barrier of this workgroup)
@@ -1043,10 +1090,6 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
           sk_lds_st32(fs + tl * 128 + row, __float_as_uint(w));
         }
       }
-    } else {
-#if !defined(SK_EXP) || !(SK_EXP & 1)
-      add_scaled(s - 1, prev);
-#endif
     }
   };
   body(std::true_type{}, 0, tA, tB);
@@ -1058,6 +1101,18 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   if ((ns - 1) & 1) add_scaled(ns - 1, tB);
   else add_scaled(ns - 1, tA);
   DPRHOT_TMB(2, 2);
+#ifdef DPRHOT_TIMING
+  SK_LT(4);
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {
+    // slots 3.. of this workgroup's record: accumulated ticks of the five parts of a step (the unit's end stamp moves to slot 7)
+    g_dprhot_tmb[(2 * 4096 + blockIdx.x) * 8 + 4] = tk_[0];
+    g_dprhot_tmb[(2 * 4096 + blockIdx.x) * 8 + 5] = tk_[1];
+    g_dprhot_tmb[(2 * 4096 + blockIdx.x) * 8 + 6] = tk_[2];
+    g_dprhot_tmb[(3 * 4096 + blockIdx.x) * 8 + 0] = tk_[3];
+    g_dprhot_tmb[(3 * 4096 + blockIdx.x) * 8 + 1] = tk_[4];
+    g_dprhot_tmb[(3 * 4096 + blockIdx.x) * 8 + 2] = (unsigned long long)ns;
+  }
+#endif
   // ---- slab tile [128][64] fp32 through LDS -> 16-byte stores, 256 bytes per row
   constexpr int TS = SK_QN + 4;
   float* const T = reinterpret_cast<float*>(sk_smem);
