@@ -947,8 +947,11 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(k0 + bkr[j], p.Nc - 1) * (unsigned)p.d + bcol[j]),
                                        (g2_lds_ptr*)(Bs + (wave_u * IB + j) * 512), 16, 0, 0);
   };
+  // Two steps are issued here, and step s + 2 right behind step s's first barrier: at that barrier every wave has finished READING
+  // slot (s - 1) % 3 -- the slot step s + 2 goes to -- so the refill needs no barrier of its own (one barrier per step instead of two;
+  // the stamps showed the wait for a slot at 0.11 of 0.73 us per step: one step less of look-ahead is affordable)
 #pragma unroll
-  for (int s = 0; s < SK_QSLOTS; ++s)
+  for (int s = 0; s < SK_QSLOTS - 1; ++s)
     if (s < ns) issue(s, s);
   // (Measured and not kept: warming this XCD's L2 for the later steps -- one lane per 128-byte line of their operands into a register
   //  nobody reads, issued right behind the first three slots' DMAs, counted in the waits of steps 0..2.  The loop did not get faster
@@ -983,7 +986,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   auto body = [&](auto first_tag, int s, f32x4 (&cur)[2][4], const f32x4 (&prev)[2][4]) {
     constexpr bool FIRST = decltype(first_tag)::value;
     SK_LT(4);
-    sk_wait_younger<PER>(min(s + SK_QSLOTS - 1, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
+    sk_wait_younger<PER>(min(s + SK_QSLOTS - 2, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
     SK_LT(0);
     const int slot = s % SK_QSLOTS;
     uint16_t* As = sk_smem + slot * SLOT;
@@ -998,6 +1001,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     }
     sk_barrier();  // (step 1: also publishes the table step 0 wrote)
     SK_LT(1);
+    if (s + SK_QSLOTS - 1 < ns) issue(s + SK_QSLOTS - 1, (s + SK_QSLOTS - 1) % SK_QSLOTS);  // into the slot read in step s - 1
     bf16x8 af[2][2];
     bf16x4 lo[2][4], hi[2][4];
 #pragma unroll
@@ -1066,12 +1070,6 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
         for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));
     }
     SK_LT(3);
-    // The matrix pipe is busy for another ~0.1 us: the barrier and the slot's refill run under it (this wave's fragments are in
-    // registers; the barrier says everybody's are)
-    if (s + SK_QSLOTS < ns) {
-      sk_barrier();
-      issue(s + SK_QSLOTS, slot);
-    }
     if constexpr (FIRST) {
       // under the MFMAs: the slice's reference per row and the weights of its tiles (published by the next barrier of this workgroup)
       asm volatile("" : "+v"(lt[0]), "+v"(lt[1]), "+v"(lt[2]), "+v"(lt[3]));

@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
       ++nb; steps += (double)r3[2];
       acc[0] += r2[4] * 0.01; acc[1] += r2[5] * 0.01; acc[2] += r2[6] * 0.01; acc[3] += r3[0] * 0.01; acc[4] += r3[1] * 0.01;
     }
-    if (nb) printf("dq loop, per step (us, avg over %d units x %.1f steps): wait for the slot %.3f | barrier %.3f | fragment reads %.3f | MFMA issue + FMAs %.3f | barrier + refill (+ step 0 table) %.3f\n",
+    if (nb) printf("dq loop, per step (us, avg over %d units x %.1f steps): wait for the slot %.3f | barrier %.3f | refill + fragment reads %.3f | MFMA issue + FMAs %.3f | (step 0: table) %.3f\n",
                    nb, steps / nb, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps);
   }
   float hs; CK(hipMemcpy(&hs, sum, 4, hipMemcpyDeviceToHost)); printf("loss_sum %.4f\n", hs);
