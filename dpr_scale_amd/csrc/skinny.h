@@ -152,8 +152,10 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     for (int j = 0; j < IPC; ++j)
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + cof[j] + kc * SK_KC), (g2_lds_ptr*)(dst + (wave * IPC + j) * 512), 16, 0, 0);
   };
+  // SLOTS - 1 chunks here; chunk c + SLOTS - 1 is issued right behind chunk c's barrier, into the slot chunk c - 1 was read from
+  // (at that barrier every wave has finished reading it): one barrier per chunk instead of two
 #pragma unroll
-  for (int c = 0; c < SLOTS; ++c)
+  for (int c = 0; c < SLOTS - 1; ++c)
     if (c < NCH) issue(c, c);
   // mask bytes and labels: raw loads only (a select on a loaded value here would park an s_waitcnt in front of everything
   // that follows); they are turned into what the epilogue needs there
@@ -208,8 +210,9 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
       const sk_u32x4 val = {abf[c].x, abf[c].y, abf[c].z, abf[c].w};
       asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(val) : "memory");
     }
-    sk_wait_younger<IPC>(min(c + SLOTS - 1, NCH - 1) - c);  // this wave's share of chunk c has landed
+    sk_wait_younger<IPC>(min(c + SLOTS - 2, NCH - 1) - c);  // this wave's share of chunk c has landed
     sk_barrier();                                                // ... everybody's has; the q chunk is in place
+    if (c + SLOTS - 1 < NCH) issue(c + SLOTS - 1, (c + SLOTS - 1) % SLOTS);
     const uint16_t* Bs = ring + (c % SLOTS) * (COLS * SK_KC);
 #pragma unroll
     for (int kk = 0; kk < SK_KC / 32; ++kk) {
@@ -228,10 +231,6 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
-    if (c + SLOTS < NCH) {
-      sk_barrier();  // every wave is done reading this slot
-      issue(c + SLOTS, c % SLOTS);
     }
   }
   sk_barrier();  // the ring is free: its start becomes the fp32 logit tile [32][COLS + 4]
@@ -263,9 +262,16 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     }
     mx = ss_max8(mx);
     float sm = 0.f;
+    float4 e[QD];  // exp(v - max): summed here, stored (scaled) as the tile softmax below -- one exponential per score
     if (mx != -INFINITY) {
 #pragma unroll
-      for (int qd = 0; qd < QD; ++qd) sm += __expf(v[qd].x - mx) + __expf(v[qd].y - mx) + __expf(v[qd].z - mx) + __expf(v[qd].w - mx);
+      for (int qd = 0; qd < QD; ++qd) {
+        e[qd] = make_float4(__expf(v[qd].x - mx), __expf(v[qd].y - mx), __expf(v[qd].z - mx), __expf(v[qd].w - mx));
+        sm += (e[qd].x + e[qd].y) + (e[qd].z + e[qd].w);
+      }
+    } else {
+#pragma unroll
+      for (int qd = 0; qd < QD; ++qd) e[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     sm = ss_sum8(sm);
     if (row < p.B) {
@@ -278,10 +284,9 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
         if (yi >= col && yi < col + 4) p.gold[row] = yi == col ? v[qd].x : (yi == col + 1 ? v[qd].y : (yi == col + 2 ? v[qd].z : v[qd].w));
         if (p.P != nullptr && n0 + col < p.Nc) {
           // exp(-inf - mx) == 0 at masked columns; the gold column leaves as 0 (sk_bwdf_kernel adds its term in fp32)
-          const float e0 = yi == col ? 0.f : __expf(v[qd].x - mx) * inv, e1 = yi == col + 1 ? 0.f : __expf(v[qd].y - mx) * inv;
-          const float e2 = yi == col + 2 ? 0.f : __expf(v[qd].z - mx) * inv, e3 = yi == col + 3 ? 0.f : __expf(v[qd].w - mx) * inv;
-          const bool dead = mx == -INFINITY;
-          *reinterpret_cast<uint2*>(p.P + (size_t)row * p.Nc + n0 + col) = dead ? make_uint2(0u, 0u) : make_uint2(pk_bf16(e0, e1), pk_bf16(e2, e3));
+          const float e0 = yi == col ? 0.f : e[qd].x * inv, e1 = yi == col + 1 ? 0.f : e[qd].y * inv;
+          const float e2 = yi == col + 2 ? 0.f : e[qd].z * inv, e3 = yi == col + 3 ? 0.f : e[qd].w * inv;
+          *reinterpret_cast<uint2*>(p.P + (size_t)row * p.Nc + n0 + col) = make_uint2(pk_bf16(e0, e1), pk_bf16(e2, e3));
         }
       }
     }
@@ -1383,16 +1388,17 @@ __global__ __launch_bounds__(128) void sk_dq_finish_kernel(SkFinArgs p) {
   const int yg = reinterpret_cast<const int*>(p.y)[2 * row] + (int)p.y_offset;
   const uint2 cg = *reinterpret_cast<const uint2*>(p.C + (size_t)yg * p.d + (ok ? q4 : 0) * 4);
   const float gl = p.gold[row];
-  const float lse = sk_row_lse(p.tile_lse, p.nt, p.B, row, lane);
+  // (the slices' references first: their loads are in flight together with the row's statistics, not behind its logsumexp)
+  float m = -INFINITY;
   if (tid < p.nslices) {
     const int s0 = tid * p.ksteps, ns = min(p.ksteps, p.nk - s0);
-    float m = -INFINITY;
     if (ns > 0) {
       const int tlo = s0 >> 1, thi = min((s0 + ns - 1) >> 1, p.nt - 1);
       for (int t = tlo; t <= thi; ++t) m = fmaxf(m, p.tile_lse[((size_t)(t >> 2) * p.B + row) * 4 + (t & 3)]);
     }
-    s_e[tid] = m == -INFINITY ? 0.f : __expf(m - lse) * p.grad_scale;
   }
+  const float lse = sk_row_lse(p.tile_lse, p.nt, p.B, row, lane);
+  if (tid < p.nslices) s_e[tid] = m == -INFINITY ? 0.f : __expf(m - lse) * p.grad_scale;
   __syncthreads();
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = 0; base < p.nslices; base += CH) {
