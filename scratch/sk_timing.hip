@@ -11,6 +11,8 @@ __device__ unsigned long long g_dprhot_tmb[4 * 4096 * 8];
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 128, K = argc > 2 ? atoi(argv[2]) : 8, d = argc > 3 ? atoi(argv[3]) : 768, W = 8;
   const bool no_g = argc > 4 && atoi(argv[4]) != 0;  // 1: G == NULL -- the plan without the dScores launch (round 4)
+  if (argc > 5) dprhot_set_option("sk_dbg", atoi(argv[5]));        // 1: dC units leave at once, 2: dQ units leave at once
+  if (argc > 6) dprhot_set_option("sk_dq_slices", atoi(argv[6]));  // context slices of the dQ units
   const int n_ctx = B * K;
   int rows_c; dprhot_packed_rows(n_ctx, d, &rows_c);
   const int Nc = W * rows_c;
@@ -44,6 +46,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 3; ++k) {
       unsigned long long t0 = ~0ull, t1 = 0; int nb = 0;
       for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (r[0]) { ++nb; t0 = std::min(t0, r[0]); t1 = std::max(t1, r[nst[k] - 1]); } }
+      if (nb == 0) { printf("it%d %s: no workgroups\n", it, names[k]); continue; }
       printf("it%d %s: %d workgroups, kernel span %.2f us | ", it, names[k], nb, (t1 - t0) * 0.01);
       // start offsets and per-phase averages (10 ns ticks)
       double startavg = 0, startmax = 0; std::vector<double> ph(nst[k], 0.0);

@@ -17,7 +17,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=120)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--few-rows", action="store_true", help="shapes of the few-rows plan WITHOUT its dScores launch (csrc/skinny.h, round 4), taken "
+                                                             "wherever that plan exists (option sk_fused = 2): B in 32..128, thousands of contexts")
     a = ap.parse_args()
+    if a.few_rows:
+        from dpr_scale_amd import _lib
+        _lib.set_option("sk_fused", 2)
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(a.seed)
 
@@ -28,8 +33,12 @@ def main():
     Ks = [1, 2, 3, 8, 9, 16, 33, 64]
     ds = [8, 64, 80, 128, 256, 768, 1024, 1032, 4096]
     bad, worst = 0, (0.0, 0.0, 0.0)
+    if a.few_rows:
+        Bs, Ks, ds = [32, 64, 96, 128], [33, 40, 64, 65, 72, 100, 128], [128, 256, 384, 768, 1024]
     for case in range(a.cases):
         B, K, d = pick(Bs), pick(Ks), pick(ds)
+        if a.few_rows and (B * K > 16384 or B * K < 4096):
+            continue
         if B * K > 32768 or B * B * K > (1 << 27) or B * K * d > (1 << 27):
             continue
         T = float(pick([0.05, 0.3, 1.0, 2.0]))
