@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -148,8 +148,13 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
     {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured no slower (B x Nc >= 2^20: cfg3 per rank), 2 = wherever the plan exists (tests), 0 = never"},
     {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward): 1 dC units leave at once, 2 dQ units leave at once, 4 dQ units load no gold rows"},
+    {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
 };
-int g_opt[OPT_COUNT] = {-1, 0, 0, 256, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0};
+int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
+const bool g_opt_defaults = [] {
+  for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = kOptDefs[i].def;
+  return true;
+}();
 inline int opt(OptId i) { return __atomic_load_n(&g_opt[i], __ATOMIC_RELAXED); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -638,20 +643,19 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
                  dC_part, g_dc_bf16 ? 1 : 0, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, loss_sum, g_loss_scale,
                  row_loss, row_lse, fz.ksteps, sk.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0, opt(OPT_SK_DBG)};
     const size_t lds = sk_bwdf_lds();
-    static AttrOnce attr_done[2];
-    if (nts <= 64) {
-      if (!attr_done[0]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwdf_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[0] = true;
+    static AttrOnce attr_done[4];
+    auto launch = [&](auto kern, int slot, int threads) -> int {
+      if (!attr_done[slot]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[slot] = true;
       }
-      hipLaunchKernelGGL(sk_bwdf_kernel<8>, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
-    } else {
-      if (!attr_done[1]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwdf_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done[1] = true;
-      }
-      hipLaunchKernelGGL(sk_bwdf_kernel<16>, dim3((unsigned)(ndq_pad + ndc)), dim3(SK_THREADS), lds, st, b);
-    }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ndq_pad + ndc)), dim3((unsigned)threads), lds, st, b);
+      return DPRHOT_OK;
+    };
+    const bool w8 = opt(OPT_SK_W8) != 0;
+    if (nts <= 64) rc = w8 ? launch(sk_bwdf_kernel<8, 8>, 2, 512) : launch(sk_bwdf_kernel<8, 4>, 0, SK_THREADS);
+    else rc = w8 ? launch(sk_bwdf_kernel<16, 8>, 3, 512) : launch(sk_bwdf_kernel<16, 4>, 1, SK_THREADS);
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     {
       const int parts = cdiv(d / 4, 128);

@@ -33,7 +33,10 @@ constexpr int SK_SLOTS = 4;
 constexpr int SK_MAXB = 128;
 constexpr int SK_DN = 128;     // d columns of a dC unit
 constexpr int SK_QN = 64;      // d columns of a dQ unit
-constexpr int SK_QSLOTS = 3;   // ring slots (64 contexts each) of a dQ unit (72 KiB: two workgroups per CU)
+#ifndef SK_QSLOTS_EXP
+#define SK_QSLOTS_EXP 3
+#endif
+constexpr int SK_QSLOTS = SK_QSLOTS_EXP;   // (3) ring slots (64 contexts each) of a dQ unit (72 KiB: two workgroups per CU)
 constexpr int SK_MAXG = 16;    // groups of 4 statistics tiles per half row: 128 tiles (Nc <= 16384 at 128 columns per tile; doubling it
                                // for the narrow sim unit costs the loss workgroup of sk_g_kernel 1.5 us: 5.8 -> 7.3 us for the launch)
 
@@ -790,7 +793,11 @@ struct SkBwdFArgs {
 
 constexpr int SK_FT = 8;                            // statistics tiles a dQ unit may touch ((ksteps + 1) / 2 + 1 <= SK_FT: sk_fused_ok)
 constexpr int SK_FX = (SK_FT * 128 + 2 * 128) * 4;  // bytes of a dQ unit's table behind its ring: w[SK_FT][128] (+ 1 KiB spare)
-inline size_t sk_bwdf_lds() { return (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2 + SK_FX; }
+constexpr int SK_FDC_TABLES = 6 * 128 * 4 + 16;  // fi, gv, rl, ym, cnt [128] each + dupf (sk_dc_unit_f)
+inline size_t sk_bwdf_lds() {  // the larger of the two unit kinds' needs
+  const size_t dq = (size_t)SK_QSLOTS * (SK_QA + SK_QB) * 2 + SK_FX, dc = (size_t)SK_COLS * (SK_DN + 4) * 4 + SK_FDC_TABLES;
+  return dq > dc ? dq : dc;
+}
 constexpr int SK_FDC_TAB = SK_COLS * SK_DC_TS * 4;  // byte offset of a dC unit's tables (behind its fp32 epilogue tile)
 
 __device__ __forceinline__ f32x4 sk_ld16_hidden(const void* ptr) {
@@ -830,15 +837,16 @@ __device__ __forceinline__ int sk_step_of_col(const SkBwdFArgs& p, int n) {
   return j < p.p_n_ctx ? ((r * p.tiles_per_rank + (j >> 7)) << 1) + ((j >> 6) & 1) : -1;
 }
 
-// The statistics of ONE row per thread pair (row = tid >> 1, half = tid & 1: groups half, half + 2, ... of four tile values).
-// issue() before the unit's DMAs, finish() after the counted wait: the row's logsumexp, identical bits in both lanes of the pair.
-template <int NG>
+// The statistics of ONE row per group of PH threads (row = tid / PH, part = tid % PH: groups part, part + PH, ... of four tile values;
+// PH = 2 in the four-wave units, 4 in the eight-wave ones).  issue() before the unit's DMAs, finish() after the counted wait: the
+// row's logsumexp, identical bits in every lane of the group.
+template <int NG, int PH = 2>
 struct SkRowStats {
   f32x4 sv[NG];
   __device__ __forceinline__ void issue(const float* tile_lse, int nt, int B, int prow, int ph) {
     const int ng = (nt + 3) >> 2;
 #pragma unroll
-    for (int u = 0; u < NG; ++u) sv[u] = sk_ld16_hidden(tile_lse + ((size_t)min(ph + 2 * u, ng - 1) * B + prow) * 4);
+    for (int u = 0; u < NG; ++u) sv[u] = sk_ld16_hidden(tile_lse + ((size_t)min(ph + PH * u, ng - 1) * B + prow) * 4);
   }
   // (guide section 5.7 item 3: makes the loaded registers opaque HERE, behind the caller's counted wait -- no consumer is scheduled above it)
   __device__ __forceinline__ void pin() {
@@ -850,21 +858,23 @@ struct SkRowStats {
     float v[NG][4];
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
-      const int t = (ph + 2 * u) * 4;  // (groups beyond the last re-read the last group: t >= nt there)
+      const int t = (ph + PH * u) * 4;  // (groups beyond the last re-read the last group: t >= nt there)
       v[u][0] = t + 0 < nt ? sv[u][0] : -INFINITY;
       v[u][1] = t + 1 < nt ? sv[u][1] : -INFINITY;
       v[u][2] = t + 2 < nt ? sv[u][2] : -INFINITY;
       v[u][3] = t + 3 < nt ? sv[u][3] : -INFINITY;
       mx = fmaxf(mx, fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3])));
     }
-    mx = fmaxf(mx, ss_dpp<0xB1>(mx));  // the other half of the row (lane ^ 1)
+    mx = fmaxf(mx, ss_dpp<0xB1>(mx));  // the other lanes of the row (lane ^ 1, then lane ^ 2)
+    if constexpr (PH == 4) mx = fmaxf(mx, ss_dpp<0x4E>(mx));
     float sm = 0.f;
     if (mx != -INFINITY) {
 #pragma unroll
       for (int u = 0; u < NG; ++u) sm += (__expf(v[u][0] - mx) + __expf(v[u][1] - mx)) + (__expf(v[u][2] - mx) + __expf(v[u][3] - mx));
     }
-    // (a + b == b + a: both lanes of the pair hold the same bits)
+    // (a + b == b + a: every lane of the group holds the same bits)
     sm += ss_dpp<0xB1>(sm);
+    if constexpr (PH == 4) sm += ss_dpp<0x4E>(sm);
     return mx + logf(sm);
   }
 };
@@ -880,13 +890,17 @@ struct SkRowStats {
 // ring runs dry behind them), and the launch came out exactly as long as the two launches it replaced (29.4 us per step both ways).
 // The factor FMAs of step s run under the MFMAs of step s + 1 (two scratch accumulators), and a slot is refilled as soon as every
 // wave holds its fragments.
-template <int NG>
+template <int NG, int NW = 4>
 __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
-  constexpr int IA = SK_QA * 2 / 1024 / 4;  // 4
-  constexpr int IB = SK_QB * 2 / 1024 / 4;  // 2
+  constexpr int NT = NW * 64;  // threads
+  constexpr int PH = NW / 2;   // threads per row of the weight table
+  constexpr int NB = 16 / NW;  // 16-column groups of a wave: four waves = 4 row groups x 64 columns, eight = 4 row groups x 2 halves of 32
+  constexpr int IA = SK_QA * 2 / 1024 / NW;  // 4 | 2
+  constexpr int IB = SK_QB * 2 / 1024 / NW;  // 2 | 1
   constexpr int PER = IA + IB;
   constexpr int SLOT = SK_QA + SK_QB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = NW == 4 ? wave : wave >> 1, wc = NW == 4 ? 0 : wave & 1;
   const int ndt = p.d / SK_QN;
   const int dt = unit % ndt, ks = unit / ndt;
   const int c0 = dt * SK_QN;
@@ -896,19 +910,19 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   const int t0 = s0 >> 1;
   float* const out = p.part + (size_t)ks * p.B * p.d;
   if (ns <= 0) {  // a remapped tiling with fewer steps than the plan's slices cover: this slice is empty, its slab is zero
-    for (int e = tid; e < p.B * (SK_QN / 4); e += SK_THREADS)
+    for (int e = tid; e < p.B * (SK_QN / 4); e += NT)
       *reinterpret_cast<float4*>(out + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   float* const fs = reinterpret_cast<float*>(sk_smem + SK_QSLOTS * SLOT);  // [SK_FT][128]: weight of (local tile, row)
   DPRHOT_TMB(2, 0);
 
-  // ---- hidden loads first (older than every DMA of this wave): the tile values of this slice, row tid >> 1, tiles t0 + (tid & 1) + 2u
-  const int prow = min(tid >> 1, p.B - 1), ph = tid & 1;
-  float lt[SK_FT / 2];
+  // ---- hidden loads first (older than every DMA of this wave): the tile values of this slice, row tid / PH, tiles t0 + tid % PH + PH u
+  const int prow = min(tid / PH, p.B - 1), ph = tid % PH;
+  float lt[SK_FT / PH];
 #pragma unroll
-  for (int u = 0; u < SK_FT / 2; ++u) {
-    const int t = min(t0 + ph + 2 * u, p.nt - 1);
+  for (int u = 0; u < SK_FT / PH; ++u) {
+    const int t = min(t0 + ph + PH * u, p.nt - 1);
     lt[u] = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
   }
 
@@ -964,31 +978,31 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   DPRHOT_TMB(2, 1);
 
   const int i16 = lane & 15, g4 = lane >> 4;
-  f32x4 acc[2][4], tA[2][4], tB[2][4];
+  f32x4 acc[2][NB], tA[2][NB], tB[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = tA[a][b] = tB[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b) acc[a][b] = tA[a][b] = tB[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  auto add_scaled = [&](int s, const f32x4 (&tm)[2][4]) {  // sum += w(row, tile of step s) * (P x C of step s)
+  auto add_scaled = [&](int s, const f32x4 (&tm)[2][NB]) {  // sum += w(row, tile of step s) * (P x C of step s)
     const int tl = ((s0 + s) >> 1) - t0;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      const f32x4 fr = *reinterpret_cast<const f32x4*>(fs + tl * 128 + wave * 32 + a * 16 + g4 * 4);
+      const f32x4 fr = *reinterpret_cast<const f32x4*>(fs + tl * 128 + wr * 32 + a * 16 + g4 * 4);
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaf(fr[r], tm[a][b][r], acc[a][b][r]);
     }
   };
-#ifdef DPRHOT_TIMING
+#if defined(DPRHOT_TIMING) && DPRHOT_TIMING >= 2
   unsigned long long tk_[5] = {0, 0, 0, 0, 0}, tl_ = wall_clock64();  // thread 0's view of a step: wait | barrier | LDS reads | barrier + refill | MFMA issue + FMAs
 #define SK_LT(i) do { const unsigned long long t_ = wall_clock64(); tk_[i] += t_ - tl_; tl_ = t_; } while (0)
 #else
 #define SK_LT(i) do {} while (0)
 #endif
   // one step: FIRST = step 0 (forms the weight table); cur receives this step's product, prev holds the previous step's
-  auto body = [&](auto first_tag, int s, f32x4 (&cur)[2][4], const f32x4 (&prev)[2][4]) {
+  auto body = [&](auto first_tag, int s, f32x4 (&cur)[2][NB], const f32x4 (&prev)[2][NB]) {
     constexpr bool FIRST = decltype(first_tag)::value;
     SK_LT(4);
     sk_wait_younger<PER>(min(s + SK_QSLOTS - 2, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
@@ -999,27 +1013,26 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     const int kvalid = p.tiles_per_rank > 0 ? 64 : p.Nc - (s0 + s) * 64;  // < 64 only in the ragged last step of an unmapped layout
     if (kvalid < 64) {
       sk_barrier();
-      for (int e = tid; e < SK_MAXB * 8; e += SK_THREADS) {
+      for (int e = tid; e < SK_MAXB * 8; e += NT) {
         const int row = e >> 3, ch = e & 7;
         if (ch * 8 >= kvalid) *reinterpret_cast<uint4*>(As + row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)) = make_uint4(0u, 0u, 0u, 0u);
       }
     }
     sk_barrier();  // (step 1: also publishes the table step 0 wrote)
     SK_LT(1);
-    if (s + SK_QSLOTS - 1 < ns) issue(s + SK_QSLOTS - 1, (s + SK_QSLOTS - 1) % SK_QSLOTS);  // into the slot read in step s - 1
     bf16x8 af[2][2];
-    bf16x4 lo[2][4], hi[2][4];
+    bf16x4 lo[2][NB], hi[2][NB];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int row = wave * 32 + a * 16 + i16;
+        const int row = wr * 32 + a * 16 + i16;
         af[kk][a] = *reinterpret_cast<const bf16x8*>(As + row * 64 + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
       }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < NB; ++b) {
         const int k = kk * 32 + g4 * 8 + (i16 >> 2);
-        const unsigned addr = (unsigned)(uintptr_t)(lds_bf16x4*)(Bs + k * SK_QN + ((b ^ sk_swz64(k)) << 4) + (i16 & 3) * 4);
+        const unsigned addr = (unsigned)(uintptr_t)(lds_bf16x4*)(Bs + k * SK_QN + (((wc * NB + b) ^ sk_swz64(k)) << 4) + (i16 & 3) * 4);
         asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512" : "=&v"(lo[kk][b]), "=&v"(hi[kk][b]) : "v"(addr));
       }
     }
@@ -1027,16 +1040,24 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     if constexpr (!FIRST) {
       const int tlp = ((s0 + s - 1) >> 1) - t0;
 #pragma unroll
-      for (int a = 0; a < 2; ++a) frp[a] = *reinterpret_cast<const f32x4*>(fs + tlp * 128 + wave * 32 + a * 16 + g4 * 4);
+      for (int a = 0; a < 2; ++a) frp[a] = *reinterpret_cast<const f32x4*>(fs + tlp * 128 + wr * 32 + a * 16 + g4 * 4);
     }
+    // The refill of step s + 2 goes into the slot read in step s - 1 (free since this step's barrier), and it is issued HERE, behind
+    // the fragment reads: six (three) LDS-DMA pieces per wave take the texture path 0.2-0.3 us to accept, which the LDS reads'
+    // latency now overlaps (stamps: "refill + fragment reads" 0.41 -> 0.33 us per step, the loop 10.4 -> 9.8 us).
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + SK_QSLOTS - 1 < ns) issue(s + SK_QSLOTS - 1, (s + SK_QSLOTS - 1) % SK_QSLOTS);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     SK_LT(2);
+    // (Measured and not kept: the refill issued unconditionally -- clamped addresses -- INSIDE the MFMA block, one LDS-DMA piece per
+    //  16 / 6 MFMAs through sched_group_barrier(0x010): the scheduler clumped five of the six pieces behind the eleventh MFMA, the
+    //  stamps moved 0.1 us from "wait for the slot" into the MFMA block, and the launch took 14.0 against 13.8 us.)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 bf[4];
+      bf16x8 bf[NB];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < NB; ++b) {
         bf16x8 r;
         r[0] = lo[kk][b][0]; r[1] = lo[kk][b][1]; r[2] = lo[kk][b][2]; r[3] = lo[kk][b][3];
         r[4] = hi[kk][b][0]; r[5] = hi[kk][b][1]; r[6] = hi[kk][b][2]; r[7] = hi[kk][b][3];
@@ -1045,7 +1066,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #if defined(SK_EXP) && (SK_EXP & 1)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], acc[a][b], 0, 0, 0);
 #else
@@ -1055,7 +1076,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       if constexpr (!FIRST) {
         // half of the previous step's factor FMAs per k slice: sum += w * (P x C of step s - 1)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[kk][b][r] = fmaf(frp[kk][r], prev[kk][b][r], acc[kk][b][r]);
       }
@@ -1064,7 +1085,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     if constexpr (!FIRST) {
       // one MFMA, one FMA pair: the vector ALU work sits in the matrix pipe's issue gaps instead of behind the last MFMA
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 4 * NB; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
       }
@@ -1072,22 +1093,24 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[a][b]));
+        for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(acc[a][b]));
     }
     SK_LT(3);
     if constexpr (FIRST) {
       // under the MFMAs: the slice's reference per row and the weights of its tiles (published by the next barrier of this workgroup)
-      asm volatile("" : "+v"(lt[0]), "+v"(lt[1]), "+v"(lt[2]), "+v"(lt[3]));
+#pragma unroll
+      for (int u = 0; u < SK_FT / PH; ++u) asm volatile("" : "+v"(lt[u]));
       const int tlast = min((s0 + ns - 1) >> 1, p.nt - 1) - t0;  // last local tile of this slice
       float m = -INFINITY;
 #pragma unroll
-      for (int u = 0; u < SK_FT / 2; ++u) m = fmaxf(m, ph + 2 * u <= tlast ? lt[u] : -INFINITY);
-      m = fmaxf(m, ss_dpp<0xB1>(m));  // the other half of the row's tiles (lane ^ 1)
-      const int row = tid >> 1;
+      for (int u = 0; u < SK_FT / PH; ++u) m = fmaxf(m, ph + PH * u <= tlast ? lt[u] : -INFINITY);
+      m = fmaxf(m, ss_dpp<0xB1>(m));  // the other tiles of the row (lane ^ 1, then lane ^ 2)
+      if constexpr (PH == 4) m = fmaxf(m, ss_dpp<0x4E>(m));
+      const int row = tid / PH;
       if (row < p.B) {
 #pragma unroll
-        for (int u = 0; u < SK_FT / 2; ++u) {
-          const int tl = ph + 2 * u;
+        for (int u = 0; u < SK_FT / PH; ++u) {
+          const int tl = ph + PH * u;
           // a tile (or a whole slice) without an unmasked column weighs 0
           const float w = (tl <= tlast && lt[u] != -INFINITY) ? __expf(lt[u] - m) : 0.f;
           sk_lds_st32(fs + tl * 128 + row, __float_as_uint(w));
@@ -1104,7 +1127,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   if ((ns - 1) & 1) add_scaled(ns - 1, tB);
   else add_scaled(ns - 1, tA);
   DPRHOT_TMB(2, 2);
-#ifdef DPRHOT_TIMING
+#if defined(DPRHOT_TIMING) && DPRHOT_TIMING >= 2
   SK_LT(4);
   if (threadIdx.x == 0 && blockIdx.x < 4096) {
     // slots 3.. of this workgroup's record: accumulated ticks of the five parts of a step (the unit's end stamp moves to slot 7)
@@ -1122,13 +1145,13 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) T[(wave * 32 + a * 16 + g4 * 4 + r) * TS + b * 16 + i16] = acc[a][b][r];
+      for (int r = 0; r < 4; ++r) T[(wr * 32 + a * 16 + g4 * 4 + r) * TS + (wc * NB + b) * 16 + i16] = acc[a][b][r];
   sk_barrier();
 #pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int e = tid + it * SK_THREADS, row = e >> 4, cq = e & 15;
+  for (int it = 0; it < SK_MAXB * 16 / NT; ++it) {
+    const int e = tid + it * NT, row = e >> 4, cq = e & 15;
     if (row < p.B) {
       const float4 v = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
       if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
@@ -1142,8 +1165,13 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 // The thread pair that derives row i's logsumexp also owns row i of the Q image: it scales the row by f in place and KEEPS the
 // unscaled values; after the GEMM it adds g_i * q_i to the output row of its gold column (one row of the fp32 tile per gold column:
 // no lookup tables, no second trip to Q).  Rows that share a gold column (cnt > 1: rare) are added one after the other instead.
-template <int NG>
+template <int NG, int NW = 4>
 __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
+  constexpr int NT = NW * 64;   // threads
+  constexpr int PH = NW / 2;    // threads per query row (statistics, the kept part of the Q row)
+  constexpr int WN = NW / 2;    // waves across the 128 d columns (2 x 64 | 4 x 32), two wave rows of 64 contexts either way
+  constexpr int NBF = 8 / WN;   // 16-column groups of a wave
+  constexpr int RC = 16 / PH;   // 16-byte chunks of a Q row kept per thread
   constexpr size_t kImg = (size_t)SK_MAXB * SK_COLS;
   uint16_t* const Gs = sk_smem;         // [128 k = query row][128 m = context]: P
   uint16_t* const Qs = sk_smem + kImg;  // [128 k = query row][128 n = d column]: Q, rows scaled by f in place
@@ -1164,13 +1192,13 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   DPRHOT_TMB(1, 0);
   if (tid < SK_COLS) cnt[tid] = 0;  // (no DMA in flight yet: a plain store)
   if (tid == 0) dupf[0] = 0;
-  const int prow = min(tid >> 1, p.B - 1), ph = tid & 1;
-  SkRowStats<NG> st;
+  const int prow = min(tid / PH, p.B - 1), ph = tid % PH;
+  SkRowStats<NG * 2 / PH, PH> st;
   st.issue(p.tile_lse, p.nt, p.B, prow, ph);
   float lt = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
   float gl = sk_ld4_hidden(p.gold + prow);
   float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
-  const int nins = kmax / 4 / 4;  // per wave and image (B % 32 == 0: 2, 4, 6 or 8)
+  const int nins = kmax / 4 / NW;  // per wave and image (B % 32 == 0: 2, 4, 6 or 8 | 1..4)
   for (int j = 0; j < nins; ++j) {
     const int krow = (wave * nins + j) * 4 + (lane >> 4), pos = lane & 15;
     const int col = ((((pos >> 1) ^ mswz(krow))) << 4) + (pos & 1) * 8;
@@ -1180,14 +1208,15 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
                                      (g2_lds_ptr*)(Qs + (wave * nins + j) * 4 * SK_DN), 16, 0, 0);
   }
   DPRHOT_TMB(1, 1);
-  sk_wait_younger<4>(nins >> 1);  // 2 * nins DMAs behind the hidden loads
+  if constexpr (NW == 4) sk_wait_younger<4>(nins >> 1);  // 2 * nins DMAs behind the hidden loads
+  else sk_wait_younger<2>(nins);
   __builtin_amdgcn_sched_barrier(0);
   st.pin();
   asm volatile("" : "+v"(lt), "+v"(gl), "+v"(yf));
   const float lse = st.finish(p.nt, ph);
   const float f = __expf(lt - lse) * p.grad_scale;
   const int yrel = __float_as_int(yf) + (int)p.y_offset - n0;  // gold column relative to this tile
-  const int row = tid >> 1;
+  const int row = tid / PH;
   const bool mine = row < p.B && yrel >= 0 && yrel < nvalid;
   const float g = (__expf(gl - lse) - 1.0f) * p.grad_scale;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1196,12 +1225,12 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   // Tables first; the rows that have a gold column in this tile keep their unscaled half row (the gold term needs it).
   // (A pass in which every thread scaled its own half row read the image at a 128-byte lane stride: 8-way bank conflicts on every
   //  b128 access, 2.1 us per unit by the stamps.)
-  uint4 raw[8];
+  uint4 raw[RC];
   {
-    const uint4* base = reinterpret_cast<const uint4*>(Qs + min(row, kmax - 1) * SK_DN + ph * 64);
+    const uint4* base = reinterpret_cast<const uint4*>(Qs + min(row, kmax - 1) * SK_DN + ph * (SK_DN / PH));
     if (mine) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[j] = base[j];
+      for (int j = 0; j < RC; ++j) raw[j] = base[j];
     }
     if (ph == 0) {
       if (row < p.B) {
@@ -1227,8 +1256,8 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
     // lanes take consecutive chunks
     uint4* const img = reinterpret_cast<uint4*>(Qs);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = tid + j * SK_THREADS;
+    for (int j = 0; j < SK_MAXB * 16 / NT; ++j) {
+      const int c = tid + j * NT;
       const float fr = fi[c >> 4];
       uint4 w = img[c];
       w.x = pk_bf16(sk_bf_lo(w.x) * fr, sk_bf_hi(w.x) * fr);
@@ -1251,23 +1280,23 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
     if (unit == 0 && tid == 0) p.loss_sum[0] = lsum;
   }
   DPRHOT_TMB(1, 3);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int i16 = lane & 15, g4 = lane >> 4;
-  f32x4 acc[4][4];
+  f32x4 acc[4][NBF];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NBF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int kk = 0; kk < kmax / 32; ++kk) {
-    bf16x8 af[4], bf[4];
+    bf16x8 af[4], bf[NBF];
 #pragma unroll
     for (int a = 0; a < 4; ++a) af[a] = load_frag<128, 64, false, true>(Gs, wm * 64 + a * 16, kk, lane);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) bf[b] = load_frag<128, 64, false, true>(Qs, wn * 64 + b * 16, kk, lane);
+    for (int b = 0; b < NBF; ++b) bf[b] = load_frag<128, 64, false, true>(Qs, wn * (SK_DN / WN) + b * 16, kk, lane);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < NBF; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
   }
   __syncthreads();  // the images are dead: the fp32 tile takes their place (the tables lie behind it)
   DPRHOT_TMB(1, 4);
@@ -1275,23 +1304,24 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < NBF; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) T[(wm * 64 + a * 16 + g4 * 4 + r) * SK_DC_TS + wn * 64 + b * 16 + i16] = acc[a][b][r];
+      for (int r = 0; r < 4; ++r) T[(wm * 64 + a * 16 + g4 * 4 + r) * SK_DC_TS + wn * (SK_DN / WN) + b * 16 + i16] = acc[a][b][r];
   __syncthreads();
-  if (solo) {  // the only row with this gold column: g * q added to that output row in fp32, this thread's 64 columns
+  if (solo) {  // the only row with this gold column: g * q added to that output row in fp32, this thread's 128 / PH columns
     float* const trow0 = T + yrel * SK_DC_TS;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      // 16-byte chunk j of this thread's half of image row `row` holds the columns of 32-byte group ((4 ph + j / 2) ^ mswz(row))
-      float* const trow = trow0 + ((((ph << 2) | (j >> 1)) ^ mswz(row)) << 4) + (j & 1) * 8 - j * 8;
-      float4 a = *reinterpret_cast<const float4*>(trow + j * 8), b = *reinterpret_cast<const float4*>(trow + j * 8 + 4);
+    for (int j = 0; j < RC; ++j) {
+      // 16-byte chunk c = RC ph + j of image row `row` holds the columns of 32-byte group ((c / 2) ^ mswz(row)), half c & 1
+      const int c = ph * RC + j;
+      float* const trow = trow0 + (((c >> 1) ^ mswz(row)) << 4) + (c & 1) * 8;
+      float4 a = *reinterpret_cast<const float4*>(trow), b = *reinterpret_cast<const float4*>(trow + 4);
       a.x = fmaf(g, sk_bf_lo(raw[j].x), a.x); a.y = fmaf(g, sk_bf_hi(raw[j].x), a.y);
       a.z = fmaf(g, sk_bf_lo(raw[j].y), a.z); a.w = fmaf(g, sk_bf_hi(raw[j].y), a.w);
       b.x = fmaf(g, sk_bf_lo(raw[j].z), b.x); b.y = fmaf(g, sk_bf_hi(raw[j].z), b.y);
       b.z = fmaf(g, sk_bf_lo(raw[j].w), b.z); b.w = fmaf(g, sk_bf_hi(raw[j].w), b.w);
-      *reinterpret_cast<float4*>(trow + j * 8) = a;
-      *reinterpret_cast<float4*>(trow + j * 8 + 4) = b;
+      *reinterpret_cast<float4*>(trow) = a;
+      *reinterpret_cast<float4*>(trow + 4) = b;
     }
   }
   if (dupf[0] != 0) {  // rows that share a gold column: one after the other, ascending (bit-reproducible)
@@ -1308,8 +1338,8 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   if (p.dc_bf16) {  // 8 values per lane: whole 256-byte rows of bf16
     uint16_t* const out = static_cast<uint16_t*>(p.dC);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int e = tid + it * SK_THREADS, mrow = e >> 4, c8 = e & 15;
+    for (int it = 0; it < SK_COLS * 16 / NT; ++it) {
+      const int e = tid + it * NT, mrow = e >> 4, c8 = e & 15;
       const int m = n0 + mrow;
       if (mrow < nvalid && c0 + c8 * 8 < p.d) {
         const float4 a = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + c8 * 8);
@@ -1323,8 +1353,8 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   } else {
     float* const out = static_cast<float*>(p.dC);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int e = tid + it * SK_THREADS, mrow = e >> 5, cq = e & 31;
+    for (int it = 0; it < SK_COLS * 32 / NT; ++it) {
+      const int e = tid + it * NT, mrow = e >> 5, cq = e & 31;
       const int m = n0 + mrow;
       if (mrow < nvalid && c0 + cq * 4 < p.d) {
         float4 v = *reinterpret_cast<const float4*>(T + mrow * SK_DC_TS + cq * 4);
@@ -1338,7 +1368,7 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
   if (last_of_rank) {
     // the header rows behind this rank's real rows belong to no tile: zero gradient rows, and the loss stamp of the packed step
     const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (t / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
-    for (int e = tid; e < hdr * 32; e += SK_THREADS) {
+    for (int e = tid; e < hdr * 32; e += NT) {
       const int m = h0 + (e >> 5), cq = e & 31;
       if (c0 + cq * 4 < p.d) {
         if (p.dc_bf16) {
@@ -1423,17 +1453,20 @@ __global__ __launch_bounds__(128) void sk_dq_finish_kernel(SkFinArgs p) {
   }
 }
 
-template <int NG>
-__global__ __launch_bounds__(SK_THREADS, 2) void sk_bwdf_kernel(SkBwdFArgs p) {
+// NW = 4: 256 threads.  NW = 8: 512 threads, the same LDS, half the output tile per wave (option sk_w8).  The stamps showed a dQ
+// unit's step bound by ONE wave's instruction stream (wait, barrier, 20 LDS reads, 16 MFMAs in a dependent chain: 0.73 us, of which
+// 0.11 waiting for the slot), and two dQ workgroups sharing a CU running at the speed of one: the CU has issue room for twice the waves.
+template <int NG, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void sk_bwdf_kernel(SkBwdFArgs p) {  // (second argument: waves per SIMD, two workgroups per CU either way)
   extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
   const int b = blockIdx.x;
   const int ndq = p.nslices * (p.d / SK_QN);
   if (b < p.ndq_pad) {
     if (b >= ndq || (p.dbg & 2)) return;  // padding
-    sk_dq_unit_f<NG>(p, sk_xcd_order(b, ndq), sk_smem);
+    sk_dq_unit_f<NG, NW>(p, sk_xcd_order(b, ndq), sk_smem);
   } else {
     if (p.dbg & 1) return;
-    sk_dc_unit_f<NG>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
+    sk_dc_unit_f<NG, NW>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
   }
 }
 

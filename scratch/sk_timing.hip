@@ -1,5 +1,7 @@
 // experiment: per-workgroup wall-clock stamps of the skinny.h kernels at the cfg3-per-rank shape (build with hipcc -O3; not shipped)
-#define DPRHOT_TIMING 1
+#ifndef DPRHOT_TIMING
+#define DPRHOT_TIMING 2  // 2: with the in-loop stamps of the dQ units (12 more registers); 1: per-workgroup stamps only
+#endif
 #include <hip/hip_runtime.h>
 __device__ unsigned long long g_dprhot_tm[64];
 __device__ unsigned long long g_dprhot_tmb[4 * 4096 * 8];
@@ -13,6 +15,7 @@ int main(int argc, char** argv) {
   const bool no_g = argc > 4 && atoi(argv[4]) != 0;  // 1: G == NULL -- the plan without the dScores launch (round 4)
   if (argc > 5) dprhot_set_option("sk_dbg", atoi(argv[5]));        // 1: dC units leave at once, 2: dQ units leave at once
   if (argc > 6) dprhot_set_option("sk_dq_slices", atoi(argv[6]));  // context slices of the dQ units
+  if (argc > 7) dprhot_set_option("sk_w8", atoi(argv[7]));         // 1: eight waves per workgroup in the fused backward launch
   const int n_ctx = B * K;
   int rows_c; dprhot_packed_rows(n_ctx, d, &rows_c);
   const int Nc = W * rows_c;

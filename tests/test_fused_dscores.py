@@ -18,15 +18,19 @@ def dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(scope="module")
-def kn():
+@pytest.fixture(scope="module", params=[0, 1], ids=["4waves", "8waves"])
+def kn(request):
     from dpr_scale_amd import _lib
     from dpr_scale_amd.hotpath import HipKernels
 
-    # the plan is chosen by default only where it measured no slower (B x Nc >= 2^20); the tests run it wherever it exists
+    # the plan is chosen by default only where it measured no slower (B x Nc >= 2^20); the tests run it wherever it exists,
+    # with both workgroup shapes of the backward launch (option sk_w8)
+    w8_default = _lib.get_option("sk_w8")
     _lib.set_option("sk_fused", 2)
+    _lib.set_option("sk_w8", request.param)
     yield HipKernels()
     _lib.set_option("sk_fused", 1)
+    _lib.set_option("sk_w8", w8_default)
 
 
 def _world(W, B, K, d, dev, seed, peaky=False, dup=False, mask_frac=0.05):
