@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -149,6 +149,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured no slower (B x Nc >= 2^20: cfg3 per rank), 2 = wherever the plan exists (tests), 0 = never"},
     {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward): 1 dC units leave at once, 2 dQ units leave at once, 4 dQ units load no gold rows"},
     {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
+    {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
 };
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
 const bool g_opt_defaults = [] {
@@ -442,14 +443,24 @@ SkPlan sk_plan(int B, int Nc, int d) {
 // per rank (128 x 8256 x 768) 28.7-29.3 us against 29.3-29.6 with the dScores launch; 64 x 8256 x 512 22.6-22.9 against 21.5-21.8 and
 // 128 x 4128 x 768 24.5-24.7 against 23.2-23.3 (fewer units per launch: the longer units of this form are not covered by the launch
 // it saves).  What it always buys is accuracy: the gold terms stay in fp32 (gradients 3e-5 of max |grad| from an fp64 reference instead of 1e-3).
-struct SkFused { bool ok; int ksteps; };
-SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk, int B = 0, int Nc = 0) {
-  SkFused f{false, 0};
+struct SkFused { bool ok; int ksteps; bool pair; int tpu, ns; };  // pair: sk_bwdp_kernel with ns slices of tpu statistics tiles
+SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk, int B, int Nc, int d) {
+  SkFused f{false, 0, false, 0, 0};
   const int mode = opt(OPT_SK_FUSED);
   if (mode == 0 || (mode == 1 && (long)B * Nc < (1l << 20))) return f;
   if (!sk.ok || sk.scols != SK_COLS || nts > 128 || sk.nslices < 1 || sk.nslices > 64) return f;
   f.ksteps = cdiv(nk, sk.nslices);  // (a tiling with fewer steps may leave the last slices empty: their units write zero slabs)
   f.ok = (f.ksteps + 1) / 2 + 1 <= SK_FT;
+  if (f.ok && opt(OPT_SK_PAIR) != 0 && d % SK_QN == 0) {
+    // one workgroup per CU (152 KiB of LDS each): at most kNumCU units, at most 16 slabs (one batch of the finishing launch's loads)
+    const int ndt = d / SK_QN;
+    int maxs = kNumCU / ndt;
+    if (maxs > 16) maxs = 16;
+    if (maxs < 1) maxs = 1;
+    f.tpu = cdiv(nts, maxs);
+    f.ns = cdiv(nts, f.tpu);
+    f.pair = f.tpu <= SK_PT;
+  }
   return f;
 }
 
@@ -478,7 +489,8 @@ WsLayout ws_layout(int B, int Nc, int d) {
   }
   const DqPlan p = dq_plan(B, Nc, d);
   const SkPlan sk = sk_plan(B, Nc, d);
-  const int slabs = sk.ok && sk.nslices > p.splits ? sk.nslices : p.splits;
+  int slabs = sk.ok && sk.nslices > p.splits ? sk.nslices : p.splits;
+  if (sk.ok && slabs < 16) slabs = 16;  // (sk_bwdp_kernel: up to 16 slices)
   w.dq_part = off; off += align256((size_t)slabs * B * d * 4);
   w.total = off;
   return w;
@@ -614,7 +626,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
               g_packed.n_ctx, g_packed.row_bytes, tpr};
   // G == NULL (nobody wants the dScores): three launches -- the sim launch leaves the tile-local softmax in the logit workspace
   const int nk_f = remap ? 2 * nts : cdiv(Nc, 64);
-  const SkFused fz = sk_fused_plan(sk, nts, nk_f, B, Nc);
+  const SkFused fz = sk_fused_plan(sk, nts, nk_f, B, Nc, d);
   const bool fused = G == nullptr && S_out == nullptr && fz.ok;
   if (G == nullptr && !fused) return fail(DPRHOT_E_INVALID, "few-rows step: G == NULL needs the fused-dScores plan (dprhot_step_wants_g)");
   if (fused) {
@@ -652,14 +664,37 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       hipLaunchKernelGGL(kern, dim3((unsigned)(ndq_pad + ndc)), dim3((unsigned)threads), lds, st, b);
       return DPRHOT_OK;
     };
-    const bool w8 = opt(OPT_SK_W8) != 0;
-    if (nts <= 64) rc = w8 ? launch(sk_bwdf_kernel<8, 8>, 2, 512) : launch(sk_bwdf_kernel<8, 4>, 0, SK_THREADS);
-    else rc = w8 ? launch(sk_bwdf_kernel<16, 8>, 3, 512) : launch(sk_bwdf_kernel<16, 4>, 1, SK_THREADS);
-    if (rc) return rc;
+    static AttrOnce attr_pair[2];
+    if (fz.pair) {
+      // one kind of unit: (slice of fz.tpu statistics tiles) x (64 columns of d), one workgroup per CU
+      b.ksteps = fz.tpu;
+      b.nslices = fz.ns;
+      const size_t ldsp = sk_bwdp_lds();
+      const unsigned gridp = (unsigned)(fz.ns * (d / SK_QN));
+      if (nts <= 64) {
+        if (!attr_pair[0]) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwdp_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+          attr_pair[0] = true;
+        }
+        hipLaunchKernelGGL(sk_bwdp_kernel<8>, dim3(gridp), dim3(512), ldsp, st, b);
+      } else {
+        if (!attr_pair[1]) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(sk_bwdp_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+          attr_pair[1] = true;
+        }
+        hipLaunchKernelGGL(sk_bwdp_kernel<16>, dim3(gridp), dim3(512), ldsp, st, b);
+      }
+    } else {
+      const bool w8 = opt(OPT_SK_W8) != 0;
+      if (nts <= 64) rc = w8 ? launch(sk_bwdf_kernel<8, 8>, 2, 512) : launch(sk_bwdf_kernel<8, 4>, 0, SK_THREADS);
+      else rc = w8 ? launch(sk_bwdf_kernel<16, 8>, 3, 512) : launch(sk_bwdf_kernel<16, 4>, 1, SK_THREADS);
+      if (rc) return rc;
+    }
     HIP_TRY(hipGetLastError());
     {
       const int parts = cdiv(d / 4, 128);
-      SkFinArgs f{part, sk.nslices, fz.ksteps, nk_f, B, d, tile_lse, nts, gold, y, y_offset, Cb, grad_scale, h_scale, d_scale, dQ, parts};
+      SkFinArgs f{part, fz.pair ? fz.ns : sk.nslices, fz.ksteps, nk_f, B, d, tile_lse, nts, gold, y, y_offset, Cb, grad_scale, h_scale, d_scale, dQ, parts,
+                  fz.pair ? 1 : 0};
       hipLaunchKernelGGL(sk_dq_finish_kernel, dim3((unsigned)(B * parts)), dim3(128), 0, st, f);
       HIP_TRY(hipGetLastError());
     }
@@ -1400,7 +1435,7 @@ int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants) {
   // 0 where the few-rows plan takes the fused-dScores form -- judged on the plain column tiling: the packed layout's remapped tiles
   // are never more and their slices never longer.  A pure function of the shape, like every plan here.
   const SkPlan sk = sk_plan(B, Nc, d);
-  *h_wants = sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc).ok ? 0 : 1;
+  *h_wants = sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc, d).ok ? 0 : 1;
   return DPRHOT_OK;
 }
 
@@ -1537,7 +1572,7 @@ int dprhot_train_dq_slabs(int B, int Nc, int d, int* h_nslabs) {
   *h_nslabs = sk.ok && sk.nslices > 1 ? sk.nslices : 0;  // the other plans (and a one-slice few-rows plan) do not split dQ or combine it themselves
   // where the step can run without the dScores (dprhot_step_wants_g = 0) its slabs are slice-normalised and need the row statistics to
   // be combined: the step's own finishing launch does that, nothing is left to the caller
-  if (sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc).ok) *h_nslabs = 0;
+  if (sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc, d).ok) *h_nslabs = 0;
   return DPRHOT_OK;
 }
 

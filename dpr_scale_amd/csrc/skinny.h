@@ -327,9 +327,9 @@ struct SkGArgs {
 };
 
 // logsumexp of one row from its tile values: 64 lanes of a wave, lane l takes groups l, l + 64 (nt <= 512)
-__device__ __forceinline__ float sk_row_lse(const float* tile_lse, int nt, int B, int row, int lane) {
+// (tv: the lane's masked tile values, tiles 4 (lane + 64 u) .. + 3 -- callers that need more than the logsumexp of them)
+__device__ __forceinline__ float sk_row_lse_tv(const float* tile_lse, int nt, int B, int row, int lane, float4 (&tv)[2]) {
   const int ng = (nt + 3) >> 2;
-  float4 tv[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int gq = lane + 64 * u;
@@ -353,6 +353,10 @@ __device__ __forceinline__ float sk_row_lse(const float* tile_lse, int nt, int B
   }
   sm = wave_sum(sm);
   return mx + logf(sm);  // every lane holds the same bits (butterfly reductions)
+}
+__device__ __forceinline__ float sk_row_lse(const float* tile_lse, int nt, int B, int row, int lane) {
+  float4 tv[2];
+  return sk_row_lse_tv(tile_lse, nt, B, row, lane, tv);
 }
 
 // grid = B * parts workgroups: workgroup (row, part) turns its share of the row's logits into G.  Every wave derives the row
@@ -1401,10 +1405,12 @@ struct SkFinArgs {
   const float* d_scale;
   float* dQ;
   int parts;              // workgroups per row
+  int plain = 0;          // 1: the slabs are plain partial sums of softmax x C (sk_bwdp_kernel): every slice's factor is grad_scale
 };
 
 __global__ __launch_bounds__(128) void sk_dq_finish_kernel(SkFinArgs p) {
   __shared__ float s_e[64];
+  __shared__ float4 s_t[128];  // the row's tile values (nt <= 512)
   const int tid = threadIdx.x, lane = tid & 63;
   const int row = blockIdx.x / p.parts, part = blockIdx.x - row * p.parts;
   const int nq = p.d >> 2, q4 = part * 128 + tid;
@@ -1414,27 +1420,35 @@ __global__ __launch_bounds__(128) void sk_dq_finish_kernel(SkFinArgs p) {
   constexpr int CH = 16;
   float4 v[CH];
 #pragma unroll
-  for (int u = 0; u < CH; ++u) v[u] = part4[(size_t)min(u, p.nslices - 1) * slab4 + o4];
+  for (int u = 0; u < CH; ++u) v[u] = u < p.nslices ? part4[(size_t)u * slab4 + o4] : make_float4(0.f, 0.f, 0.f, 0.f);  // (uniform branch)
   const int yg = reinterpret_cast<const int*>(p.y)[2 * row] + (int)p.y_offset;
   const uint2 cg = *reinterpret_cast<const uint2*>(p.C + (size_t)yg * p.d + (ok ? q4 : 0) * 4);
   const float gl = p.gold[row];
-  // (the slices' references first: their loads are in flight together with the row's statistics, not behind its logsumexp)
-  float m = -INFINITY;
+  // The slices' references come from the tile values the logsumexp loads anyway, through LDS: a loop of dependent 4-byte global
+  // loads per slice thread (up to 8 L2 round trips in front of the barrier everybody waits at) was most of this launch (4.8 us).
+  float4 tv[2];
+  const float lse = sk_row_lse_tv(p.tile_lse, p.nt, p.B, row, lane, tv);
+  if (tid < 64) {
+    s_t[lane] = tv[0];
+    s_t[lane + 64] = tv[1];
+  }
+  __syncthreads();
   if (tid < p.nslices) {
     const int s0 = tid * p.ksteps, ns = min(p.ksteps, p.nk - s0);
+    float m = -INFINITY;
     if (ns > 0) {
       const int tlo = s0 >> 1, thi = min((s0 + ns - 1) >> 1, p.nt - 1);
-      for (int t = tlo; t <= thi; ++t) m = fmaxf(m, p.tile_lse[((size_t)(t >> 2) * p.B + row) * 4 + (t & 3)]);
+      const float* const st = reinterpret_cast<const float*>(s_t);
+      for (int t = tlo; t <= thi; ++t) m = fmaxf(m, st[t]);
     }
+    s_e[tid] = p.plain ? p.grad_scale : (m == -INFINITY ? 0.f : __expf(m - lse) * p.grad_scale);
   }
-  const float lse = sk_row_lse(p.tile_lse, p.nt, p.B, row, lane);
-  if (tid < p.nslices) s_e[tid] = m == -INFINITY ? 0.f : __expf(m - lse) * p.grad_scale;
   __syncthreads();
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = 0; base < p.nslices; base += CH) {
     if (base > 0) {
 #pragma unroll
-      for (int u = 0; u < CH; ++u) v[u] = part4[(size_t)min(base + u, p.nslices - 1) * slab4 + o4];
+      for (int u = 0; u < CH; ++u) v[u] = base + u < p.nslices ? part4[(size_t)(base + u) * slab4 + o4] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
@@ -1468,6 +1482,466 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sk_bwdf_kernel(SkBwdFArgs p) 
     if (p.dbg & 1) return;
     sk_dc_unit_f<NG, NW>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
   }
+}
+
+
+// =====================================================================================================================
+// Round 4, second form: the backward launch with ONE kind of unit  (sk_sim_kernel with P  ->  sk_bwdp_kernel  ->  sk_dq_finish_kernel)
+// =====================================================================================================================
+// With B <= 128 a statistics tile of P -- [B rows][128 contexts] -- is complete in BOTH directions the backward needs it: its columns
+// are all the scores of 128 contexts (dC of those contexts, given the Q columns), its rows are whole K ranges of the dQ product (a
+// partial dQ, given the same contexts' C rows).  sk_bwdf_kernel pulls every P tile through the texture path 6 + 12 times (one dC unit
+// per 128 d columns, one dQ unit per 64) and its dQ units are latency chains of 13 steps; here a unit is
+//     (slice of up to SK_PT consecutive statistics tiles) x (64 columns of d)
+// and per tile it loads P [128][128] and C [128][64] ONCE (48 KiB), scales the rows of P by f_it = exp(lse_it - lse_i) in LDS -- the
+// row softmax in bf16, what the dScores launch used to write -- and multiplies twice: dQ += P' C (accumulated over the slice's tiles
+// in registers) and dC_t = P'^T Q (stored per tile; Q [128][64] is loaded once per unit, unscaled: the gold term g_i q_i is added to
+// the staged fp32 tile from it).  The slabs are then plain partial sums: the finishing launch adds them and the gold rows of C.
+// One workgroup of eight waves per CU (152 KiB of LDS: both operands double-buffered, the next tile's DMAs fly under this tile's
+// MFMAs), 16 slices x d / 64 units (192 at d = 768).  Texture-path bytes per launch at cfg3 per rank: 71 MB against 91.
+// LDS stores next to the DMAs in flight are asm (sk_lds_st*): hipcc would drain the queue in front of each plain one.
+constexpr int SK_PT = 8;                            // statistics tiles a unit may cover (its factor table)
+constexpr int SK_P_IMG = SK_MAXB * SK_COLS;         // elements of a P tile image   [128 rows][128 contexts], 32-byte groups at g ^ mswz(row)
+constexpr int SK_P_CIMG = SK_COLS * SK_QN;          // elements of a C / Q image    [128 k][64 columns], 32-byte groups at g ^ sk_swz64(k)
+constexpr int SK_P_TS = SK_QN + 4;                  // row stride of the fp32 staging tile
+constexpr int SK_P_OFF_C = 2 * SK_P_IMG * 2;        // byte offsets: two P images | two C images | Q | staging tile | tables
+constexpr int SK_P_OFF_Q = SK_P_OFF_C + 2 * SK_P_CIMG * 2;
+constexpr int SK_P_OFF_T = SK_P_OFF_Q + SK_P_CIMG * 2;
+constexpr int SK_P_OFF_TAB = SK_P_OFF_T + SK_COLS * SK_P_TS * 4;
+constexpr int SK_P_TABLES = SK_PT * 128 * 4 + 4 * 128 * 4 + 16;  // f [SK_PT][128] | g, row loss, gold column, count [128] | flag
+inline size_t sk_bwdp_lds() { return (size_t)SK_P_OFF_TAB + SK_P_TABLES; }
+
+__device__ __forceinline__ void sk_lds_st128(void* lds_ptr, uint4 v) {
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  const unsigned addr = (unsigned)(uintptr_t)(lds_u32*)lds_ptr;
+  typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
+  const sk_u32x4 val = {v.x, v.y, v.z, v.w};
+  asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(val) : "memory");
+}
+__device__ __forceinline__ void sk_lds_add32(void* lds_ptr, unsigned v) {
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  const unsigned addr = (unsigned)(uintptr_t)(lds_u32*)lds_ptr;
+  asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// LDS READS next to the DMAs in flight are asm as well: hipcc orders a plain ds_read behind every LDS-DMA that may have written its
+// address -- s_waitcnt vmcnt(0) in front of each (seen in this kernel's first build: the next tile's DMAs were drained six times
+// per step).  The results are valid behind SK_LGKM0() only (the compiler does not know the asm is a load).
+__device__ __forceinline__ unsigned sk_lds_addr(const void* lds_ptr) {
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  return (unsigned)(uintptr_t)(lds_u32*)const_cast<void*>(lds_ptr);
+}
+typedef unsigned sk_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sk_lds_ld128_async(sk_u32x4_t& r, const void* lds_ptr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(sk_lds_addr(lds_ptr)) : "memory");
+}
+__device__ __forceinline__ void sk_lds_ld32_async(unsigned& r, const void* lds_ptr) {
+  asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(sk_lds_addr(lds_ptr)) : "memory");
+}
+#define SK_LGKM0()                                        \
+  do {                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+  } while (0)
+// transposed 8-byte read pair (rows k, k + 4 of a k-major image): the two halves of an MFMA operand fragment; OFF = byte distance of 4 rows
+template <int OFF>
+__device__ __forceinline__ void sk_tr_pair_async(bf16x4& lo, bf16x4& hi, const uint16_t* lds_ptr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(sk_lds_addr(lds_ptr)), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ bf16x8 sk_join(const bf16x4& lo, const bf16x4& hi) {
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+// SkBwdFArgs as for sk_bwdf_kernel, with ksteps = statistics tiles per unit and nslices = slices (slabs).
+template <int NG>
+__global__ __launch_bounds__(512, 2) void sk_bwdp_kernel(SkBwdFArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
+  char* const smem = reinterpret_cast<char*>(sk_smem);
+  uint16_t* const Pimg = sk_smem;
+  uint16_t* const Cimg = reinterpret_cast<uint16_t*>(smem + SK_P_OFF_C);
+  uint16_t* const Qs = reinterpret_cast<uint16_t*>(smem + SK_P_OFF_Q);
+  float* const T = reinterpret_cast<float*>(smem + SK_P_OFF_T);
+  float* const ftab = reinterpret_cast<float*>(smem + SK_P_OFF_TAB);  // [SK_PT][128]: exp(lse_it - lse_i), 0 for rows >= B
+  float* const gv = ftab + SK_PT * 128;                               // g of the row
+  float* const rl = gv + 128;                                         // row loss
+  int* const ym = reinterpret_cast<int*>(rl + 128);                   // gold column (global), or -1
+  int* const cnt = ym + 128;                                          // rows whose gold column is context m of the current tile
+  int* const dupf = cnt + 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int ndt = p.d / SK_QN;
+  const int unit = sk_xcd_order(blockIdx.x, gridDim.x);  // (the d tiles of a slice -- one P tile sequence -- on one XCD)
+  const int dt = unit % ndt, sl = unit / ndt, c0 = dt * SK_QN;
+  const int t_lo = sl * p.ksteps, ntl = min(p.ksteps, p.nt - t_lo);
+  DPRHOT_TMB(1, 0);
+
+  // ---- hidden loads first: the row's tile values (four threads per row), this slice's tile values, gold logit, label
+  const int prow = min(tid >> 2, p.B - 1), ph = tid & 3;
+  SkRowStats<NG / 2, 4> st;
+  st.issue(p.tile_lse, p.nt, p.B, prow, ph);
+  float lt[SK_PT / 4];
+#pragma unroll
+  for (int u = 0; u < SK_PT / 4; ++u) {
+    const int t = min(t_lo + ph + 4 * u, p.nt - 1);
+    lt[u] = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
+  }
+  float gl = sk_ld4_hidden(p.gold + prow);
+  float yf = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
+
+  // ---- DMA coordinates: P image pieces of 4 rows x 256 bytes (4 per wave), C / Q image pieces of 8 rows x 128 bytes (2 per wave)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  unsigned p_row[4];
+  int p_col[4], c_row[2];
+  unsigned c_col[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave * 4 + j) * 4 + (lane >> 4), pos = lane & 15;
+    p_row[j] = (unsigned)min(row, p.B - 1) * (unsigned)p.Nc;
+    p_col[j] = (((pos >> 1) ^ mswz(row)) << 4) + (pos & 1) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int krow = (wave * 2 + j) * 8 + (lane >> 3), pos = lane & 7;
+    c_row[j] = krow;
+    c_col[j] = (unsigned)(c0 + ((((pos >> 1) ^ sk_swz64(krow)) << 4) + (pos & 1) * 8));
+  }
+  auto issue_tile = [&](int t, int buf) {
+    const int n0 = sk_tile_col(p, t);
+    uint16_t* const Pd = Pimg + buf * SK_P_IMG;
+    uint16_t* const Cd = Cimg + buf * SK_P_CIMG;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.P + p_row[j] + min(n0 + p_col[j], p.Nc - 8)), (g2_lds_ptr*)(Pd + (wave_u * 4 + j) * 512), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(n0 + c_row[j], p.Nc - 1) * (unsigned)p.d + c_col[j]),
+                                       (g2_lds_ptr*)(Cd + (wave_u * 2 + j) * 512), 16, 0, 0);
+  };
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.Qb + (unsigned)min(c_row[j], p.B - 1) * (unsigned)p.d + c_col[j]),
+                                     (g2_lds_ptr*)(Qs + (wave_u * 2 + j) * 512), 16, 0, 0);
+  issue_tile(t_lo, 0);
+  DPRHOT_TMB(1, 1);
+  sk_wait_vm<8>();  // the hidden loads have landed (eight DMAs of this wave are younger)
+  __builtin_amdgcn_sched_barrier(0);
+  st.pin();
+#pragma unroll
+  for (int u = 0; u < SK_PT / 4; ++u) asm volatile("" : "+v"(lt[u]));
+  asm volatile("" : "+v"(gl), "+v"(yf));
+  const float lse = st.finish(p.nt, ph);
+  const int row = tid >> 2;
+  {
+#pragma unroll
+    for (int u = 0; u < SK_PT / 4; ++u) {
+      const int tl = ph + 4 * u;
+      const float w = (row < p.B && tl < ntl && lt[u] != -INFINITY) ? __expf(lt[u] - lse) : 0.f;
+      sk_lds_st32(ftab + tl * 128 + row, __float_as_uint(w));
+    }
+    if (ph == 0) {
+      const bool real = row < p.B;
+      const float g = (__expf(gl - lse) - 1.0f) * p.grad_scale;
+      sk_lds_st32(gv + row, __float_as_uint(real ? g : 0.f));
+      sk_lds_st32(rl + row, __float_as_uint(real ? lse - gl : 0.f));
+      sk_lds_st32(ym + row, (unsigned)(real ? __float_as_int(yf) + (int)p.y_offset : -1));
+      if (unit == 0 && real) {
+        if (p.row_loss) p.row_loss[row] = lse - gl;
+        if (p.row_lse) p.row_lse[row] = lse;
+      }
+    }
+    if (tid == 0) sk_lds_st32(dupf, 0u);
+  }
+  DPRHOT_TMB(1, 2);
+  const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
+  const bool stamp = dt == 0 && p.stamp_period > 0 && !p.dc_bf16;
+  float lsum = 0.f;
+
+  const int wr = wave >> 1, wc = wave & 1;  // both products: four groups of 32 output rows x two of 32 columns
+  f32x4 dq[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) dq[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the staged dC tile of the tile before (rows n0p .. n0p + nvp): gold rows that share a column, then the stores -- issued at the
+  // START of the next tile's step, so that the wait for that tile's operands does not wait for these stores' acknowledgements
+  auto flush_tile = [&](int tp) {
+    const int n0p = sk_tile_col(p, tp);
+    const int nvp = p.tiles_per_rank > 0 ? SK_COLS : min(SK_COLS, p.Nc - n0p);
+    unsigned dupv;
+    sk_lds_ld32_async(dupv, dupf);
+    SK_LGKM0();
+    if (dupv != 0) {  // rows that share a gold column: one after the other, ascending (bit-reproducible); rare
+      for (int i = 0; i < p.B; ++i) {
+        const int m = ym[i] - n0p;
+        if (m >= 0 && m < nvp && cnt[m] > 1) {  // (uniform: every thread reads the same table entries)
+          if (tid < SK_QN) {
+            const float qv = sk_bf_lo((unsigned)Qs[i * SK_QN + (((tid >> 4) ^ sk_swz64(i)) << 4) + (tid & 15)]);
+            sk_lds_st32(T + m * SK_P_TS + tid, __float_as_uint(fmaf(gv[i], qv, T[m * SK_P_TS + tid])));
+          }
+          sk_barrier();
+        }
+      }
+      if (tid == 0) sk_lds_st32(dupf, 0u);
+      sk_barrier();
+    }
+    if (p.dc_bf16) {
+      uint16_t* const out = static_cast<uint16_t*>(p.dC);
+      sk_u32x4_t ta[SK_COLS * 8 / 512], tb[SK_COLS * 8 / 512];
+#pragma unroll
+      for (int it = 0; it < SK_COLS * 8 / 512; ++it) {
+        const int e = tid + it * 512, mrow = e >> 3, c8 = e & 7;
+        sk_lds_ld128_async(ta[it], T + mrow * SK_P_TS + c8 * 8);
+        sk_lds_ld128_async(tb[it], T + mrow * SK_P_TS + c8 * 8 + 4);
+      }
+      SK_LGKM0();
+#pragma unroll
+      for (int it = 0; it < SK_COLS * 8 / 512; ++it) {
+        const int e = tid + it * 512, mrow = e >> 3, c8 = e & 7;
+        if (mrow < nvp) {
+          const float4 a = make_float4(__uint_as_float(ta[it][0]), __uint_as_float(ta[it][1]), __uint_as_float(ta[it][2]), __uint_as_float(ta[it][3]));
+          const float4 b = make_float4(__uint_as_float(tb[it][0]), __uint_as_float(tb[it][1]), __uint_as_float(tb[it][2]), __uint_as_float(tb[it][3]));
+          typedef unsigned sk_u4 __attribute__((ext_vector_type(4)));
+          const sk_u4 w = {pk_bf16(a.x * sc, a.y * sc), pk_bf16(a.z * sc, a.w * sc), pk_bf16(b.x * sc, b.y * sc), pk_bf16(b.z * sc, b.w * sc)};
+          sk_u4* const dst = reinterpret_cast<sk_u4*>(out + (size_t)(n0p + mrow) * p.d + c0 + c8 * 8);
+          if (p.nt_store) __builtin_nontemporal_store(w, dst);
+          else *dst = w;
+        }
+      }
+    } else {
+      float* const out = static_cast<float*>(p.dC);
+      sk_u32x4_t tv[SK_COLS * 16 / 512];
+#pragma unroll
+      for (int it = 0; it < SK_COLS * 16 / 512; ++it) {
+        const int e = tid + it * 512, mrow = e >> 4, cq = e & 15;
+        sk_lds_ld128_async(tv[it], T + mrow * SK_P_TS + cq * 4);
+      }
+      SK_LGKM0();
+#pragma unroll
+      for (int it = 0; it < SK_COLS * 16 / 512; ++it) {
+        const int e = tid + it * 512, mrow = e >> 4, cq = e & 15;
+        const int m = n0p + mrow;
+        if (mrow < nvp) {
+          float4 v = make_float4(__uint_as_float(tv[it][0]), __uint_as_float(tv[it][1]), __uint_as_float(tv[it][2]), __uint_as_float(tv[it][3]));
+          v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+          if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+          f32x4* const dst = reinterpret_cast<f32x4*>(out + (size_t)m * p.d + c0 + cq * 4);
+          if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, dst);
+          else *dst = f32x4{v.x, v.y, v.z, v.w};
+        }
+      }
+    }
+    if (p.tiles_per_rank > 0 && tp % p.tiles_per_rank == p.tiles_per_rank - 1) {
+      // the header rows behind this rank's real rows belong to no tile: zero gradient rows, and the loss stamp of the packed step
+      const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (tp / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
+      for (int e = tid; e < hdr * 16; e += 512) {
+        const int m = h0 + (e >> 4), cq = e & 15;
+        if (p.dc_bf16) {
+          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.dC) + (size_t)m * p.d + c0 + cq * 4) = make_uint2(0u, 0u);
+        } else {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (stamp && cq == 0 && m % p.stamp_period == p.stamp_row) v.x = lsum;
+          *reinterpret_cast<float4*>(static_cast<float*>(p.dC) + (size_t)m * p.d + c0 + cq * 4) = v;
+        }
+      }
+    }
+  };
+
+#if defined(DPRHOT_TIMING) && DPRHOT_TIMING >= 2
+  unsigned long long pk_[7] = {0, 0, 0, 0, 0, 0, 0}, pl_ = wall_clock64();  // thread 0's view of a tile step
+#define SK_PLT(i) do { const unsigned long long t_ = wall_clock64(); pk_[i] += t_ - pl_; pl_ = t_; } while (0)
+#else
+#define SK_PLT(i) do {} while (0)
+#endif
+  for (int ti = 0; ti < ntl; ++ti) {
+    const int t = t_lo + ti, buf = ti & 1;
+    const int n0 = sk_tile_col(p, t);
+    const int nvalid = p.tiles_per_rank > 0 ? SK_COLS : min(SK_COLS, p.Nc - n0);
+    uint16_t* const Pb = Pimg + buf * SK_P_IMG;
+    const uint16_t* const Cb = Cimg + buf * SK_P_CIMG;
+    SK_PLT(6);
+    sk_wait_vm<0>();  // this tile's operands have landed (and the stores issued in front of them are acknowledged)
+    SK_PLT(0);
+    sk_barrier();     // ... everybody's have; the tile before is multiplied, staged and patched
+    SK_PLT(1);
+    // (No DMA is in flight between here and the refill below, but hipcc cannot know: it put s_waitcnt vmcnt(0) in front of every
+    //  plain LDS read of the store loop -- each store waited for the one before it.  Every LDS access of the loop is asm.)
+    unsigned ymr_u, gr_u;
+    sk_lds_ld32_async(ymr_u, ym + row);
+    sk_lds_ld32_async(gr_u, gv + row);
+    if (ti == 0) {
+      if (stamp || unit == 0) {  // loss numerator, fixed order (every wave computes the same bits)
+        lsum = sk_loss_sum(rl, SK_MAXB, lane) * p.loss_scale;
+        if (unit == 0 && tid == 0) p.loss_sum[0] = lsum;
+      }
+    } else {
+      flush_tile(t - 1);
+    }
+    SK_PLT(2);
+    // ---- P rows x f in place (bf16 both ways; columns beyond the matrix become 0); the gold-column counts start at 0
+    {
+      uint4* const img = reinterpret_cast<uint4*>(Pb);
+      constexpr int NJ = SK_P_IMG / 8 / 512;
+      sk_u32x4_t pw[NJ];
+      unsigned fru[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = tid + j * 512;
+        sk_lds_ld128_async(pw[j], img + c);
+        sk_lds_ld32_async(fru[j], ftab + ti * 128 + (c >> 4));
+      }
+      SK_LGKM0();
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = tid + j * 512, r = c >> 4, slot = c & 15;
+        const int ctx0 = (((((slot >> 1) ^ mswz(r)) << 1) | (slot & 1))) << 3;  // first context of this 16-byte chunk
+        const float fr = __uint_as_float(fru[j]);
+        uint4 w;
+        w.x = pk_bf16(sk_bf_lo(pw[j][0]) * fr, sk_bf_hi(pw[j][0]) * fr);
+        w.y = pk_bf16(sk_bf_lo(pw[j][1]) * fr, sk_bf_hi(pw[j][1]) * fr);
+        w.z = pk_bf16(sk_bf_lo(pw[j][2]) * fr, sk_bf_hi(pw[j][2]) * fr);
+        w.w = pk_bf16(sk_bf_lo(pw[j][3]) * fr, sk_bf_hi(pw[j][3]) * fr);
+        if (ctx0 >= nvalid) w = make_uint4(0u, 0u, 0u, 0u);  // (whatever the clamped source held: not even 0 x inf)
+        sk_lds_st128(img + c, w);
+      }
+      if (tid < SK_COLS) sk_lds_st32(cnt + tid, 0u);
+    }
+    const int ymr = (int)ymr_u;  // (valid since the SK_LGKM0 above)
+    const float gr = __uint_as_float(gr_u);
+    sk_barrier();
+    SK_PLT(3);
+    if (ti + 1 < ntl) issue_tile(t + 1, buf ^ 1);  // (the other buffers: last read before this step's first barrier)
+    // ---- from here to the end of the step every LDS access is asm (the DMAs above are in flight)
+    const int yrel = ymr - n0;  // this row's gold column relative to the tile (rows >= B: far negative)
+    const bool mine = yrel >= 0 && yrel < nvalid;
+    if (mine && ph == 0) sk_lds_add32(cnt + yrel, 1u);
+    // ---- dQ += P' C  and  dC_t = P'^T Q
+    f32x4 dc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) dc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < SK_COLS / 32; ++kk) {
+      sk_u32x4_t aqr[2];
+      bf16x4 acl[2], ach[2], bql[2], bqh[2], bcl[2], bch[2];
+      const int k = kk * 32 + g4 * 8 + (i16 >> 2);  // (transposed reads: rows k and k + 4 of a k-major image)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int r = wr * 32 + a * 16 + i16, kc = kk * 4 + g4;  // 16-byte chunk kc of row r: contexts 8 kc ..
+        sk_lds_ld128_async(aqr[a], Pb + r * SK_COLS + ((((kc >> 1) ^ mswz(r)) << 1 | (kc & 1)) << 3));
+        // P as [k = query row][m = context]: the 16 contexts of block 2 wr + a
+        sk_tr_pair_async<4 * SK_COLS * 2>(acl[a], ach[a], Pb + k * SK_COLS + (((wr * 2 + a) ^ mswz(k)) << 4) + (i16 & 3) * 4);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int off = (((wc * 2 + b) ^ sk_swz64(k)) << 4) + (i16 & 3) * 4;
+        sk_tr_pair_async<4 * SK_QN * 2>(bql[b], bqh[b], Cb + k * SK_QN + off);
+        sk_tr_pair_async<4 * SK_QN * 2>(bcl[b], bch[b], Qs + k * SK_QN + off);
+      }
+      SK_LGKM0();
+      bf16x8 aq[2], ac[2], bq[2], bc[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        aq[a] = *reinterpret_cast<const bf16x8*>(&aqr[a]);
+        ac[a] = sk_join(acl[a], ach[a]);
+        bq[a] = sk_join(bql[a], bqh[a]);
+        bc[a] = sk_join(bcl[a], bch[a]);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          dq[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[a], bq[b], dq[a][b], 0, 0, 0);
+          dc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[a], bc[b], dc[a][b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sk_lds_st32(T + (wr * 32 + a * 16 + g4 * 4 + r) * SK_P_TS + (wc * 2 + b) * 16 + i16, __float_as_uint(dc[a][b][r] * p.grad_scale));
+    SK_PLT(4);
+    sk_barrier();
+    SK_PLT(5);
+    // ---- the gold term: g_i q_i added to the staged row of the row's gold column (fp32; four threads per row, 16 columns each)
+    {
+      unsigned cn = 0;
+      sk_u32x4_t qv[2], tv[4];
+      float* const trow = T + (mine ? yrel : 0) * SK_P_TS + ph * 16;
+      if (mine) {
+        sk_lds_ld32_async(cn, cnt + yrel);
+        const uint16_t* const qsrc = Qs + row * SK_QN + ((ph ^ sk_swz64(row)) << 4);
+        sk_lds_ld128_async(qv[0], qsrc);
+        sk_lds_ld128_async(qv[1], qsrc + 8);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) sk_lds_ld128_async(tv[h], trow + h * 4);
+      }
+      SK_LGKM0();
+      if (mine) {
+        if (cn == 1) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            sk_u32x4_t a = tv[2 * h], b = tv[2 * h + 1];
+            const sk_u32x4_t q = qv[h];
+            a[0] = __float_as_uint(fmaf(gr, sk_bf_lo(q[0]), __uint_as_float(a[0]))); a[1] = __float_as_uint(fmaf(gr, sk_bf_hi(q[0]), __uint_as_float(a[1])));
+            a[2] = __float_as_uint(fmaf(gr, sk_bf_lo(q[1]), __uint_as_float(a[2]))); a[3] = __float_as_uint(fmaf(gr, sk_bf_hi(q[1]), __uint_as_float(a[3])));
+            b[0] = __float_as_uint(fmaf(gr, sk_bf_lo(q[2]), __uint_as_float(b[0]))); b[1] = __float_as_uint(fmaf(gr, sk_bf_hi(q[2]), __uint_as_float(b[1])));
+            b[2] = __float_as_uint(fmaf(gr, sk_bf_lo(q[3]), __uint_as_float(b[2]))); b[3] = __float_as_uint(fmaf(gr, sk_bf_hi(q[3]), __uint_as_float(b[3])));
+            sk_lds_st128(trow + h * 8, make_uint4(a[0], a[1], a[2], a[3]));
+            sk_lds_st128(trow + h * 8 + 4, make_uint4(b[0], b[1], b[2], b[3]));
+          }
+        } else if (ph == 0) {
+          sk_lds_st32(dupf, 1u);  // (read behind the next barrier: flush_tile)
+        }
+      }
+    }
+  }
+  DPRHOT_TMB(1, 3);
+#if defined(DPRHOT_TIMING) && DPRHOT_TIMING >= 2
+  SK_PLT(6);
+  if (threadIdx.x == 0 && blockIdx.x < 4096) {  // (the records of unit kind 2 are free in this launch)
+    for (int i = 0; i < 7; ++i) g_dprhot_tmb[(2 * 4096 + blockIdx.x) * 8 + i] = pk_[i];
+    g_dprhot_tmb[(2 * 4096 + blockIdx.x) * 8 + 7] = (unsigned long long)ntl;
+  }
+#endif
+  sk_wait_vm<0>();
+  sk_barrier();
+  flush_tile(t_lo + ntl - 1);  // (its first statement is a plain LDS read: see the loop's first barrier)
+  DPRHOT_TMB(1, 4);
+  sk_barrier();  // the staging tile is free: the slab goes through it
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sk_lds_st32(T + (wr * 32 + a * 16 + g4 * 4 + r) * SK_P_TS + (wc * 2 + b) * 16 + i16, __float_as_uint(dq[a][b][r]));
+  sk_barrier();
+  {
+    float* const out = p.part + (size_t)sl * p.B * p.d;
+    sk_u32x4_t tv[SK_MAXB * 16 / 512];
+#pragma unroll
+    for (int it = 0; it < SK_MAXB * 16 / 512; ++it) {
+      const int e = tid + it * 512;
+      sk_lds_ld128_async(tv[it], T + (e >> 4) * SK_P_TS + (e & 15) * 4);
+    }
+    SK_LGKM0();
+#pragma unroll
+    for (int it = 0; it < SK_MAXB * 16 / 512; ++it) {
+      const int e = tid + it * 512, r = e >> 4, cq = e & 15;
+      if (r < p.B) {
+        const f32x4 v = {__uint_as_float(tv[it][0]), __uint_as_float(tv[it][1]), __uint_as_float(tv[it][2]), __uint_as_float(tv[it][3])};
+        f32x4* const dst = reinterpret_cast<f32x4*>(out + (size_t)r * p.d + c0 + cq * 4);
+        if (p.nt_store) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
+      }
+    }
+  }
+  DPRHOT_TMB(1, 5);
 }
 
 }  // namespace dprhot

@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
   if (argc > 5) dprhot_set_option("sk_dbg", atoi(argv[5]));        // 1: dC units leave at once, 2: dQ units leave at once
   if (argc > 6) dprhot_set_option("sk_dq_slices", atoi(argv[6]));  // context slices of the dQ units
   if (argc > 7) dprhot_set_option("sk_w8", atoi(argv[7]));         // 1: eight waves per workgroup in the fused backward launch
+  if (argc > 8) dprhot_set_option("sk_pair", atoi(argv[8]));       // 1: one kind of unit (sk_bwdp_kernel; its stamps print as "dc")
   const int n_ctx = B * K;
   int rows_c; dprhot_packed_rows(n_ctx, d, &rows_c);
   const int Nc = W * rows_c;
@@ -72,6 +73,18 @@ int main(int argc, char** argv) {
       }
     }
   }
+  int pair_on = 0; dprhot_get_option("sk_pair", &pair_on);
+  if (no_g && pair_on) {  // the one-kind units' tile steps (thread 0 of each unit): accumulated time of the parts of a step
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0}, steps = 0; int nb = 0;
+    for (int b = 0; b < 4096; ++b) {
+      const unsigned long long* r2 = &t[((size_t)2 * 4096 + b) * 8];
+      if (!r2[7]) continue;
+      ++nb; steps += (double)r2[7];
+      for (int i = 0; i < 7; ++i) acc[i] += r2[i] * 0.01;
+    }
+    if (nb) printf("one-kind units, per tile step (us, avg over %d units x %.1f steps): wait for the operands %.3f | barrier %.3f | stores of the tile before %.3f | scale P + barrier %.3f | refill + products + staging %.3f | barrier %.3f | gold rows %.3f\n",
+                   nb, steps / nb, acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps, acc[6] / steps);
+  } else
   if (no_g) {  // inside the fused dQ units' loop (thread 0 of each unit): accumulated time of the five parts of a step
     double acc[5] = {0, 0, 0, 0, 0}, steps = 0; int nb = 0;
     for (int b = 0; b < 4096; ++b) {

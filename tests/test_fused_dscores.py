@@ -18,19 +18,21 @@ def dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["4waves", "8waves"])
+@pytest.fixture(scope="module", params=[(0, 0), (1, 0), (1, 1)], ids=["two-kinds-4waves", "two-kinds-8waves", "one-kind"])
 def kn(request):
     from dpr_scale_amd import _lib
     from dpr_scale_amd.hotpath import HipKernels
 
-    # the plan is chosen by default only where it measured no slower (B x Nc >= 2^20); the tests run it wherever it exists,
-    # with both workgroup shapes of the backward launch (option sk_w8)
-    w8_default = _lib.get_option("sk_w8")
+    # the plan is chosen by default only where it measured no slower (B x Nc >= 2^20); the tests run it wherever it exists, in
+    # every form of the backward launch: dQ units + dC units with four or eight waves (sk_bwdf_kernel, option sk_w8), and the one
+    # kind of unit that multiplies a P tile both ways (sk_bwdp_kernel, option sk_pair)
+    defaults = {k: _lib.get_option(k) for k in ("sk_fused", "sk_w8", "sk_pair")}
     _lib.set_option("sk_fused", 2)
-    _lib.set_option("sk_w8", request.param)
+    _lib.set_option("sk_w8", request.param[0])
+    _lib.set_option("sk_pair", request.param[1])
     yield HipKernels()
-    _lib.set_option("sk_fused", 1)
-    _lib.set_option("sk_w8", w8_default)
+    for k, v in defaults.items():
+        _lib.set_option(k, v)
 
 
 def _world(W, B, K, d, dev, seed, peaky=False, dup=False, mask_frac=0.05):
