@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -150,6 +150,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward): 1 dC units leave at once, 2 dQ units leave at once, 4 dQ units load no gold rows"},
     {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
     {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
+    {"sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},
 };
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
 const bool g_opt_defaults = [] {
@@ -586,7 +587,19 @@ int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
 template <int NCH, int COLS, int SLOTS>
 int launch_sk_sim_c(const SkSimArgs& a, int grid, hipStream_t st) {
   const size_t lds = sk_sim_lds();
-  static AttrOnce attr_done[2];  // benign race: idempotent
+  static AttrOnce attr_done[3];  // benign race: idempotent
+  if constexpr (COLS == SK_COLS) {
+    if (a.q != nullptr && opt(OPT_SK_SIM_W8) != 0) {
+      auto kern = sk_sim_kernel<NCH, true, COLS, SLOTS, 8>;
+      if (!attr_done[2]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done[2] = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
+      HIP_TRY(hipGetLastError());
+      return DPRHOT_OK;
+    }
+  }
   if (a.q != nullptr) {
     auto kern = sk_sim_kernel<NCH, true, COLS, SLOTS>;
     if (!attr_done[0]) {

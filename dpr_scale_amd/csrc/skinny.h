@@ -107,15 +107,24 @@ inline size_t sk_sim_lds() { return (size_t)SK_ASTAGE * 2 + (size_t)SK_SLOTS * S
 // LDS = 72 KiB -> two workgroups per CU: all units of cfg3 per rank (4 x 64 = 256 with tiles_per_rank, else 260) are resident at once, and one
 // workgroup's MFMA / epilogue overlaps the other's loads.
 // COLS = columns of a unit (128 with SLOTS = 4 ring slots, or 64 with 8): every wave multiplies COLS / 4 of them.
-template <int NCH, bool A_F32, int COLS = SK_COLS, int SLOTS = SK_SLOTS>
-__global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
+// NW = 8 (512 threads; 128-column units of the training path): two wave rows of 16 query rows each, the q rows' k chunks dealt to the
+// two thread halves, 16 threads per row in the statistics phase -- half the instruction stream per wave where one wave per SIMD had
+// nothing to hide its latencies behind.
+template <int NCH, bool A_F32, int COLS = SK_COLS, int SLOTS = SK_SLOTS, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void sk_sim_kernel(SkSimArgs p) {
   extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
   constexpr int D = NCH * SK_KC;
-  constexpr int IPC = COLS * SK_KC * 2 / 1024 / 4;  // DMA instructions per wave and ring slot (4 / 2)
+  constexpr int NT = NW * 64;
+  constexpr int WR = NW / 4;  // wave rows (1: a wave multiplies all 32 query rows; 2: 16 each)
+  constexpr int NA = 2 / WR;  // 16-row blocks per wave
+  constexpr int NQ = NCH / WR;  // k chunks of the q rows a thread holds (chunk i * WR + tid / 256)
+  static_assert(NCH % WR == 0, "k chunks per thread half");
+  constexpr int IPC = COLS * SK_KC * 2 / 1024 / NW;  // DMA instructions per wave and ring slot
   constexpr int CPW = COLS / 4, NB = CPW / 16;       // columns per wave, 16-column MFMA blocks per wave
   uint16_t* const Ast = sk_smem;                      // 2 x [32][64]: 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
   uint16_t* const ring = sk_smem + SK_ASTAGE;         // SLOTS x [COLS n][64 k], same swizzle
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave & 3, wr = wave >> 2, kh = tid >> 8;
   const int nrb = (p.B + SK_ROWS - 1) / SK_ROWS;
   const int unit = sk_xcd_order(blockIdx.x, gridDim.x);
   const int rb = unit % nrb, ct = unit / nrb;
@@ -125,23 +134,25 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
 
   // ---- every global read of the unit's first phase, back to back: the q rows (registers: thread t holds the 8 values
   //      k = kc * 64 + (t & 7) * 8 .. of row t >> 3 for every k chunk kc), the first ring slots, mask bytes, labels
-  const int arow = tid >> 3, ac8 = tid & 7;
-  uint4 areg[NCH][A_F32 ? 2 : 1];
+  const int arow = (tid & 255) >> 3, ac8 = tid & 7;
+  uint4 areg[NQ][A_F32 ? 2 : 1];
   {
     const int gr = min(m0 + arow, p.B - 1);
 #pragma unroll
-    for (int kc = 0; kc < NCH; ++kc) {
+    for (int i = 0; i < NQ; ++i) {
+      const int kc = i * WR + kh;
       if constexpr (A_F32) {
         const float* src = p.q + (size_t)gr * D + kc * SK_KC + ac8 * 8;
-        areg[kc][0] = *reinterpret_cast<const uint4*>(src);
-        areg[kc][1] = *reinterpret_cast<const uint4*>(src + 4);
+        areg[i][0] = *reinterpret_cast<const uint4*>(src);
+        areg[i][1] = *reinterpret_cast<const uint4*>(src + 4);
       } else {
-        areg[kc][0] = *reinterpret_cast<const uint4*>(p.Qin + (size_t)gr * D + kc * SK_KC + ac8 * 8);
+        areg[i][0] = *reinterpret_cast<const uint4*>(p.Qin + (size_t)gr * D + kc * SK_KC + ac8 * 8);
       }
     }
   }
   const int i16 = lane & 15, g4 = lane >> 4;
-  const int srow = tid >> 3, sseg = tid & 7;  // statistics / store phase: 8 threads per row
+  constexpr int TPR = NT / SK_ROWS;            // statistics / store phase: threads per row (8 | 16)
+  const int srow = tid / TPR, sseg = tid % TPR;
 
   unsigned cof[IPC];  // element offset of this lane's source chunk inside a k chunk, per DMA instruction (8 rows of 128 bytes)
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
   bool mover[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
-    const int n = min(n0 + wave * CPW + nb * 16 + i16, p.Nc - 1);
+    const int n = min(n0 + wc * CPW + nb * 16 + i16, p.Nc - 1);
     const int rc = p.packed != nullptr ? p.p_rows_c : 1;
     const int r = n / rc, j = n - r * rc;
     mover[nb] = p.packed != nullptr && j >= p.p_n_ctx;  // mask / padding rows of the packed buffer: always masked
@@ -182,35 +193,35 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
 
   DPRHOT_TMB(0, 1);
   // ---- q rows -> bf16, kept in registers (and written to Qb); one k chunk at a time goes to LDS inside the K loop
-  uint4 abf[NCH];
+  uint4 abf[NQ];
 #pragma unroll
-  for (int kc = 0; kc < NCH; ++kc) {
+  for (int i = 0; i < NQ; ++i) {
     if constexpr (A_F32) {
-      const uint4 a = areg[kc][0], b = areg[kc][1];
-      abf[kc] = make_uint4(pack_bf16_rne(a.x, a.y), pack_bf16_rne(a.z, a.w), pack_bf16_rne(b.x, b.y), pack_bf16_rne(b.z, b.w));
+      const uint4 a = areg[i][0], b = areg[i][1];
+      abf[i] = make_uint4(pack_bf16_rne(a.x, a.y), pack_bf16_rne(a.z, a.w), pack_bf16_rne(b.x, b.y), pack_bf16_rne(b.z, b.w));
       if (p.Qb != nullptr && ct == 0 && m0 + arow < p.B)
-        *reinterpret_cast<uint4*>(p.Qb + (size_t)(m0 + arow) * D + kc * SK_KC + ac8 * 8) = abf[kc];
+        *reinterpret_cast<uint4*>(p.Qb + (size_t)(m0 + arow) * D + (i * WR + kh) * SK_KC + ac8 * 8) = abf[i];
     } else {
-      abf[kc] = areg[kc][0];
+      abf[i] = areg[i][0];
     }
   }
   DPRHOT_TMB(0, 2);
-  f32x4 acc[2][NB];
+  f32x4 acc[NA][NB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     uint16_t* const Ac = Ast + (c & 1) * (SK_ROWS * SK_KC);
-    {
+    if (WR == 1 || (c % WR) == kh) {  // (the thread half that holds this k chunk)
       // asm store: hipcc orders a plain LDS store behind every LDS-DMA in flight with s_waitcnt vmcnt(0) (it cannot tell the
       // q image from the ring slots), which would drain the ring at every chunk; sk_barrier() below waits lgkmcnt(0)
       typedef __attribute__((address_space(3))) uint16_t lds_u16;
       const unsigned addr = (unsigned)(uintptr_t)(lds_u16*)(Ac + arow * SK_KC + ((ac8 ^ ((arow >> 1) & 7)) << 3));
       typedef unsigned sk_u32x4 __attribute__((ext_vector_type(4)));
-      const sk_u32x4 val = {abf[c].x, abf[c].y, abf[c].z, abf[c].w};
+      const sk_u32x4 val = {abf[c / WR].x, abf[c / WR].y, abf[c / WR].z, abf[c / WR].w};
       asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(val) : "memory");
     }
     sk_wait_younger<IPC>(min(c + SLOTS - 2, NCH - 1) - c);  // this wave's share of chunk c has landed
@@ -219,19 +230,19 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     const uint16_t* Bs = ring + (c % SLOTS) * (COLS * SK_KC);
 #pragma unroll
     for (int kk = 0; kk < SK_KC / 32; ++kk) {
-      bf16x8 af[2], bf[NB];
+      bf16x8 af[NA], bf[NB];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int row = a * 16 + i16;
+      for (int a = 0; a < NA; ++a) {
+        const int row = (wr * NA + a) * 16 + i16;
         af[a] = *reinterpret_cast<const bf16x8*>(Ac + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
       }
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const int row = wave * CPW + b * 16 + i16;
+        const int row = wc * CPW + b * 16 + i16;
         bf[b] = *reinterpret_cast<const bf16x8*>(Bs + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NA; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
@@ -241,16 +252,16 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
 
   // ---- epilogue: mask, 1/T -> LDS tile -> per-row tile logsumexp, gold logit, coalesced fp32 store
   constexpr int TS = COLS + 4;
-  constexpr int QD = COLS / 32;  // float4 runs per thread in the statistics / store phase (8 threads per row)
+  constexpr int QD = COLS / 4 / TPR;  // float4 runs per thread in the statistics / store phase
   float* const T = reinterpret_cast<float*>(ring);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int col = wave * CPW + b * 16 + i16;
+    const int col = wc * CPW + b * 16 + i16;
     const bool masked = (n0 + col >= p.Nc) || mover[b] || (have_mask && mraw[b] != 0);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) T[(a * 16 + g4 * 4 + r) * TS + col] = masked ? -INFINITY : acc[a][b][r] * p.inv_T;
+      for (int r = 0; r < 4; ++r) T[((wr * NA + a) * 16 + g4 * 4 + r) * TS + col] = masked ? -INFINITY : acc[a][b][r] * p.inv_T;
   }
   sk_barrier();
   {
@@ -260,10 +271,11 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
     float mx = -INFINITY;
 #pragma unroll
     for (int qd = 0; qd < QD; ++qd) {
-      v[qd] = *reinterpret_cast<const float4*>(T + srow * TS + (qd * 8 + sseg) * 4);
+      v[qd] = *reinterpret_cast<const float4*>(T + srow * TS + (qd * TPR + sseg) * 4);
       mx = fmaxf(mx, fmaxf(fmaxf(v[qd].x, v[qd].y), fmaxf(v[qd].z, v[qd].w)));
     }
     mx = ss_max8(mx);
+    if constexpr (TPR == 16) mx = fmaxf(mx, ss_dpp<0x140>(mx));  // row_mirror: the other eight lanes of the row
     float sm = 0.f;
     float4 e[QD];  // exp(v - max): summed here, stored (scaled) as the tile softmax below -- one exponential per score
     if (mx != -INFINITY) {
@@ -277,12 +289,13 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
       for (int qd = 0; qd < QD; ++qd) e[qd] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     sm = ss_sum8(sm);
+    if constexpr (TPR == 16) sm += ss_dpp<0x140>(sm);
     if (row < p.B) {
       if (sseg == 0) p.tile_lse[((size_t)(ct >> 2) * p.B + row) * 4 + (ct & 3)] = mx == -INFINITY ? -INFINITY : mx + logf(sm);
       const float inv = sm > 0.f ? 1.0f / sm : 0.f;  // (a tile whose columns are all masked: every probability is 0)
 #pragma unroll
       for (int qd = 0; qd < QD; ++qd) {
-        const int col = (qd * 8 + sseg) * 4;
+        const int col = (qd * TPR + sseg) * 4;
         if (p.S != nullptr && n0 + col < p.Nc) *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col) = v[qd];
         if (yi >= col && yi < col + 4) p.gold[row] = yi == col ? v[qd].x : (yi == col + 1 ? v[qd].y : (yi == col + 2 ? v[qd].z : v[qd].w));
         if (p.P != nullptr && n0 + col < p.Nc) {
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(SK_THREADS, 2) void sk_sim_kernel(SkSimArgs p) {
   if (p.tiles_per_rank > 0 && ct % p.tiles_per_rank == p.tiles_per_rank - 1) {
     // the header rows behind this rank's real rows: masked columns of the logit matrix
     const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (ct / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
-    for (int i = tid; i < SK_ROWS * hdr; i += SK_THREADS) {
+    for (int i = tid; i < SK_ROWS * hdr; i += NT) {
       const int row = m0 + i / hdr;
       if (row < p.B) {
         if (p.S != nullptr) p.S[(size_t)row * p.Nc + h0 + i % hdr] = -INFINITY;

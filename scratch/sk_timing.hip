@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
   if (argc > 5) dprhot_set_option("sk_dbg", atoi(argv[5]));        // 1: dC units leave at once, 2: dQ units leave at once
   if (argc > 6) dprhot_set_option("sk_dq_slices", atoi(argv[6]));  // context slices of the dQ units
   if (argc > 7) dprhot_set_option("sk_w8", atoi(argv[7]));         // 1: eight waves per workgroup in the fused backward launch
+  if (argc > 9) dprhot_set_option("sk_sim_w8", atoi(argv[9]));     // 0: four waves per workgroup in the sim launch
   if (argc > 8) dprhot_set_option("sk_pair", atoi(argv[8]));       // 1: one kind of unit (sk_bwdp_kernel; its stamps print as "dc")
   const int n_ctx = B * K;
   int rows_c; dprhot_packed_rows(n_ctx, d, &rows_c);
