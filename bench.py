@@ -384,7 +384,9 @@ def operator_block(dev, d=768):
     """What TRAINING runs (dpr_task.py:153-214 under AMP): hotpath.inbatch_contrastive_loss forward + (loss * 1024).backward() --
     the autograd operator with a non-unit grad_output -- next to the bare C-ABI step of the same shape, at cfg2 (B 32 x 256 contexts)
     and at the cfg3-per-rank shape (B 128 x 8192 contexts).  HIP events; `graph` = ten steps per HIP graph (device time), `eager` =
-    one Python call per step (host-bound at these sizes)."""
+    one Python call per step (host-bound at these sizes).  `autograd_floor_eager_us`: the same forward + backward(grad) call pattern
+    around a Python autograd.Function that launches nothing (`..._cpp_node_...`: around a C++ node that launches nothing -- the floor
+    of the operator's own node); `four_torch_launches_eager_us`: four in-place adds on 8 floats."""
     from dpr_scale_amd import hotpath
     from dpr_scale_amd.datamodule.synthetic import unit_logit_embeddings
 
@@ -403,10 +405,52 @@ def operator_block(dev, d=768):
             loss.backward(scale)
 
         g_us, e_us = _time_python_step(op_step)
+
+        # What the eager number is made of that no operator can avoid: torch's autograd machinery around a Python Function that launches
+        # NOTHING (same call pattern, gradients from the caching allocator), and the host cost of the step's launches by themselves.
+        class _Floor(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, a, b):
+                ctx.shapes = (a.shape, b.shape)
+                return torch.empty((), device=a.device)
+
+            @staticmethod
+            def backward(ctx, go):
+                return torch.empty(ctx.shapes[0], device=go.device), torch.empty(ctx.shapes[1], device=go.device)
+
+        def floor_step():
+            tq.grad = None
+            tc.grad = None
+            _Floor.apply(tq, tc).backward(scale)
+
+        one = torch.zeros(8, device=dev)
+
+        def launches_step(n=4):  # (the operator's step is three or four library launches + one in backward)
+            for _ in range(n):
+                one.add_(1.0)
+
+        for _ in range(5):
+            floor_step()
+            launches_step()
+        floor_us = _event_us(floor_step, 120)
+        cfloor_us = None
+        if getattr(hotpath, "_OPX_NODE", False) and hasattr(hotpath._OPX, "floor_loss"):
+            def cfloor_step():
+                tq.grad = None
+                tc.grad = None
+                hotpath._OPX.floor_loss(tq, tc).backward(scale)
+
+            for _ in range(5):
+                cfloor_step()
+            cfloor_us = _event_us(cfloor_step, 120)
+        launch_us = _event_us(launches_step, 120)
         hp = HotPathStep(B, K, d, 1.0, 1, 0, dev)
         abi = time_kernel(hp, hp.k_step, reps=10, iters=30)
         out[name] = {"shape": f"B={B} x Nc={B * K} x d={d}", "operator_graph_us": None if g_us is None else round(g_us, 2),
-                     "operator_eager_us": round(e_us, 2), "c_abi_step_us": round(abi, 2),
+                     "operator_eager_us": round(e_us, 2), "autograd_floor_eager_us": round(floor_us, 2),
+                     "autograd_floor_cpp_node_eager_us": None if cfloor_us is None else round(cfloor_us, 2),
+                     "operator_node": "C++ (csrc/opx.cpp: InBatchFn)" if getattr(hotpath, "_OPX_NODE", False) else "Python (hotpath.InBatchContrastive)",
+                     "four_torch_launches_eager_us": round(launch_us, 2), "c_abi_step_us": round(abi, 2),
                      "operator_minus_c_abi_us": None if g_us is None else round(g_us - abi, 2),
                      "operator_over_c_abi": None if g_us is None else round(g_us / abi, 3)}
         del hp

@@ -120,6 +120,110 @@ std::vector<at::Tensor> rescale(const at::Tensor& dQ, const c10::optional<at::Te
   return {out2, out2.narrow(0, 1, 1)};
 }
 
+// ---- the operator itself as a C++ autograd node (forward + backward without a Python frame) ----------------------------------
+// InBatchContrastive (hotpath.py) keeps every other case; this node is what a single-GPU training step runs: the gradients are
+// computed by the forward call for the grad_output the previous backward saw (a device scalar per (device, B, Nc, d)), backward
+// compares and rescales in one launch (dprhot_rescale_grads) and hands the tensors to autograd without keeping a reference --
+// AccumulateGrad takes a gradient nobody else holds as .grad itself instead of cloning it.
+std::map<std::tuple<int, int, int, int>, at::Tensor> g_scale;  // (device, B, Nc, d) -> [1] fp32: expected grad_output
+py::object* g_regen = nullptr;  // Python: second backward through a retained graph (hotpath._opx_regen); leaked on purpose (interpreter exit)
+
+at::Tensor scale_get(const at::Device& dev, int B, int Nc, int d) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  at::Tensor& t = g_scale[std::make_tuple((int)dev.index(), B, Nc, d)];
+  if (!t.defined()) t = at::ones({1}, at::TensorOptions().dtype(at::kFloat).device(dev));
+  return t;
+}
+void scale_put(const at::Device& dev, int B, int Nc, int d, const at::Tensor& t) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_scale[std::make_tuple((int)dev.index(), B, Nc, d)] = t;
+}
+
+struct InBatchFn : public torch::autograd::Function<InBatchFn> {
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& q, const at::Tensor& c, const at::Tensor& pos_idx,
+                            const at::Tensor& mask, double inv_T, int64_t epoch) {
+    const int B = (int)q.size(0), d = (int)q.size(1), Nc = (int)c.size(0);
+    const at::Tensor used = scale_get(q.device(), B, Nc, d);
+    std::vector<at::Tensor> out = train_step(q, c, pos_idx, mask, inv_T, inv_T / B, 1.0 / B, used, epoch);
+    auto& sd = ctx->saved_data;
+    sd["dQ"] = out[2];
+    sd["dC"] = out[3];
+    if (out[7].defined()) sd["part"] = out[7];
+    sd["used"] = used;
+    sd["Qb"] = out[4];  // (what a second backward through a retained graph recomputes from)
+    sd["Cb"] = out[5];
+    if (out[6].defined()) sd["G"] = out[6];
+    sd["pos"] = pos_idx;
+    sd["mask"] = mask;
+    sd["inv_T"] = inv_T;
+    return out[0].select(0, 0);
+  }
+
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list gos) {
+    auto& sd = ctx->saved_data;
+    at::Tensor go = gos[0];
+    if (go.scalar_type() != at::kFloat || !go.is_contiguous()) go = go.detach().to(at::kFloat).contiguous();
+    const bool need_dq = ctx->needs_input_grad(0), need_dc = ctx->needs_input_grad(1);
+    at::Tensor dQ, dC;
+    const at::Tensor Qb = sd["Qb"].toTensor(), Cb = sd["Cb"].toTensor();
+    const int B = (int)Qb.size(0), d = (int)Qb.size(1), Nc = (int)Cb.size(0);
+    if (sd.find("dQ") != sd.end()) {
+      dQ = sd["dQ"].toTensor();
+      dC = sd["dC"].toTensor();
+      c10::optional<at::Tensor> part;
+      if (sd.find("part") != sd.end()) part = sd["part"].toTensor();
+      const at::Tensor used = sd["used"].toTensor();
+      sd.erase("dQ");
+      sd.erase("dC");
+      sd.erase("part");
+      sd.erase("used");
+      std::vector<at::Tensor> r = rescale(dQ, part, dC, go, used, need_dq, need_dc);
+      scale_put(go.device(), B, Nc, d, r[1]);
+    } else {
+      // a second backward through a retained graph: the first one gave its gradient tensors away; the backward GEMMs run again on
+      // the operands the step left behind (exact, rare) -- in Python, where the general kernels' wrappers live
+      TORCH_CHECK(g_regen != nullptr, "opx: no regeneration callback registered (hotpath sets it at import)");
+      py::gil_scoped_acquire gil;
+      const double inv_T = sd["inv_T"].toDouble();
+      py::object G = sd.find("G") != sd.end() ? py::cast(sd["G"].toTensor()) : py::none();
+      py::tuple res = (*g_regen)(Qb, Cb, G, sd["pos"].toTensor(), sd["mask"].toTensor(), inv_T, inv_T / B, go, need_dq, need_dc);
+      if (!res[0].is_none()) dQ = res[0].cast<at::Tensor>();
+      if (!res[1].is_none()) dC = res[1].cast<at::Tensor>();
+      sd["G"] = res[2].cast<at::Tensor>();
+    }
+    return {need_dq ? dQ : at::Tensor(), need_dc ? dC : at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+  }
+};
+
+// None when the step is not the plain single-rank fp32 one (the caller then takes InBatchContrastive).
+c10::optional<at::Tensor> inbatch_loss(const at::Tensor& q, const at::Tensor& c, const at::Tensor& pos_idx, const at::Tensor& mask, double inv_T,
+                                       int64_t options_epoch) {
+  const bool ok = q.is_cuda() && c.is_cuda() && pos_idx.is_cuda() && mask.is_cuda() && q.dim() == 2 && c.dim() == 2 && q.scalar_type() == at::kFloat &&
+                  c.scalar_type() == at::kFloat && q.is_contiguous() && c.is_contiguous() && c.size(1) == q.size(1) && c.size(0) % 8 == 0 &&
+                  q.size(1) % 8 == 0 && mask.is_contiguous() && mask.element_size() == 1 && mask.numel() == c.size(0) &&
+                  pos_idx.scalar_type() == at::kLong && pos_idx.is_contiguous() && pos_idx.numel() == q.size(0) &&
+                  (q.requires_grad() || c.requires_grad()) && at::GradMode::is_enabled();
+  if (!ok) return c10::nullopt;
+  return InBatchFn::apply(q, c, pos_idx, mask, inv_T, options_epoch);
+}
+
+void set_regen(py::object fn) { g_regen = new py::object(std::move(fn)); }
+
+// Measurement probe (bench.py, operator block): the same node shape -- two differentiable inputs, a scalar output, fresh gradient
+// tensors from the caching allocator -- that launches NOTHING.  What remains is torch's autograd machinery for a C++ node.
+struct FloorFn : public torch::autograd::Function<FloorFn> {
+  static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& q, const at::Tensor& c) {
+    ctx->saved_data["qs"] = q.sizes().vec();
+    ctx->saved_data["cs"] = c.sizes().vec();
+    return at::empty({}, q.options());
+  }
+  static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list gos) {
+    const auto opt = gos[0].options();
+    return {at::empty(ctx->saved_data["qs"].toIntVector(), opt), at::empty(ctx->saved_data["cs"].toIntVector(), opt)};
+  }
+};
+at::Tensor floor_loss(const at::Tensor& q, const at::Tensor& c) { return FloorFn::apply(q, c); }
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -127,4 +231,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("init", &init);
   m.def("train_step", &train_step);
   m.def("rescale", &rescale);
+  m.def("inbatch_loss", &inbatch_loss);
+  m.def("set_regen", &set_regen);
+  m.def("floor_loss", &floor_loss);
 }

@@ -840,8 +840,30 @@ def _pad_hidden(q, c):
     return torch.nn.functional.pad(q, (0, pad)), torch.nn.functional.pad(c, (0, pad))
 
 
+def _opx_regen(Qb, Cb, G, pos_idx, mask, inv_T, grad_scale, go, need_dq, need_dc):
+    """Second backward through a retained graph of the C++ node (csrc/opx.cpp: InBatchFn::backward): the backward GEMMs again, on the
+    operands the step left behind; the dScores are recomputed first where the step never materialised them."""
+    kn = default_kernels()
+    if G is None:
+        G = kn.inbatch_fwd(Qb, Cb, pos_idx, 0, mask.view(torch.uint8) if mask.dtype == torch.bool else mask, inv_T, grad_scale)[3]
+    dQ, dC = kn.inbatch_bwd(G, Qb, Cb, 1.0, go.reshape(1), need_dq, need_dc)
+    return dQ, dC, G
+
+
+_OPX_NODE = _OPX is not None and hasattr(_OPX, "inbatch_loss") and os.environ.get("DPRHOT_OPX_NODE", "1") != "0"
+if _OPX_NODE:
+    _OPX.set_regen(_opx_regen)
+
+
 def inbatch_contrastive_loss(q, c, pos_idx, ctx_mask, temperature=1.0, group=None, kernels=None, gather=None, pending=None):
     if gather is None:
+        if (_OPX_NODE and kernels is None and q.is_cuda and (group is False or D.world(group)[0] == 1) and not _fp32_g_mode()
+                and not (D.force_dist() and group is not False)):
+            # the plain single-rank fp32 step: a C++ autograd node (csrc/opx.cpp), no Python frame in forward or backward
+            # (DPRHOT_OPX_NODE=0: InBatchContrastive's own fast path, the same two library calls from Python)
+            loss = _OPX.inbatch_loss(q, c, pos_idx, ctx_mask, 1.0 / float(temperature), default_kernels()._lib.options_epoch())
+            if loss is not None:
+                return loss
         q, c = _pad_hidden(q, c)
     return InBatchContrastive.apply(q, c, pos_idx, ctx_mask, temperature, group, kernels, gather, pending)
 

@@ -1313,3 +1313,38 @@ def test_packed_skinny_step_tiles_over_real_rows(W, B, K, d, kn, dev):
             stamped[k * rows_c + n_ctx, 0] = 0.0
         assert ((stamped - dc_ref).abs().max() / dc_ref.abs().max()).item() <= 2e-3
         assert torch.all(stamped.view(W, rows_c, d)[:, n_ctx:] == 0)  # header rows: their columns of G are exactly 0
+
+
+@pytest.mark.gpu
+def test_cpp_autograd_node_equals_the_python_operator(dev):
+    """hotpath.inbatch_contrastive_loss runs the plain single-rank fp32 step as a C++ autograd node (csrc/opx.cpp: InBatchFn); the
+    Python operator (InBatchContrastive, every other case) makes the same two library calls: same bits, for a unit and a non-unit
+    grad_output, and for a second backward through a retained graph."""
+    from dpr_scale_amd import hotpath
+
+    if not getattr(hotpath, "_OPX_NODE", False):
+        pytest.skip("the optional host extension _opx.so is not built")
+    meta, g = load_golden("cfg2_Ur_T0.05")
+    q, c, y, m = rank_inputs(meta)[0]
+    ty, tm = t(y, dev), t(m, dev)
+
+    def run(fn, scale, twice=False):
+        tq, tc = t(q, dev).requires_grad_(True), t(c, dev).requires_grad_(True)
+        loss = fn(tq, tc)
+        assert loss.grad_fn is not None
+        (loss * scale).backward(retain_graph=twice)
+        if twice:
+            (loss * 3.0).backward()
+        return loss.detach().clone(), tq.grad.clone(), tc.grad.clone()
+
+    cpp = lambda tq, tc: hotpath.inbatch_contrastive_loss(tq, tc, ty, tm, meta["T"])  # noqa: E731
+    py = lambda tq, tc: hotpath.InBatchContrastive.apply(tq, tc, ty, tm, meta["T"], None, None, None, None)  # noqa: E731
+    for scale, twice in ((1.0, False), (1024.0, False), (1024.0, False), (2.0, True), (1.0, False)):
+        a, b = run(cpp, scale, twice), run(py, scale, twice)
+        assert "InBatchFn" in cpp(t(q, dev).requires_grad_(True), t(c, dev)).grad_fn.name()
+        for x, z in zip(a, b):
+            assert torch.equal(x, z), (scale, twice)
+    # no gradient wanted: the node is not taken (forward only, the general path)
+    with torch.no_grad():
+        loss = hotpath.inbatch_contrastive_loss(t(q, dev), t(c, dev), ty, tm, meta["T"])
+    assert loss.grad_fn is None and abs(loss.item() - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
