@@ -146,7 +146,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
     {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
     {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
-    {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured no slower (B x Nc >= 2^20: cfg3 per rank), 2 = wherever the plan exists (tests), 0 = never"},
+    {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured faster (B x Nc >= 2^19), 2 = wherever the plan exists (tests), 0 = never"},
     {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward): 1 dC units leave at once, 2 dQ units leave at once, 4 dQ units load no gold rows"},
     {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
     {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
@@ -440,15 +440,17 @@ SkPlan sk_plan(int B, int Nc, int d) {
 // the row logsumexp and the per-tile factors itself).  nts = statistics tiles, nk = 64-context steps of the dQ units (tile space: the
 // packed layout's remapped tiles skip the header rows).  128-column statistics tiles only (a dC unit is one tile), at most 128 of
 // them, the dQ slices as the plan cut them and short enough for a unit's factor table (SK_FT tiles).
-// Where it is chosen (option sk_fused = 1): B x Nc >= 2^20 -- measured, three alternating runs on one box (profiles/r04_fused_ab.txt): cfg3
-// per rank (128 x 8256 x 768) 28.7-29.3 us against 29.3-29.6 with the dScores launch; 64 x 8256 x 512 22.6-22.9 against 21.5-21.8 and
-// 128 x 4128 x 768 24.5-24.7 against 23.2-23.3 (fewer units per launch: the longer units of this form are not covered by the launch
-// it saves).  What it always buys is accuracy: the gold terms stay in fp32 (gradients 3e-5 of max |grad| from an fp64 reference instead of 1e-3).
+// Where it is chosen (option sk_fused = 1): B x Nc >= 2^19 -- measured with eight-wave units (profiles/r04_rank_shapes_w8.txt, one box, us per
+// step without / with the dScores launch): 128 x 8256 x 768 25.4-26.1 / 29.5; 128 x 6208 x 768 23.7 / 25.5; 128 x 4160 x 768 21.9 / 22.4;
+// 128 x 4160 x 1024 23.2 / 24.9; 128 x 8256 x 256 18.8 / 20.2; 96 x 6208 x 768 22.6 / 24.2; 64 x 8256 x 512 / 768 / 1024 20.6 / 20.8,
+// 23.4 / 25.7, 29.6 / 32.4; below 2^19 scores (128 x 2112, 64 x 4160) the two plans tie.  (With four-wave units the plan lost below
+// 2^20: r04_fused_ab.txt.)  What it always buys is accuracy: the gold terms stay in fp32 (gradients 3e-5 of max |grad| from an fp64
+// reference instead of 1e-3).
 struct SkFused { bool ok; int ksteps; bool pair; int tpu, ns; };  // pair: sk_bwdp_kernel with ns slices of tpu statistics tiles
 SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk, int B, int Nc, int d) {
   SkFused f{false, 0, false, 0, 0};
   const int mode = opt(OPT_SK_FUSED);
-  if (mode == 0 || (mode == 1 && (long)B * Nc < (1l << 20))) return f;
+  if (mode == 0 || (mode == 1 && (long)B * Nc < (1l << 19))) return f;
   if (!sk.ok || sk.scols != SK_COLS || nts > 128 || sk.nslices < 1 || sk.nslices > 64) return f;
   f.ksteps = cdiv(nk, sk.nslices);  // (a tiling with fewer steps may leave the last slices empty: their units write zero slabs)
   f.ok = (f.ksteps + 1) / 2 + 1 <= SK_FT;

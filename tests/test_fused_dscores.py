@@ -23,7 +23,7 @@ def kn(request):
     from dpr_scale_amd import _lib
     from dpr_scale_amd.hotpath import HipKernels
 
-    # the plan is chosen by default only where it measured no slower (B x Nc >= 2^20); the tests run it wherever it exists, in
+    # the plan is chosen by default only where it measured no slower (B x Nc >= 2^19); the tests run it wherever it exists, in
     # every form of the backward launch: dQ units + dC units with four or eight waves (sk_bwdf_kernel, option sk_w8), and the one
     # kind of unit that multiplies a P tile both ways (sk_bwdp_kernel, option sk_pair)
     defaults = {k: _lib.get_option(k) for k in ("sk_fused", "sk_w8", "sk_pair")}
