@@ -50,6 +50,9 @@ const char* dprhot_last_error(void);
 /* Process-wide test / A-B switches of the shape plans (all default to "plan decides"; production never calls this).  Names:
  *   tile (-1 | 0..5)   no_tr   unfused_bwd   big_min (256)   no_nl   no_big_bwd   no_skinny   no_small_step   no_short
  *   sk_cols (0 | 64 | 128)   search_unfused   no_8pb   no_wide   no_8p_store   no_wide_bwd   nt_stores (1)   sk_dq_slices (0)
+ *   sk_fused (1: the few-rows step without its dScores launch from 2^19 scores up | 2: wherever it exists | 0: never)
+ *   sk_w8 (1) / sk_sim_w8 (1): eight waves per workgroup in the few-rows backward / sim launch   sk_pair (0): one kind of backward unit
+ *   sk_dbg (0; timing experiments only)
  * Setting one changes the plans of every later call on every thread (workspace sizes included: query them after setting).
  * DPRHOT_E_INVALID for an unknown name. */
 int dprhot_set_option(const char* name, int value);
