@@ -251,6 +251,27 @@ class HotPathStep:
                 self.D.all_reduce_sum(self.loss_sum, self.group)
 
 
+def _host_identity():
+    """CPU model, logical CPUs and the cost of one trivial ctypes call into the library (ns): what the eager driver's step time varies with."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    from dpr_scale_amd import _lib
+    fn = _lib.lib.dprhot_version
+    for _ in range(2000):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(20000):
+        fn()
+    return {"cpu": model, "logical_cpus": os.cpu_count(), "ctypes_call_ns": round((time.perf_counter() - t0) / 20000 * 1e9, 1)}
+
+
 def capture(hp, fn, repeat=1):
     """Capture `repeat` back-to-back invocations of fn into one HIP graph; returns the replay callable."""
     g = torch.cuda.CUDAGraph()
@@ -812,7 +833,10 @@ def core_line(a, W, B, K, d, T, hp, els, driver, collectives, backend, DM):
                    "driver": driver, "collectives": collectives},
         "roofline": None, "kernels": None, "other_driver": None,
         "timing": {"repeats": len(es), "steps_per_repeat": a.steps, "statistic": "median",
-                   "ms_per_step_min": round(es[0] / a.steps * 1e3, 5), "ms_per_step_max": round(es[-1] / a.steps * 1e3, 5)},
+                   "ms_per_step_min": round(es[0] / a.steps * 1e3, 5), "ms_per_step_max": round(es[-1] / a.steps * 1e3, 5),
+                   # the eager loop is host-paced (two launches + one ctypes call per step against 8.7 us of kernels): which host
+                   # this lease ran on, and how fast it makes a foreign call -- other_driver.graph10 is the number that does not move
+                   "host": _host_identity()},
         "rccl_ranks": W if (DM and backend == "nccl") else 0,
         "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
     }
