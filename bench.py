@@ -556,7 +556,19 @@ def grad_hook_block(dev, n=110_000_000, W=8):
         res["torch_ops_total_us"] = round(_event_us(torch_legs, 5), 1)
         out[str(wire).replace("torch.", "")] = res
         del send, recv, mine, full
-    del buf
+    # What plain streams reach on THIS box (the library's own copy / fill kernels through torch): the practical ceiling of a leg
+    # that is two thirds writes (unpack: 2 bytes read, 4 written per element) is the write stream's, not 8 TB/s.
+    dst = torch.empty_like(buf)
+    half = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    same = {}
+    for name, fn, by in (("fill_fp32", lambda: dst.zero_(), 4.0 * n), ("copy_fp32", lambda: dst.copy_(buf), 8.0 * n),
+                         ("widen_bf16_to_fp32", lambda: dst.copy_(half), 6.0 * n)):
+        for _ in range(3):
+            fn()
+        us = _event_us(fn, 20)
+        same[name] = {"us": round(us, 1), "achieved": round(by / us * 1e-3, 1), "frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 4)}
+    out["torch_streams_same_box"] = same
+    del buf, dst, half
     torch.cuda.empty_cache()
     return out
 

@@ -1662,7 +1662,9 @@ int dprhot_grad_pack(const float* bucket, size_t n, float scale, int wire, void*
   REQUIRE(n > 0 && n_padded >= n && n_padded % 8 == 0, "bad sizes n=%zu n_padded=%zu (n_padded %% 8 == 0, >= n)", n, n_padded);
   REQUIRE(wire >= GC_BF16 && wire <= GC_FP32, "wire=%d (0 bf16, 1 fp16, 2 fp32)", wire);
   REQUIRE(aligned16(bucket) && aligned16(send), "pointers must be 16-byte aligned");
-  const dim3 grid(gc_blocks(n_padded / 8 / GC_U + 1)), block(256);
+  const size_t tiles = (n_padded / 4 + 256 * GC_UT - 1) / (256 * GC_UT);
+  REQUIRE(tiles < (1ull << 31), "n_padded=%zu", n_padded);
+  const dim3 grid((unsigned)tiles), block(256);  // one workgroup per contiguous tile (gradcomm.h)
   hipStream_t st = (hipStream_t)stream;
   if (wire == GC_BF16) hipLaunchKernelGGL(grad_pack_kernel<GC_BF16>, grid, block, 0, st, bucket, n, scale, send, n_padded);
   else if (wire == GC_FP16) hipLaunchKernelGGL(grad_pack_kernel<GC_FP16>, grid, block, 0, st, bucket, n, scale, send, n_padded);
@@ -1694,7 +1696,9 @@ int dprhot_grad_unpack(const void* full, int kind, float* bucket, size_t n, void
   REQUIRE(full && bucket && n > 0, "bad argument");
   REQUIRE(kind >= GC_BF16 && kind <= GC_FP32, "kind=%d (0 bf16, 1 fp16, 2 fp32)", kind);
   REQUIRE(aligned16(full) && aligned16(bucket), "pointers must be 16-byte aligned");
-  const dim3 grid(gc_blocks(n / 8 / GC_U + 1)), block(256);
+  const size_t tiles = (n / 4 + 256 * GC_UT - 1) / (256 * GC_UT);
+  REQUIRE(tiles < (1ull << 31), "n=%zu", n);
+  const dim3 grid((unsigned)(tiles > 0 ? tiles : 1)), block(256);  // one workgroup per contiguous tile (gradcomm.h)
   hipStream_t st = (hipStream_t)stream;
   if (kind == GC_BF16) hipLaunchKernelGGL(grad_unpack_kernel<GC_BF16>, grid, block, 0, st, full, bucket, n);
   else if (kind == GC_FP16) hipLaunchKernelGGL(grad_unpack_kernel<GC_FP16>, grid, block, 0, st, full, bucket, n);

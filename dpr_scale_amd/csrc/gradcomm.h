@@ -90,38 +90,37 @@ __device__ __forceinline__ float gc_load1(const void* base, size_t i) {
 
 constexpr int GC_U = 4;  // 16-byte groups per thread and trip (x2 loads each for fp32 sources)
 
-// send[0..n_pad) <- wire(bucket[0..n) * scale), zeros beyond n.  n8 = n / 8 whole groups, then a scalar tail, then zero groups.
+// send[0..n_pad) <- wire(bucket[0..n) * scale), zeros beyond n.  One workgroup per contiguous tile of 256 x GC_UT groups of four values
+// (see grad_unpack_kernel: the persistent grid-stride form of this leg ran at 0.72).  n_pad % 8 == 0.
+#ifndef GC_UT_EXP
+#define GC_UT_EXP 2
+#endif
+constexpr int GC_UT = GC_UT_EXP;  // (tile sweep of the unpack leg, 110 M elements: 16 / 8 / 4 / 2 groups per thread 124 / 117 / 111 / 110 us)
 template <int WIRE>
 __global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ bucket, size_t n, float scale, void* __restrict__ send,
                                                         size_t n_pad) {
-  const size_t n8 = n / 8, p8 = n_pad / 8;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  for (; c + (GC_U - 1) * stride < n8; c += GC_U * stride) {
-    float v[GC_U][8];
+  typedef float gc_f4 __attribute__((ext_vector_type(4)));
+  const size_t n4 = n / 4, p4 = n_pad / 4;
+  const size_t base = (size_t)blockIdx.x * (256 * GC_UT) + threadIdx.x;
+  gc_f4 v[GC_UT];
 #pragma unroll
-    for (int u = 0; u < GC_U; ++u) gc_load8<GC_FP32, true>(bucket, c + u * stride, v[u]);
-#pragma unroll
-    for (int u = 0; u < GC_U; ++u) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[u][e] *= scale;
-      gc_store8<WIRE>(send, c + u * stride, v[u]);
-    }
-  }
-  for (; c < p8; c += stride) {
-    float v[8];
-    if (c < n8) {
-      gc_load8<GC_FP32, true>(bucket, c, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= scale;
+  for (int u = 0; u < GC_UT; ++u) {
+    const size_t g = base + u * 256;
+    if (g < n4) {
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const gc_f4*>(bucket) + g);  // (read once, larger than the Infinity Cache)
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const size_t i = c * 8 + e;
-        v[e] = i < n ? bucket[i] * scale : 0.f;
-      }
+      for (int e = 0; e < 4; ++e) v[u][e] = (g < p4 && g * 4 + e < n) ? bucket[g * 4 + e] : 0.f;  // the ragged end, then zero padding
     }
-    gc_store8<WIRE>(send, c, v);
+  }
+#pragma unroll
+  for (int u = 0; u < GC_UT; ++u) {
+    const size_t g = base + u * 256;
+    if (g < p4) {
+      const gc_f4 w = v[u] * scale;
+      if constexpr (WIRE == GC_FP32) reinterpret_cast<gc_f4*>(send)[g] = w;
+      else reinterpret_cast<uint2*>(send)[g] = make_uint2(gc_pack2<WIRE>(w[0], w[1]), gc_pack2<WIRE>(w[2], w[3]));
+    }
   }
 }
 
@@ -154,27 +153,38 @@ __global__ __launch_bounds__(256) void grad_sum_shards_kernel(const void* __rest
 }
 
 // bucket[0..n) <- float(full[0..n))
+// One workgroup per contiguous tile of 256 x GC_UT groups of FOUR values (8 bytes in, 16 out per thread and group): every load
+// instruction of a wave covers 512 contiguous bytes, every store 1 KiB without holes, and a workgroup's GC_UT groups are neighbours.
+// The persistent grid-stride form with 8 values per thread (16 bytes in, two 16-byte stores 32 bytes apart out; its GC_U groups a
+// whole grid apart) ran at 0.59-0.62 of the HBM rate where torch's own widening copy reaches 0.72 on the same box (bench.py:
+// grad_hook.torch_streams_same_box); trading halves between lanes to densify ITS stores had made it slower (145 us against 130).
 template <int KIND>
 __global__ __launch_bounds__(256) void grad_unpack_kernel(const void* __restrict__ full, float* __restrict__ bucket, size_t n) {
-  const size_t n8 = n / 8;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  // (Round 4, measured and not kept: a thread's 8 values become two float4, so each store instruction writes 16 bytes out of every 32;
-  //  letting neighbouring lanes trade halves first -- one DPP move per value, every store instruction of the wave then covers 1 KiB
-  //  without holes -- took this leg from 130 to 145-147 us for 110 M elements: the half-dense stores were not what holds it at 0.62.)
-  for (; c + (GC_U - 1) * stride < n8; c += GC_U * stride) {
-    float v[GC_U][8];
+  const size_t n4 = n / 4;
+  const size_t base = (size_t)blockIdx.x * (256 * GC_UT) + threadIdx.x;
+  if constexpr (KIND == GC_FP32) {
+    float4 v[GC_UT];
 #pragma unroll
-    for (int u = 0; u < GC_U; ++u) gc_load8<KIND>(full, c + u * stride, v[u]);
+    for (int u = 0; u < GC_UT; ++u)
+      if (base + u * 256 < n4) v[u] = reinterpret_cast<const float4*>(full)[base + u * 256];
 #pragma unroll
-    for (int u = 0; u < GC_U; ++u) gc_store8<GC_FP32>(bucket, c + u * stride, v[u]);
+    for (int u = 0; u < GC_UT; ++u)
+      if (base + u * 256 < n4) reinterpret_cast<float4*>(bucket)[base + u * 256] = v[u];
+  } else {
+    uint2 w[GC_UT];
+#pragma unroll
+    for (int u = 0; u < GC_UT; ++u)
+      if (base + u * 256 < n4) w[u] = reinterpret_cast<const uint2*>(full)[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < GC_UT; ++u)
+      if (base + u * 256 < n4) {
+        float4 v;
+        gc_unpack2<KIND>(w[u].x, v.x, v.y);
+        gc_unpack2<KIND>(w[u].y, v.z, v.w);
+        reinterpret_cast<float4*>(bucket)[base + u * 256] = v;
+      }
   }
-  for (; c < n8; c += stride) {
-    float v[8];
-    gc_load8<KIND>(full, c, v);
-    gc_store8<GC_FP32>(bucket, c, v);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) bucket[n8 * 8 + threadIdx.x] = gc_load1<KIND>(full, n8 * 8 + threadIdx.x);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bucket[n4 * 4 + threadIdx.x] = gc_load1<KIND>(full, n4 * 4 + threadIdx.x);
 }
 
 // ---- the autograd operator's grad_output fix-up ------------------------------------------------------------------------------------
