@@ -777,6 +777,8 @@ struct Epi8Filter {
   float* cand_v;            // [M][N]
   int* cand_j;              // [M][N]
   const void* dummy;
+  int j_bias = 0;           // added to the column written to cand_j: a chunk appended to the candidate lists of the chunk(s) before
+                            // it (dprhot_search merges groups of warm chunks once; the merge sees columns relative to the group's start)
   __device__ __forceinline__ const void* meta_src(int m0, int n0, int e) const {
     if (e >= 512 && e < 768) return kth_val + (size_t)min(m0 + e - 512, M - 1) * k + (k - 1);
     return dummy;
@@ -843,7 +845,7 @@ struct Epi8Filter {
         for (int r = 0; r < 16; ++r) {
           if ((mask >> (b * 16 + r)) & 1u) {
             cand_v[(size_t)m * N + pos] = acc.v[a][b][r];
-            cand_j[(size_t)m * N + pos] = t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
+            cand_j[(size_t)m * N + pos] = j_bias + t.n0 + t.wn * 64 + b * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
             ++pos;
           }
         }

@@ -625,6 +625,8 @@ def test_topk_state_with_fewer_columns_than_k(kn, dev):
 
 @pytest.mark.parametrize("nq,shards,d,k,chunk", [(9, (4000, 13, 8, 2051), 64, 20, 1024), (130, (50000,), 768, 100, 8192),
                                                  (512, (100000, 40000), 128, 50, 32768),  # >= 256 tiles per chunk: the gemm8p.h filter epilogue
+                                                 (512, (300000,), 128, 50, 32768),  # warm chunks merged in groups of 2, then 4 (dprhot_search)
+                                                 (300, (200000, 70000), 128, 1000, 32768),  # ... at k = 1000, a second shard behind them
                                                  (7, (30000, 5000), 128, 1000, 4096),  # --topk 1000: dragon/README recipes
                                                  (40, (60000, 9000), 128, 300, 8192)])  # 48 KB variant, counted candidate merges
 def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk, kn, dev):
@@ -632,16 +634,23 @@ def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk,
     the stable top-k of the full score matrix computed by the same similarity kernel; scores against fp32 torch."""
     from dpr_scale_amd.hotpath import CorpusSearch, sim_score
 
+    from dpr_scale_amd import _lib
+
     g = torch.Generator().manual_seed(nq)
     q = torch.randn(nq, d, generator=g).to(dev)
     parts = [torch.randn(n, d, generator=g).to(dev) for n in shards]
     parts[0][100:140] = parts[0][60:100]  # duplicated passages: exact score ties
-    s = CorpusSearch(q, k, chunk=chunk, kernels=kn)
-    first = 0
-    for p in parts:
-        s.add(p.to(torch.bfloat16) if first == 0 else p, first)  # bf16-resident and fp32 shards
-        first += p.shape[0]
-    v, i = s.result()
+    grouped = shards[0] >= 6 * chunk  # (the two cases long enough for it: grouped merges are an option, off by default)
+    _lib.set_option("search_group", 1 if grouped else 0)
+    try:
+        s = CorpusSearch(q, k, chunk=chunk, kernels=kn)
+        first = 0
+        for p in parts:
+            s.add(p.to(torch.bfloat16) if first == 0 else p, first)  # bf16-resident and fp32 shards
+            first += p.shape[0]
+        v, i = s.result()
+    finally:
+        _lib.set_option("search_group", 0)
     C = torch.cat(parts)
     S = sim_score(q, C, kernels=kn)
     order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
