@@ -810,10 +810,17 @@ __device__ __forceinline__ void tk_merge_count(float* sv, long long* si, int k, 
   __syncthreads();
 }
 
-// bitonic network over P slots (a power of two, already padded), best-first; ends with a barrier
+// bitonic network over P slots (a power of two, already padded), best-first; ends with a barrier.
+// A stage of stride <= 64 keeps every wave inside its own blocks of 128 slots (64 consecutive pair indices t cover 128 consecutive
+// slots), so consecutive stages of that kind need no workgroup barrier between them -- LDS operations of one wave execute in
+// order; only the compiler has to be told.  For P = 1024 that leaves 6 + 2 barriers of 55 (k = 1000 retrieval: each merge launch is
+// a sort of ~1024 candidates per row).
 __device__ __forceinline__ void tk_bitonic(float* sv, long long* si, int P, int tid) {
+  bool wave_local = false;  // the stage before this one was synchronised inside the waves only
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      const bool wide = stride > 64;
+      if (wide && wave_local) __syncthreads();
       for (int t = tid; t < P / 2; t += 256) {
         const int lo = (t / stride) * 2 * stride + (t % stride), hi = lo + stride;
         const bool up = (lo & size) == 0;  // this block sorts best-first
@@ -822,9 +829,17 @@ __device__ __forceinline__ void tk_bitonic(float* sv, long long* si, int P, int 
         const bool swap = up ? tk_before(b, ib, a, ia) : tk_before(a, ia, b, ib);
         if (swap) { sv[lo] = b; sv[hi] = a; si[lo] = ib; si[hi] = ia; }
       }
-      __syncthreads();
+      if (wide) {
+        __syncthreads();
+      } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      wave_local = !wide;
     }
   }
+  __syncthreads();
 }
 
 template <bool COUNTING>  // the 12 KB kernel (k <= 256, <= 1024 slots) merges by counting; the 48 KB one sorts

@@ -86,10 +86,15 @@ def test_topk_beyond_the_kernel_limit_on_the_hip_path(k, n, chunk, shard):
 
     dev = torch.device("cuda:0")
     _wide_k_check(None, dev, k, n, chunk, shard)  # warm-up + the check itself
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        _wide_k_check(None, dev, k, n, chunk, shard)
-        torch.cuda.synchronize()
-    names = [e.key for e in prof.key_averages()]
+    for attempt in range(3):  # (the first profile of a process sometimes comes back with runtime calls only, no device activity)
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            _wide_k_check(None, dev, k, n, chunk, shard)
+            torch.cuda.synchronize()
+        names = [e.key for e in prof.key_averages()]
+        if any("dprhot" in x for x in names):
+            break
+    if not any("dprhot" in x or "kernel" in x.lower() for x in names):
+        pytest.skip("the profiler recorded no device activity on this box")
     assert any("topk_stream_kernel" in x for x in names), names
     assert not any(("sort" in x.lower() or "radix" in x.lower()) and "dprhot" not in x for x in names), [x for x in names if "sort" in x.lower()]
 
