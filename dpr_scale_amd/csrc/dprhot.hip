@@ -708,10 +708,12 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     }
     HIP_TRY(hipGetLastError());
     {
-      const int parts = cdiv(d / 4, 128);
+      // one workgroup per row where the row fits 256 threads (d <= 1024): the row's statistics are derived once, not once per part
+      const int fthreads = d / 4 >= 256 ? 256 : cdiv(d / 4, 64) * 64;
+      const int parts = cdiv(d / 4, fthreads);
       SkFinArgs f{part, fz.pair ? fz.ns : sk.nslices, fz.ksteps, nk_f, B, d, tile_lse, nts, gold, y, y_offset, Cb, grad_scale, h_scale, d_scale, dQ, parts,
                   fz.pair ? 1 : 0};
-      hipLaunchKernelGGL(sk_dq_finish_kernel, dim3((unsigned)(B * parts)), dim3(128), 0, st, f);
+      hipLaunchKernelGGL(sk_dq_finish_kernel, dim3((unsigned)(B * parts)), dim3((unsigned)fthreads), 0, st, f);
       HIP_TRY(hipGetLastError());
     }
     return DPRHOT_OK;

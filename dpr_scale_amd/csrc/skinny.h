@@ -1421,12 +1421,12 @@ struct SkFinArgs {
   int plain = 0;          // 1: the slabs are plain partial sums of softmax x C (sk_bwdp_kernel): every slice's factor is grad_scale
 };
 
-__global__ __launch_bounds__(128) void sk_dq_finish_kernel(SkFinArgs p) {
+__global__ __launch_bounds__(256) void sk_dq_finish_kernel(SkFinArgs p) {
   __shared__ float s_e[64];
   __shared__ float4 s_t[128];  // the row's tile values (nt <= 512)
   const int tid = threadIdx.x, lane = tid & 63;
   const int row = blockIdx.x / p.parts, part = blockIdx.x - row * p.parts;
-  const int nq = p.d >> 2, q4 = part * 128 + tid;
+  const int nq = p.d >> 2, q4 = part * (int)blockDim.x + tid;  // (one workgroup per row up to d = 1024: a whole number of waves)
   const bool ok = q4 < nq;
   const size_t slab4 = (size_t)p.B * nq, o4 = (size_t)row * nq + (ok ? q4 : 0);
   const float4* const part4 = reinterpret_cast<const float4*>(p.part);
