@@ -983,9 +983,11 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + (unsigned)min(k0 + bkr[j], p.Nc - 1) * (unsigned)p.d + bcol[j]),
                                        (g2_lds_ptr*)(Bs + (wave_u * IB + j) * 512), 16, 0, 0);
   };
-  // Two steps are issued here, and step s + 2 right behind step s's first barrier: at that barrier every wave has finished READING
-  // slot (s - 1) % 3 -- the slot step s + 2 goes to -- so the refill needs no barrier of its own (one barrier per step instead of two;
-  // the stamps showed the wait for a slot at 0.11 of 0.73 us per step: one step less of look-ahead is affordable)
+  // Two steps are issued here, and step s + 2 inside step s, behind its barrier and its fragment reads: at that barrier every wave has
+  // finished READING slot (s - 1) % 3 -- the slot step s + 2 goes to -- so the refill needs no barrier of its own (one barrier per step
+  // instead of two; the stamps showed the wait for a slot at 0.11 of 0.73 us per step: one step less of look-ahead is affordable --
+  // and a ring of TWO slots runs the units alone on the chip just as fast: the third slot pays only next to the dC units, by 1.1 us
+  // per launch)
 #pragma unroll
   for (int s = 0; s < SK_QSLOTS - 1; ++s)
     if (s < ns) issue(s, s);
