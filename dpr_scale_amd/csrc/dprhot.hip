@@ -447,14 +447,24 @@ SkPlan sk_plan(int B, int Nc, int d) {
 // 23.4 / 25.7, 29.6 / 32.4; below 2^19 scores (128 x 2112, 64 x 4160) the two plans tie.  (With four-wave units the plan lost below
 // 2^20: r04_fused_ab.txt.)  What it always buys is accuracy: the gold terms stay in fp32 (gradients 3e-5 of max |grad| from an fp64
 // reference instead of 1e-3).
-struct SkFused { bool ok; int ksteps; bool pair; int tpu, ns; };  // pair: sk_bwdp_kernel with ns slices of tpu statistics tiles
+struct SkFused { bool ok; int ksteps, nslices; bool pair; int tpu, ns; };  // nslices x ksteps: the dQ units' slices; pair: sk_bwdp_kernel with ns slices of tpu statistics tiles
 SkFused sk_fused_plan(const SkPlan& sk, int nts, int nk, int B, int Nc, int d) {
-  SkFused f{false, 0, false, 0, 0};
+  SkFused f{false, 0, 0, false, 0, 0};
   const int mode = opt(OPT_SK_FUSED);
   if (mode == 0 || (mode == 1 && (long)B * Nc < (1l << 19))) return f;
   if (!sk.ok || sk.scols != SK_COLS || nts > 128 || sk.nslices < 1 || sk.nslices > 64) return f;
-  f.ksteps = cdiv(nk, sk.nslices);  // (a tiling with fewer steps may leave the last slices empty: their units write zero slabs)
-  f.ok = (f.ksteps + 1) / 2 + 1 <= SK_FT;
+  f.nslices = sk.nslices;
+  f.ksteps = cdiv(nk, f.nslices);  // (a tiling with fewer steps may leave the last slices empty: their units write zero slabs)
+  if ((f.ksteps + 1) / 2 + 1 > SK_FT) {
+    // the plan's slices span more statistics tiles than a dQ unit's factor table holds (long rows, or few slices at d = 1024).
+    // This form can cut its own, 13 steps each (7 tiles + 1) -- but those are shapes with more workgroups than the chip holds at
+    // once, and there it measured SLOWER than the plan with the dScores launch (128 x 12352 x 768: 40.0 against 35.7 us;
+    // 128 x 8256 x 1024: 33.6 / 31.8; 64 x 8256 x 1024: 30.2 / 29.6): only on request (sk_fused = 2)
+    if (mode != 2) return f;
+    f.ksteps = 2 * (SK_FT - 1) - 1;
+    f.nslices = cdiv(nk, f.ksteps);
+  }
+  f.ok = f.nslices <= 64 && (f.ksteps + 1) / 2 + 1 <= SK_FT;
   if (f.ok && opt(OPT_SK_PAIR) != 0 && d % SK_QN == 0) {
     // one workgroup per CU (152 KiB of LDS each): at most kNumCU units, at most 16 slabs (one batch of the finishing launch's loads)
     const int ndt = d / SK_QN;
@@ -495,6 +505,7 @@ WsLayout ws_layout(int B, int Nc, int d) {
   const SkPlan sk = sk_plan(B, Nc, d);
   int slabs = sk.ok && sk.nslices > p.splits ? sk.nslices : p.splits;
   if (sk.ok && slabs < 16) slabs = 16;  // (sk_bwdp_kernel: up to 16 slices)
+  if (sk.ok && slabs < cdiv(cdiv(Nc, 64), 2 * (SK_FT - 1) - 1)) slabs = cdiv(cdiv(Nc, 64), 2 * (SK_FT - 1) - 1);  // (sk_fused_plan's own slices)
   w.dq_part = off; off += align256((size_t)slabs * B * d * 4);
   w.total = off;
   return w;
@@ -666,10 +677,10 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   if (fused) {
     if (g_dq_part != nullptr) return fail(DPRHOT_E_INVALID, "few-rows step without dScores: dQ is finished by the step itself (dprhot_train_dq_slabs = 0)");
     float* part = reinterpret_cast<float*>(ws + wl.dq_part);
-    const int ndq = sk.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = nts * (d / SK_DN);
+    const int ndq = fz.nslices * (d / SK_QN), ndq_pad = (ndq + 7) & ~7, ndc = nts * (d / SK_DN);
     SkBwdFArgs b{a.P, Qb, Cb, B, Nc, d, tile_lse, gold, y, y_offset, nts, tpr, g_packed.rows_c, g_packed.n_ctx, grad_scale, h_scale, d_scale,
                  dC_part, g_dc_bf16 ? 1 : 0, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, loss_sum, g_loss_scale,
-                 row_loss, row_lse, fz.ksteps, sk.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0, opt(OPT_SK_DBG)};
+                 row_loss, row_lse, fz.ksteps, fz.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0, opt(OPT_SK_DBG)};
     const size_t lds = sk_bwdf_lds();
     static AttrOnce attr_done[4];
     auto launch = [&](auto kern, int slot, int threads) -> int {
@@ -711,7 +722,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       // one workgroup per row where the row fits 256 threads (d <= 1024): the row's statistics are derived once, not once per part
       const int fthreads = d / 4 >= 256 ? 256 : cdiv(d / 4, 64) * 64;
       const int parts = cdiv(d / 4, fthreads);
-      SkFinArgs f{part, fz.pair ? fz.ns : sk.nslices, fz.ksteps, nk_f, B, d, tile_lse, nts, gold, y, y_offset, Cb, grad_scale, h_scale, d_scale, dQ, parts,
+      SkFinArgs f{part, fz.pair ? fz.ns : fz.nslices, fz.ksteps, nk_f, B, d, tile_lse, nts, gold, y, y_offset, Cb, grad_scale, h_scale, d_scale, dQ, parts,
                   fz.pair ? 1 : 0};
       hipLaunchKernelGGL(sk_dq_finish_kernel, dim3((unsigned)(B * parts)), dim3((unsigned)fthreads), 0, st, f);
       HIP_TRY(hipGetLastError());

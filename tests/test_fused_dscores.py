@@ -96,8 +96,8 @@ PACKED_CASES = [
     (8, 64, 16, 512, 1.0, False, True),     # two row blocks
     (4, 128, 16, 128, 1.0, False, False),   # d = 128: one dC column tile, two dQ column tiles
     (8, 32, 32, 768, 1.0, False, True),     # one row block of 32: a single LDS-DMA piece per wave and image in the eight-wave dC units
-    (2, 128, 16, 1024, 0.25, True, False),  # d = 1024: sixteen dQ column tiles, the widest finishing row (at 8208 columns a dQ slice
-                                            # would span more statistics tiles than a unit's factor table holds: that shape keeps the dScores launch)
+    (2, 128, 16, 1024, 0.25, True, False),  # d = 1024: sixteen dQ column tiles, the widest finishing row
+    (2, 128, 32, 1024, 1.0, False, True),   # ... at 8208 columns: the plan's 8 slices would span 9 statistics tiles, this form cuts its own 10
 ]
 
 
@@ -139,7 +139,7 @@ def test_packed_step_without_dscores_launch(W, B, K, d, T, peaky, dup, kn, dev):
         assert torch.all(st.view(W, rows_c, d)[:, n_ctx:] == 0)  # header rows: exactly zero gradient
 
 
-@pytest.mark.parametrize("B,Nc,d,T", [(128, 8192, 768, 1.0), (128, 4096, 768, 0.05), (96, 8200, 256, 1.0), (128, 16384, 128, 1.0)])
+@pytest.mark.parametrize("B,Nc,d,T", [(128, 8192, 768, 1.0), (128, 4096, 768, 0.05), (96, 8200, 256, 1.0), (128, 16384, 128, 1.0), (128, 12288, 768, 1.0)])
 def test_single_rank_step_without_dscores_launch(B, Nc, d, T, kn, dev):
     """dprhot_inbatch_step_f32 with G == NULL: explicit mask vector, plain column tiles (Nc = 8200: a ragged last tile of 8 columns;
     16384: the plan's widest shape -- 128 statistics tiles)."""
