@@ -91,6 +91,21 @@ def test_argument_validation_is_host_side():
     assert lib.dprhot_step_wants_g(32, 256, 768, ctypes.byref(w)) == 0 and w.value == 1             # cfg2: G is written by the fused small step
     assert lib.dprhot_step_wants_g(128, 1032, 768, ctypes.byref(w)) == 0 and w.value == 1           # narrow sim units: the four-launch plan
     assert lib.dprhot_train_dq_slabs(32, 256, 768, ctypes.byref(n)) == 0 and n.value == 0          # cfg2: dQ comes out whole
+    # where the plan without the dScores launch is chosen (round 4, eight-wave units): from 2^19 scores up, where the few-rows plan's
+    # own dQ slices fit a unit's factor table; sk_fused = 2 takes it wherever it exists (it then cuts its own slices)
+    for shape, want_g in (((128, 4160, 768), 0), ((64, 8256, 512), 0), ((96, 6208, 768), 0), ((128, 4096, 768), 0), ((128, 2112, 768), 1),
+                          ((64, 4160, 768), 1), ((128, 8256, 1024), 1), ((128, 12384, 768), 1), ((128, 16512, 768), 1)):
+        assert lib.dprhot_step_wants_g(*shape, ctypes.byref(w)) == 0 and w.value == want_g, (shape, w.value)
+    assert lib.dprhot_set_option(b"sk_fused", 2) == 0
+    big = ctypes.c_size_t(0)
+    for shape, want_g in (((128, 2112, 768), 1), ((128, 8256, 1024), 0), ((128, 12384, 768), 0), ((128, 16512, 768), 1)):  # (2112: narrow sim units)
+        assert lib.dprhot_step_wants_g(*shape, ctypes.byref(w)) == 0 and w.value == want_g, (shape, w.value)
+        # its slabs fit the workspace: ceil(ceil(Nc / 64) / 13) slices of B x d floats (plus everything else in there)
+        assert lib.dprhot_workspace_bytes(*shape, ctypes.byref(big)) == 0
+        assert big.value >= -(-(-(-shape[1] // 64)) // 13) * shape[0] * shape[2] * 4
+    assert lib.dprhot_set_option(b"sk_fused", 1) == 0
+    for name, default in ((b"sk_w8", 1), (b"sk_sim_w8", 1), (b"sk_pair", 0), (b"search_group", 0), (b"sk_fused", 1), (b"nt_stores", 1)):
+        assert lib.dprhot_get_option(name, ctypes.byref(n)) == 0 and n.value == default, (name, n.value)
     # the few-rows plan's measured boundaries ("Mid-size steps"), seen through the slab count: split-K slabs where
     # the plan applies with more than 512 contexts, none where its dQ units are unsplit or another plan has the shape
     for shape, want_slabs in (((128, 1032, 768), True), ((64, 1088, 1024), True), ((32, 1056, 768), True), ((32, 2112, 768), True),
