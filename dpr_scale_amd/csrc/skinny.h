@@ -1086,12 +1086,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-#if defined(SK_EXP) && (SK_EXP & 1)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], acc[a][b], 0, 0, 0);
-#else
           cur[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bf[b], kk == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : cur[a][b], 0, 0, 0);
-#endif
-#if !defined(SK_EXP) || !(SK_EXP & 1)
       if constexpr (!FIRST) {
         // half of the previous step's factor FMAs per k slice: sum += w * (P x C of step s - 1)
 #pragma unroll
@@ -1099,7 +1094,6 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[kk][b][r] = fmaf(frp[kk][r], prev[kk][b][r], acc[kk][b][r]);
       }
-#endif
     }
     if constexpr (!FIRST) {
       // one MFMA, one FMA pair: the vector ALU work sits in the matrix pipe's issue gaps instead of behind the last MFMA
