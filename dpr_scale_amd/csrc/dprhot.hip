@@ -800,9 +800,9 @@ int dprhot_cast_bf16(const float* src, dprhot_bf16* dst, size_t n, void* stream)
   REQUIRE(n % 8 == 0, "n=%zu must be a multiple of 8", n);
   REQUIRE(aligned16(src) && aligned16(dst), "pointers must be 16-byte aligned");
   if (n == 0) return DPRHOT_OK;
-  const size_t n8 = n / 8;
-  const int blocks = (int)((n8 + 255) / 256 > 2048 ? 2048 : (n8 + 255) / 256);
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n8);
+  const size_t n4 = n / 4, tiles = (n4 + 256 * CAST_UT - 1) / (256 * CAST_UT);
+  REQUIRE(tiles < (1ull << 31), "n=%zu", n);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, src, dst, n4);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
 }
