@@ -2,9 +2,13 @@
 derives the row logsumexp and one factor per (row, tile) itself) against (a) an fp64 restatement of dpr_task.py:197-212 and its
 autograd backward on the same bf16-representable inputs and (b) the four-launch plan of the same library (G materialised).
 Through the C ABI (dprhot_inbatch_step_f32 / _packed_f32 / dprhot_train_step_packed_f32 with G == NULL)."""
+import functools
+
 import numpy as np
 import pytest
 import torch
+
+from oracle import inbatch_oracle as O  # the checker (numpy restatement of dpr_task.py:153-214, pinned to the reference's fixtures)
 
 pytestmark = pytest.mark.gpu
 
@@ -137,6 +141,73 @@ def test_packed_step_without_dscores_launch(W, B, K, d, T, peaky, dup, kn, dev):
         #  1.3e-3 at d = 1024, T = 0.25)
         assert e_dq <= max(1.5 * e_dq0, 2e-3) and e_dc <= max(2.0 * e_dc0, 3e-3)
         assert torch.all(st.view(W, rows_c, d)[:, n_ctx:] == 0)  # header rows: exactly zero gradient
+
+
+@functools.lru_cache(maxsize=4)
+def _oracle_world(W, B, K, d, dist, ragged, T, seed):
+    """The ORACLE's inputs and global step for a BASELINE-shaped world (computed once per case, shared by the three kernel forms)."""
+    parts = [O.synth_embeddings(seed + r, B, K, d, dist, ragged) for r in range(W)]
+    n_ctx = B * K
+    Q = np.concatenate([p[0] for p in parts])
+    C = np.concatenate([p[1] for p in parts])
+    y = O.gathered_labels(np.stack([p[2] for p in parts]), n_ctx)
+    m = np.concatenate([p[3] for p in parts])
+    ref = O.training_step_global(Q, C, y, m, T)
+    return parts, {k: ref[k] for k in ("loss", "lse", "dQ", "dC")}
+
+
+# BASELINE configs[2] (cfg3: W8 B128 K8 d768) in the distributions / temperatures the reference-generated fixtures use, and
+# configs[4] at a per-rank batch wide enough for this plan (cfg5's d = 1024 vectors, B 128 K 8)
+ORACLE_CASES = [
+    (8, 128, 8, 768, "U", True, 1.0, 3100),
+    (8, 128, 8, 768, "U", True, 0.05, 3200),
+    (8, 128, 8, 768, "P", False, 1.0, 3300),
+    (4, 128, 8, 1024, "U", True, 1.0, 3400),
+]
+
+
+@pytest.mark.parametrize("W,B,K,d,dist,ragged,T,seed", ORACLE_CASES)
+def test_default_plan_against_the_oracle_at_baseline_shapes(W, B, K, d, dist, ragged, T, seed, kn, dev):
+    """Every rank's packed step WITHOUT a dScores launch (G == NULL: what production runs at these shapes) on the oracle's own
+    synthetic inputs (O.synth_embeddings) against O.training_step_global -- the restatement of dpr_task.py:163-212
+    that tests/test_oracle_golden.py pins to the reference-generated fixtures: loss, every row's logsumexp, every rank's q.grad,
+    and c.grad of all W * B * K contexts after the (emulated) reduce-scatter."""
+    parts, ref = _oracle_world(W, B, K, d, dist, ragged, T, seed)
+    n_ctx, Nq = B * K, W * B
+    rows_c = kn.packed_rows(n_ctx, d)
+    sends = []
+    for r in range(W):
+        send = torch.empty((rows_c, d), dtype=torch.bfloat16, device=dev)
+        kn.pack_ctx(torch.from_numpy(parts[r][1]).to(dev), torch.from_numpy(parts[r][3].astype(np.uint8)).to(dev), send)
+        sends.append(send)
+    Cb = torch.cat(sends, 0).contiguous()
+    if kn._lib.step_wants_g(B, W * rows_c, d):
+        pytest.skip("this shape's plan keeps the dScores launch")
+    Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+    inv_T = 1.0 / T
+    dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
+    loss, e_dq = 0.0, 0.0
+    for r in range(W):
+        q = torch.from_numpy(parts[r][0]).to(dev)
+        y = torch.from_numpy(parts[r][2]).to(dev)
+        rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, y, inv_T, inv_T / Nq, want_G=False)
+        assert G is None
+        loss += ls.item()
+        dC += dcp.double()
+        ref_lse = ref["lse"][r * B:(r + 1) * B]
+        assert np.abs(lse.cpu().numpy() - ref_lse).max() <= 1e-3 * max(1.0, np.abs(ref_lse).max())
+        ref_dq = ref["dQ"][r * B:(r + 1) * B]
+        e = np.abs(dq.cpu().numpy() - ref_dq).max() / np.abs(ref["dQ"]).max()
+        e_dq = max(e_dq, e)
+    assert abs(loss / Nq - ref["loss"]) <= LOSS_BAR * max(1.0, abs(ref["loss"]))
+    got = dC.cpu().numpy().reshape(W, rows_c, d)
+    for k in range(W):  # the piggy-backed loss numerator at [n_ctx][0] of every chunk, then nothing but zeros in the header rows
+        assert abs(got[k, n_ctx, 0] - loss) <= 1e-5 * max(1.0, abs(loss))  # (summed over the ranks: the global numerator)
+        got[k, n_ctx, 0] = 0.0
+    assert np.all(got[:, n_ctx:] == 0.0)
+    e_dc = np.abs(got[:, :n_ctx].reshape(W * n_ctx, d) - ref["dC"]).max() / np.abs(ref["dC"]).max()
+    print(f"[plan-error] oracle W{W} B{B} K{K} d{d} {dist} T{T}: dQ {e_dq:.2e}  dC {e_dc:.2e} (of max |grad|, default plan)")
+    assert e_dq <= GRAD_BAR and e_dc <= GRAD_BAR
 
 
 @pytest.mark.parametrize("B,Nc,d,T", [(128, 8192, 768, 1.0), (128, 4096, 768, 0.05), (96, 8200, 256, 1.0), (128, 16384, 128, 1.0), (128, 12288, 768, 1.0)])

@@ -254,9 +254,13 @@ def _packed_world(meta, kn, dev):
     return parts, rows_c, torch.cat(sends, 0).contiguous()
 
 
+@pytest.mark.parametrize("plan", ["with-dscores", "default-plan"])
 @pytest.mark.parametrize("name", golden_names("cfg3") + golden_names("cfg5"))
-def test_production_packed_step_every_rank_full_size(name, kn, dev):
-    """The entry point DDP training actually runs -- dprhot_inbatch_step_packed_f32: fp32 q straight into the sim kernel
+def test_production_packed_step_every_rank_full_size(name, plan, kn, dev):
+    """plan: "with-dscores" passes a G buffer (the plan that materialises the dScores, four launches at cfg3 per rank);
+    "default-plan" passes G == NULL wherever dprhot_step_wants_g says the shape's plan needs none -- what the autograd operator
+    (want_G = "auto") and bench.py run since round 4: three launches at cfg3 per rank, sk_sim -> sk_bwdf -> sk_dq_finish.
+    The entry point DDP training actually runs -- dprhot_inbatch_step_packed_f32: fp32 q straight into the sim kernel
     (dprhot_sim_stats_f32<AF, !BF>, long-row statistics plan at B = 128 / packed Nc = 8 * 1032 = 8256 for cfg3; the
     short-row plan with d = 1024 for cfg5), mask bytes read from the gathered buffer, loss numerator riding in dC_part --
     for EVERY rank of cfg3 (W8 B128 K8 d768) and cfg5 (W8 B64 K2 d1024), against the reference's own global step
@@ -266,21 +270,25 @@ def test_production_packed_step_every_rank_full_size(name, kn, dev):
     W, B, K, d, T = meta["W"], meta["B"], meta["K"], meta["d"], meta["T"]
     own, n_ctx = meta["own_rank"], B * K
     parts, rows_c, Cb = _packed_world(meta, kn, dev)
+    want_G = plan == "with-dscores"
+    if not want_G and kn._wants_g(B, W * rows_c, d):
+        pytest.skip("this shape's default plan materialises the dScores: covered by the with-dscores leg")
     inv_T = 1.0 / T
     Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
     dC = torch.zeros((W * rows_c, d), dtype=torch.float64, device=dev)
     local, lses, dq_own, rl_all = [], [], None, []
     for r in range(W):
         rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev),
-                                                              inv_T, inv_T / (W * B))
+                                                              inv_T, inv_T / (W * B), want_G=want_G)
         assert np.array_equal(Qb.float().cpu().numpy(), parts[r][0])  # bf16 copy-out of the fp32-operand sim kernel
         dC += dcp.double()  # what the reduce-scatter sums
         local.append(ls.item())
         lses.append(lse.cpu().numpy())
         rl_all.append(rl.cpu().numpy())
         assert abs(ls.item() - rl.double().sum().item()) <= 1e-5 * max(1.0, abs(ls.item()))
-        Gf = G.float()
-        assert Gf.sum(dim=1).abs().max().item() <= 2e-2 * inv_T / (W * B)  # softmax - onehot: rows sum to zero
+        assert (G is not None) == want_G
+        if want_G:
+            assert G.float().sum(dim=1).abs().max().item() <= 2e-2 * inv_T / (W * B)  # softmax - onehot: rows sum to zero
         if r == own:
             dq_own = dq.cpu().numpy()
     loss = sum(local) / (W * B)
@@ -288,6 +296,9 @@ def test_production_packed_step_every_rank_full_size(name, kn, dev):
     assert rel(np.concatenate(lses), g["lse"]) <= LOGIT_RTOL
     assert rel(dq_own, g["dq_own"]) <= GRAD_RTOL
     chunk = dC.cpu().numpy().reshape(W, rows_c, d)[own]
+    print(f"[plan-error] {name} {plan}: loss rel {abs(loss - g['loss']) / max(1.0, abs(g['loss'])):.2e}  dq_own {rel(dq_own, g['dq_own']):.2e}  "
+          f"dc_own_head {rel(chunk[:64], g['dc_own_head']):.2e}  dc_own_rowsum {rel(chunk[:n_ctx].sum(1), g['dc_own_rowsum']):.2e}  "
+          f"dc_own_colsum {rel(chunk[:n_ctx].sum(0), g['dc_own_colsum']):.2e}")
     assert rel(chunk[:64], g["dc_own_head"]) <= GRAD_RTOL
     assert rel(chunk[:n_ctx].sum(1), g["dc_own_rowsum"]) <= GRAD_RTOL
     assert rel(chunk[:n_ctx].sum(0), g["dc_own_colsum"]) <= GRAD_RTOL
@@ -408,16 +419,23 @@ def test_packed_step_narrow_sim_units_against_the_oracle(W, B, K, d, kn, dev):
     assert rel(got, ref["dC"]) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("plan", ["with-dscores", "default-plan"])
+@pytest.mark.parametrize("name", golden_names("cfg3"))
 @pytest.mark.parametrize("wire", ["fp32", "bf16"])
-def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
-    """dprhot_train_step_packed_f32 -- what the autograd operator runs under DDP -- for EVERY rank of cfg3 against the
+def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, name, plan, kn, dev):
+    """Every cfg3 fixture the reference wrote (U ragged T 1, U ragged T 0.05, peaky T 1), in the plan that materialises the dScores
+    and in the one production takes by default (G == NULL: no dScores launch), in both wire formats of the reduce-scatter.
+    dprhot_train_step_packed_f32 -- what the autograd operator runs under DDP -- for EVERY rank of cfg3 against the
     reference's global step: the loss leaves the kernel as the mean (loss_scale = 1 / Nq), the gradients are scaled by a
     DEVICE grad_output (here 8), and dC_part is written as fp32 or, for the bf16 wire of the reduce-scatter, as bf16 by the
     dC epilogue itself (each partial rounded once; summed here in fp64 like the all-pairs reduce-scatter sums in fp32)."""
-    meta, g = load_golden("cfg3_Ur_T1")
+    meta, g = load_golden(name)
     W, B, K, d, T = meta["W"], meta["B"], meta["K"], meta["d"], meta["T"]
     own, n_ctx = meta["own_rank"], B * K
     parts, rows_c, Cb = _packed_world(meta, kn, dev)
+    want_G = plan == "with-dscores"
+    if not want_G and kn._wants_g(B, W * rows_c, d):
+        pytest.skip("this shape's default plan materialises the dScores")
     inv_T, go = 1.0 / T, 8.0
     dt = torch.float32 if wire == "fp32" else torch.bfloat16
     d_scale = torch.full((1,), go, device=dev)
@@ -426,8 +444,8 @@ def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
     loss, dq_own = 0.0, None
     for r in range(W):
         rl, lse, lo, G, dq, dcp = kn.train_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), inv_T,
-                                                           inv_T / (W * B), 1.0 / (W * B), d_scale, dt)
-        assert dcp.dtype == dt
+                                                           inv_T / (W * B), 1.0 / (W * B), d_scale, dt, want_G=want_G)
+        assert dcp.dtype == dt and (G is not None) == want_G
         dC += dcp.double()
         loss += lo[0].item()  # the all-reduce of the per-rank means
         assert abs(lo[0].item() * W * B - rl.double().sum().item()) <= 1e-5 * max(1.0, rl.double().sum().item())
@@ -437,7 +455,7 @@ def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
             # differs from the expected one: dQ = go2 * sum of the slabs, dC rescaled by go2 / go)
             go2 = torch.full((1,), 2.0, device=dev)
             _, _, _, _, dq_def, dcp2 = kn.train_step_packed_f32(t(parts[r][0], dev), Cb, Qb, W, r, n_ctx, t(parts[r][2], dev), inv_T,
-                                                                inv_T / (W * B), 1.0 / (W * B), d_scale, dt, defer_dq=True)
+                                                                inv_T / (W * B), 1.0 / (W * B), d_scale, dt, defer_dq=True, want_G=want_G)
             nsl = kn._lib.train_dq_slabs(B, W * rows_c, d)  # 0 where the step finishes dQ itself (the plan without a dScores launch)
             assert (isinstance(dq_def, tuple) and dq_def[1].shape[0] == nsl) if nsl else not isinstance(dq_def, tuple)
             out2 = kn.rescale_grads(dq_def, dcp2, go2, d_scale)
@@ -447,6 +465,9 @@ def test_train_step_packed_every_rank_cfg3_in_both_wire_formats(wire, kn, dev):
     assert abs(loss - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
     assert rel(dq_own, g["dq_own"]) <= GRAD_RTOL
     chunk = dC.cpu().numpy().reshape(W, rows_c, d)[own] / go
+    print(f"[plan-error] train-step {name} {plan} {wire}: loss rel {abs(loss - g['loss']) / max(1.0, abs(g['loss'])):.2e}  dq_own {rel(dq_own, g['dq_own']):.2e}  "
+          f"dc_own_head {rel(chunk[:64], g['dc_own_head']):.2e}  dc_own_rowsum {rel(chunk[:n_ctx].sum(1), g['dc_own_rowsum']):.2e}  "
+          f"dc_own_colsum {rel(chunk[:n_ctx].sum(0), g['dc_own_colsum']):.2e}")
     assert rel(chunk[:64], g["dc_own_head"]) <= GRAD_RTOL
     assert rel(chunk[:n_ctx].sum(1), g["dc_own_rowsum"]) <= GRAD_RTOL
     assert rel(chunk[:n_ctx].sum(0), g["dc_own_colsum"]) <= GRAD_RTOL
