@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SEARCH_GROUP, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SEARCH_GROUP, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -152,6 +152,8 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
     {"sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},
     {"search_group", 0, "1: dprhot_search merges warm chunks in groups of up to four (one merge launch per group; measured: 4.76 ms either way at 1024 x 2 M x 768, k = 1000 -- the merged lists are as much longer as the launches are fewer)"},
+    {"sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
+    {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
 };
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
 const bool g_opt_defaults = [] {
@@ -603,6 +605,20 @@ int launch_sk_sim_c(const SkSimArgs& a, int grid, hipStream_t st) {
   const size_t lds = sk_sim_lds();
   static AttrOnce attr_done[3];  // benign race: idempotent
   if constexpr (COLS == SK_COLS) {
+    if (a.q != nullptr && opt(OPT_SK_SIM_PRIV) != 0 && grid <= kNumCU) {
+      // wave-private rings, one workgroup per CU (round 5): as many chunks in flight per wave as 160 KiB of LDS hold next to the q block
+      constexpr int PS = NCH <= 12 ? 6 : (NCH <= 14 ? 5 : 4);
+      auto kern = sk_simp_kernel<NCH, PS>;
+      const size_t ldsp = sk_simp_lds(NCH, PS);
+      static AttrOnce attr_p;
+      if (!attr_p) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
+        attr_p = true;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), ldsp, st, a);
+      HIP_TRY(hipGetLastError());
+      return DPRHOT_OK;
+    }
     if (a.q != nullptr && opt(OPT_SK_SIM_W8) != 0) {
       auto kern = sk_sim_kernel<NCH, true, COLS, SLOTS, 8>;
       if (!attr_done[2]) {
@@ -656,9 +672,13 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   const SkFused fz = sk_fused_plan(sk, nts, nk_f, B, Nc, d);
   const bool fused = G == nullptr && S_out == nullptr && fz.ok;
   if (G == nullptr && !fused) return fail(DPRHOT_E_INVALID, "few-rows step: G == NULL needs the fused-dScores plan (dprhot_step_wants_g)");
+  // the finishing role inside the backward launch (sk_fin_unit): two-kinds form only; a dbg switch that silences units would strand it
+  const bool tail = fused && !fz.pair && opt(OPT_SK_TAIL) != 0 && opt(OPT_SK_DBG) == 0 && fz.nslices <= 62 && d <= 1024;
+  unsigned* const tail_cnt = reinterpret_cast<unsigned*>(ws + wl.header + 128);
   if (fused) {
     a.S = nullptr;
     a.P = reinterpret_cast<uint16_t*>(ws + wl.logits);
+    if (tail) a.zero_me = tail_cnt;
   }
   const int grid1 = sk.nrb * nts;
   int rc = DPRHOT_OK;
@@ -688,7 +708,12 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done[slot] = true;
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)(ndq_pad + ndc)), dim3((unsigned)threads), lds, st, b);
+      if (tail) {
+        b.tail_cnt = tail_cnt;
+        b.nfin = cdiv(B, threads / 256);
+        b.tail_fence = opt(OPT_SK_TAIL) == 2 ? 1 : 0;
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)(ndq_pad + ndc + b.nfin)), dim3((unsigned)threads), lds, st, b);
       return DPRHOT_OK;
     };
     static AttrOnce attr_pair[2];
@@ -718,7 +743,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());
-    {
+    if (!tail) {
       // one workgroup per row where the row fits 256 threads (d <= 1024): the row's statistics are derived once, not once per part
       const int fthreads = d / 4 >= 256 ? 256 : cdiv(d / 4, 64) * 64;
       const int parts = cdiv(d / 4, fthreads);

@@ -64,6 +64,27 @@ __device__ __forceinline__ void sk_wait_younger(int n) {
     default: sk_wait_vm<7 * PER>(); break;
   }
 }
+// wait until at most n vector-memory operations of this wave are outstanding (n a constant after unrolling, 0..15)
+__device__ __forceinline__ void sk_wait_vm_n(int n) {
+  switch (n) {
+    case 0: sk_wait_vm<0>(); break;
+    case 1: sk_wait_vm<1>(); break;
+    case 2: sk_wait_vm<2>(); break;
+    case 3: sk_wait_vm<3>(); break;
+    case 4: sk_wait_vm<4>(); break;
+    case 5: sk_wait_vm<5>(); break;
+    case 6: sk_wait_vm<6>(); break;
+    case 7: sk_wait_vm<7>(); break;
+    case 8: sk_wait_vm<8>(); break;
+    case 9: sk_wait_vm<9>(); break;
+    case 10: sk_wait_vm<10>(); break;
+    case 11: sk_wait_vm<11>(); break;
+    case 12: sk_wait_vm<12>(); break;
+    case 13: sk_wait_vm<13>(); break;
+    case 14: sk_wait_vm<14>(); break;
+    default: sk_wait_vm<15>(); break;
+  }
+}
 __device__ __forceinline__ void sk_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -97,6 +118,7 @@ struct SkSimArgs {
   // What the backward needs of the row softmax is then one factor per (row, tile), exp(tile_lse - row_lse): no launch in between
   // has to see whole rows.
   uint16_t* P = nullptr;
+  unsigned* zero_me = nullptr;  // a counter of the NEXT launch of the step (sk_bwdf_kernel's finishing role): zeroed here, one launch ahead
 };
 
 constexpr int SK_ASTAGE = 2 * SK_ROWS * SK_KC;  // elements: two [32 rows][64 k] images of the q rows
@@ -130,6 +152,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sk_sim_kernel(SkSimArgs p) {
   const int rb = unit % nrb, ct = unit / nrb;
   const int m0 = rb * SK_ROWS;
   const int n0 = p.tiles_per_rank > 0 ? (ct / p.tiles_per_rank) * p.p_rows_c + (ct % p.tiles_per_rank) * COLS : ct * COLS;
+  if (p.zero_me != nullptr && blockIdx.x == 0 && tid == 0) *p.zero_me = 0u;
   DPRHOT_TMB(0, 0);
 
   // ---- every global read of the unit's first phase, back to back: the q rows (registers: thread t holds the 8 values
@@ -309,6 +332,265 @@ __global__ __launch_bounds__(NW * 64, 2) void sk_sim_kernel(SkSimArgs p) {
   }
   if (p.tiles_per_rank > 0 && ct % p.tiles_per_rank == p.tiles_per_rank - 1) {
     // the header rows behind this rank's real rows: masked columns of the logit matrix
+    const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (ct / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
+    for (int i = tid; i < SK_ROWS * hdr; i += NT) {
+      const int row = m0 + i / hdr;
+      if (row < p.B) {
+        if (p.S != nullptr) p.S[(size_t)row * p.Nc + h0 + i % hdr] = -INFINITY;
+        if (p.P != nullptr) p.P[(size_t)row * p.Nc + h0 + i % hdr] = 0;
+      }
+    }
+  }
+  DPRHOT_TMB(0, 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the same sim unit with PRIVATE rings -- no barrier inside the K loop.
+// scratch/ingest2 (profiles/r05_ingest2.txt) settled what the K loop of sk_sim_kernel is bound by: NOT the texture path's
+// acceptance of LDS-DMA pieces -- the same 196 KiB C tile, the same 1-KiB pieces, the same one-barrier-per-chunk ring arrive
+// in 1.7 us (48 B/clk per CU) when nothing is multiplied, against 3.5 us for the kernel's twelve chunks -- and not something
+// register streaming would fix (MFMA-fragment-shaped global_load_dwordx4, 16 rows x 64 B per instruction: 20 B/clk; whole
+// 128-byte lines to registers: 64 B/clk, but those are not fragments).  What is left is the loop's own chain: every chunk is
+// wait -> workgroup barrier -> six fragment reads -> four MFMAs, eight waves in lock step, ~700 clocks per 16-KiB chunk with one
+// workgroup per CU and nothing to run beside it.  A C row is used by exactly one 16-column MFMA block, so here every wave owns
+// its 16 columns outright: it DMAs them (2 KiB per k chunk, two pieces) into its own ring, waits on its own vmcnt, reads its own
+// fragments -- no other wave ever touches them, so no barrier orders them.  The q block (32 rows x d, rounded to bf16) is shared by
+// all eight waves: it is written to LDS ONCE, whole, in the prologue (d = 768: 48 KiB) behind the only barrier of the loop.  Waves
+// drift apart freely; two of them per SIMD cover each other's waits.  LDS = d / 64 x 4 KiB + 8 x SLOTS x 2 KiB (768: 144 KiB with
+// six chunks in flight per wave): one workgroup per CU, so the launch takes this kernel only where the grid fits the chip once
+// (cfg3 per rank: 256 units).  Outputs are those of sk_sim_kernel<NCH, true, 128, 4, 8> bit for bit (same k order per element).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned sk_u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void sk_ldsr128(sk_u32x4p& r, const void* lds_ptr) {  // asm: a plain ds_read next to LDS-DMAs in flight gets vmcnt(0) from hipcc
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  const unsigned addr = (unsigned)(uintptr_t)(lds_u32*)const_cast<void*>(lds_ptr);
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ bf16x8 sk_as_frag(const sk_u32x4p& r) {
+  union { sk_u32x4p u; bf16x8 f; } c;
+  c.u = r;
+  return c.f;
+}
+__device__ __forceinline__ f32x4 sk_ld16_early(const void* ptr) {  // asm loads: invisible to hipcc's wait counters, waited for by hand
+  f32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+__device__ __forceinline__ unsigned sk_ld4u_early(const void* ptr) {
+  unsigned r;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+__device__ __forceinline__ unsigned sk_ld1_early(const void* ptr) {
+  unsigned r;
+  asm volatile("global_load_ubyte %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+__device__ __forceinline__ void sk_lds_w128(void* lds_ptr, uint4 v) {
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  const unsigned addr = (unsigned)(uintptr_t)(lds_u32*)lds_ptr;
+  const sk_u32x4p val = {v.x, v.y, v.z, v.w};
+  asm volatile("ds_write_b128 %0, %1\n\ts_nop 1" ::"v"(addr), "v"(val) : "memory");
+}
+__device__ __forceinline__ void sk_lds_w64(void* lds_ptr, uint2 v) {
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  typedef unsigned sk_u32x2p __attribute__((ext_vector_type(2)));
+  const unsigned addr = (unsigned)(uintptr_t)(lds_u32*)lds_ptr;
+  const sk_u32x2p val = {v.x, v.y};
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(val) : "memory");
+}
+inline size_t sk_simp_lds(int nch, int slots) { return (size_t)nch * SK_ROWS * SK_KC * 2 + (size_t)8 * slots * 16 * SK_KC * 2; }
+
+template <int NCH, int SLOTS>
+__global__ __launch_bounds__(512, 2) void sk_simp_kernel(SkSimArgs p) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
+  constexpr int D = NCH * SK_KC, NT = 512, COLS = SK_COLS;
+  constexpr int QIMG = SK_ROWS * SK_KC;  // elements of one k chunk of the q block  [32 rows][64 k], 16-byte chunk c of row r at c ^ ((r >> 1) & 7)
+  constexpr int WSLOT = 16 * SK_KC;      // elements of one ring slot of a wave     [16 n][64 k], same swizzle
+  constexpr int NQ = NCH / 2;            // k chunks of the q rows a thread holds (chunk 2 i + tid / 256)
+  constexpr int NS = SLOTS < NCH ? SLOTS : NCH;
+  static_assert(NCH % 2 == 0, "k chunks per thread half");
+  uint16_t* const Qs = sk_smem;
+  uint16_t* const ring = sk_smem + NCH * QIMG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kh = tid >> 8;
+  const int nrb = (p.B + SK_ROWS - 1) / SK_ROWS;
+  const int unit = sk_xcd_order(blockIdx.x, gridDim.x);
+  const int rb = unit % nrb, ct = unit / nrb;
+  const int m0 = rb * SK_ROWS;
+  const int n0 = p.tiles_per_rank > 0 ? (ct / p.tiles_per_rank) * p.p_rows_c + (ct % p.tiles_per_rank) * COLS : ct * COLS;
+  if (p.zero_me != nullptr && blockIdx.x == 0 && tid == 0) *p.zero_me = 0u;
+  DPRHOT_TMB(0, 0);
+
+  // ---- every global read of the prologue back to back: the q rows (fp32; OLDEST, so that a counted wait releases them while the
+  //      chunks behind them are still landing), the first NS chunks of this wave's columns, mask byte and label.  The q rows, the
+  //      mask byte and the label are asm loads counted by hand: hipcc answers the first use of an ordinary load next to an LDS-DMA
+  //      with s_waitcnt vmcnt(0), which held the whole prologue (q AND six chunks, 194 KiB per CU) in front of the first MFMA.
+  // One load instruction = 8 rows x 128 contiguous bytes (whole lines): lane l takes floats [h * 32 + (l & 7) * 4, + 4) of k chunk kc of
+  // row l >> 3, h = 0, 1.  (sk_sim_kernel's form -- 8 consecutive floats per lane as two loads 16 bytes apart -- makes every instruction
+  // touch half of each of 16 lines: the access shape scratch/ingest2 measured at 20 B/clk per CU against 64 for whole lines, and the
+  // q block is a third of this unit's bytes.)
+  const int arow = (tid & 255) >> 3, ac8 = tid & 7;
+  f32x4 areg[NQ][2];
+  {
+    const int gr = min(m0 + arow, p.B - 1);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const float* src = p.q + (size_t)gr * D + (i * 2 + kh) * SK_KC + ac8 * 4;
+      areg[i][0] = sk_ld16_early(src);
+      areg[i][1] = sk_ld16_early(src + 32);
+    }
+  }
+  const int i16 = lane & 15, g4 = lane >> 4;
+  unsigned cof[2];  // element offset of this lane's source chunk inside a k chunk, per DMA instruction (8 rows of 128 bytes)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = wave * 16 + j * 8 + (lane >> 3);
+    cof[j] = (unsigned)min(n0 + row, p.Nc - 1) * (unsigned)D + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+  uint16_t* const myring = ring + wave * (SLOTS * WSLOT);
+  auto issue = [&](int kc, int slot) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(p.C + cof[j] + kc * SK_KC), (g2_lds_ptr*)(myring + slot * WSLOT + j * 512), 16, 0, 0);
+  };
+#pragma unroll
+  for (int c = 0; c < NS; ++c) issue(c, c);
+  const bool have_mask = p.packed != nullptr || p.colmask != nullptr;
+  const uint8_t* const mbase = p.packed != nullptr ? p.packed : (p.colmask != nullptr ? p.colmask : reinterpret_cast<const uint8_t*>(p.y));
+  unsigned mraw;
+  bool mover;
+  {
+    const int n = min(n0 + wave * 16 + i16, p.Nc - 1);
+    const int rc = p.packed != nullptr ? p.p_rows_c : 1;
+    const int r = n / rc, j = n - r * rc;
+    mover = p.packed != nullptr && j >= p.p_n_ctx;
+    const size_t off = p.packed != nullptr ? (size_t)(r * rc + p.p_n_ctx) * p.p_row_bytes + min(j, p.p_n_ctx - 1)
+                                           : (p.colmask != nullptr ? (size_t)n : (size_t)0);
+    mraw = sk_ld1_early(mbase + off);
+  }
+  constexpr int TPR = NT / SK_ROWS;  // 16 threads per row in the statistics phase
+  const int srow = tid / TPR, sseg = tid % TPR;
+  unsigned yraw = sk_ld4u_early(reinterpret_cast<const int*>(p.y) + 2 * min(m0 + srow, p.B - 1));
+  constexpr int NEARLY = 2;  // the two loads behind the DMAs
+  DPRHOT_TMB(0, 1);
+
+  // ---- q rows -> bf16 -> the whole q block into LDS (and to Qb for the backward), one barrier
+  sk_wait_vm<2 * NS + NEARLY>();  // the q rows have landed (in-order return); the chunks stay in flight
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) asm volatile("" : "+v"(areg[i][0]), "+v"(areg[i][1]));
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int kc = i * 2 + kh;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 a = areg[i][h];
+      const uint2 v = make_uint2(pack_bf16_rne(__float_as_uint(a[0]), __float_as_uint(a[1])), pack_bf16_rne(__float_as_uint(a[2]), __float_as_uint(a[3])));
+      // elements k = h * 32 + ac8 * 4 .. + 4 of the row: half (ac8 & 1) of 16-byte chunk h * 4 + (ac8 >> 1)
+      const int ch = h * 4 + (ac8 >> 1);
+      if (p.Qb != nullptr && ct == 0 && m0 + arow < p.B) *reinterpret_cast<uint2*>(p.Qb + (size_t)(m0 + arow) * D + kc * SK_KC + h * 32 + ac8 * 4) = v;
+      sk_lds_w64(Qs + kc * QIMG + arow * SK_KC + ((ch ^ ((arow >> 1) & 7)) << 3) + (ac8 & 1) * 4, v);  // (asm: a plain LDS store next to the DMAs would drain them)
+    }
+  }
+  sk_barrier();  // lgkmcnt(0) + raw s_barrier: the q block is in place, nobody's chunks were waited for
+  DPRHOT_TMB(0, 2);
+
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    // this wave's chunk c has landed: what may still be outstanding are the chunks behind it -- prologue chunks c + 1 .. NS - 1 and the two
+    // early loads (c < NS), refills NS .. min(c - 1 + SLOTS, NCH - 1) issued by iterations 0 .. c - 1 -- two operations per chunk.  (The Qb
+    // stores of the ct == 0 units sit between the prologue and the refills: not counted, so those units wait for a little more.)
+    {
+      const int last = (c - 1 + SLOTS < NCH - 1) ? c - 1 + SLOTS : NCH - 1;  // last chunk issued so far (c >= 1), or NS - 1
+      const int issued_last = c == 0 ? NS - 1 : (last > NS - 1 ? last : NS - 1);
+      sk_wait_vm_n(2 * (issued_last - c) + (c < NS ? NEARLY : 0));  // (a constant after unrolling)
+    }
+    const uint16_t* const Bs = myring + (c % SLOTS) * WSLOT;
+    const uint16_t* const Ac = Qs + c * QIMG;
+    sk_u32x4p bq[2], aq[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      sk_ldsr128(bq[kk], Bs + i16 * SK_KC + (((kk * 4 + g4) ^ ((i16 >> 1) & 7)) << 3));
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int row = a * 16 + i16;
+        sk_ldsr128(aq[kk][a], Ac + row * SK_KC + (((kk * 4 + g4) ^ ((row >> 1) & 7)) << 3));
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + SLOTS < NCH) issue(c + SLOTS, c % SLOTS);  // the slot just read is this wave's alone: refill it at once
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sk_as_frag(aq[kk][a]), sk_as_frag(bq[kk]), acc[a], 0, 0, 0);
+  }
+  sk_wait_vm<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(mraw), "+v"(yraw));
+  __syncthreads();  // every wave is done with its ring: the ring's start becomes the fp32 logit tile [32][COLS + 4]
+  DPRHOT_TMB(0, 3);
+
+  // ---- epilogue: mask, 1/T -> LDS tile -> per-row tile logsumexp, gold logit, tile softmax / logits out in 16-byte stores
+  constexpr int TS = COLS + 4;
+  float* const T = reinterpret_cast<float*>(ring);
+  {
+    const int col = wave * 16 + i16;
+    const bool masked = (n0 + col >= p.Nc) || mover || (have_mask && mraw != 0);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(a * 16 + g4 * 4 + r) * TS + col] = masked ? -INFINITY : acc[a][r] * p.inv_T;
+  }
+  __syncthreads();
+  {
+    const int row = m0 + srow;
+    const int yi = (int)yraw + (int)p.y_offset - n0;  // gold column relative to the tile
+    const int col = sseg * 8;                    // this thread's eight consecutive columns
+    const float4 v0 = *reinterpret_cast<const float4*>(T + srow * TS + col), v1 = *reinterpret_cast<const float4*>(T + srow * TS + col + 4);
+    float mx = fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
+    mx = ss_max8(mx);
+    mx = fmaxf(mx, ss_dpp<0x140>(mx));  // row_mirror: the other eight lanes of the row
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sm = 0.f;
+    if (mx != -INFINITY) {
+      e[0] = __expf(v0.x - mx); e[1] = __expf(v0.y - mx); e[2] = __expf(v0.z - mx); e[3] = __expf(v0.w - mx);
+      e[4] = __expf(v1.x - mx); e[5] = __expf(v1.y - mx); e[6] = __expf(v1.z - mx); e[7] = __expf(v1.w - mx);
+      // (the order of sk_sim_kernel's sums: the two float4 of a thread there are columns sseg * 4 and 64 + sseg * 4 -- a different
+      //  association of the same 128 terms; tile_lse may differ from that kernel's in the last bit)
+      sm = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+    }
+    sm = ss_sum8(sm);
+    sm += ss_dpp<0x140>(sm);
+    if (row < p.B) {
+      if (sseg == 0) p.tile_lse[((size_t)(ct >> 2) * p.B + row) * 4 + (ct & 3)] = mx == -INFINITY ? -INFINITY : mx + logf(sm);
+      const float inv = sm > 0.f ? 1.0f / sm : 0.f;
+      if (yi >= col && yi < col + 8) {
+        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float gsel = vv[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) gsel = yi == col + u ? vv[u] : gsel;
+        p.gold[row] = gsel;
+      }
+      if (n0 + col < p.Nc) {  // (Nc % 8 == 0 and n0 % 8 == 0: the eight columns are in or out together)
+        if (p.S != nullptr) {
+          *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col) = v0;
+          *reinterpret_cast<float4*>(p.S + (size_t)row * p.Nc + n0 + col + 4) = v1;
+        }
+        if (p.P != nullptr) {
+          float pe[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pe[u] = yi == col + u ? 0.f : e[u] * inv;  // the gold column leaves as 0 (its term is added in fp32 by the backward)
+          *reinterpret_cast<uint4*>(p.P + (size_t)row * p.Nc + n0 + col) =
+              make_uint4(pk_bf16(pe[0], pe[1]), pk_bf16(pe[2], pe[3]), pk_bf16(pe[4], pe[5]), pk_bf16(pe[6], pe[7]));
+        }
+      }
+    }
+  }
+  if (p.tiles_per_rank > 0 && ct % p.tiles_per_rank == p.tiles_per_rank - 1) {
     const int hdr = p.p_rows_c - p.p_n_ctx, h0 = (ct / p.tiles_per_rank) * p.p_rows_c + p.p_n_ctx;
     for (int i = tid; i < SK_ROWS * hdr; i += NT) {
       const int row = m0 + i / hdr;
@@ -806,6 +1088,11 @@ struct SkBwdFArgs {
   int ndq_pad;
   int nt_store;
   int dbg = 0;            // TIMING EXPERIMENTS ONLY (option sk_dbg): 1 dC units leave at once, 2 dQ units leave at once, 
+  // Round 5: the finishing role INSIDE this launch (sk_fin_unit): the dQ units publish their slabs with write-through stores and count
+  // themselves in; the last workgroups of the grid wait for that count and fold the slabs.  nullptr: sk_dq_finish_kernel does it.
+  unsigned* tail_cnt = nullptr;  // zeroed by the sim launch (SkSimArgs::zero_me)
+  int nfin = 0;                  // finishing workgroups (rows / (threads / 256))
+  int tail_fence = 0;            // 1: ordinary slab stores + ONE release fence per dQ unit, acquire fence + ordinary loads in the finishing role (A/B of the publish form)
 };
 
 constexpr int SK_FT = 8;                            // statistics tiles a dQ unit may touch ((ksteps + 1) / 2 + 1 <= SK_FT: sk_fused_ok)
@@ -831,6 +1118,17 @@ typedef unsigned sk_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ sk_u32x2 sk_ld8_hidden(const void* ptr) {
   sk_u32x2 r;
   asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(ptr) : "memory");
+  return r;
+}
+// write-through (sc1) 16-byte store: leaves this XCD's L2 at once -- the payload of an in-launch hand-off (guide 6 G16, R1 form);
+// the statement ends with s_nop 1 (guide 5.7 item 1: hipcc may otherwise overwrite the data registers before the store has read them)
+__device__ __forceinline__ void sk_st16_sc1(void* ptr, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory");
+}
+// the matching load: served by L2 / memory, never by this CU's L1 (asm: counted by hand like the other hidden loads)
+__device__ __forceinline__ f32x4 sk_ld16_sc1(const void* ptr) {
+  f32x4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(ptr) : "memory");
   return r;
 }
 // LDS stores next to LDS-DMAs in flight: asm, for the reason given at sk_sim_kernel's q chunk (hipcc would drain the queue first)
@@ -926,9 +1224,27 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   const int ns = min(p.ksteps, nk - s0);
   const int t0 = s0 >> 1;
   float* const out = p.part + (size_t)ks * p.B * p.d;
+  // publish (finishing role in this launch): the slab went out with write-through stores; every wave drains its own, the barrier
+  // collects the waves, ONE relaxed device-scope add counts the unit in (guide 5 "in-launch split-K reduction", the sc1 form: no
+  // L2 write-back fence -- this XCD's L2 is full of the dC units' dirty lines)
+  auto publish = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      if (p.tail_fence) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (guide 6 G16 pitfall 12: the wait behind buffer_wbl2 restated where hipcc cannot drop it)
+      }
+      __hip_atomic_fetch_add(p.tail_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   if (ns <= 0) {  // a remapped tiling with fewer steps than the plan's slices cover: this slice is empty, its slab is zero
-    for (int e = tid; e < p.B * (SK_QN / 4); e += NT)
-      *reinterpret_cast<float4*>(out + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < p.B * (SK_QN / 4); e += NT) {
+      float* const dst = out + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4;
+      if (p.tail_cnt != nullptr && !p.tail_fence) sk_st16_sc1(dst, f32x4{0.f, 0.f, 0.f, 0.f});
+      else *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.tail_cnt != nullptr) publish();
     return;
   }
   float* const fs = reinterpret_cast<float*>(sk_smem + SK_QSLOTS * SLOT);  // [SK_FT][128]: weight of (local tile, row)
@@ -1167,10 +1483,12 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     const int e = tid + it * NT, row = e >> 4, cq = e & 15;
     if (row < p.B) {
       const float4 v = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
-      if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
+      if (p.tail_cnt != nullptr && !p.tail_fence) sk_st16_sc1(out + (size_t)row * p.d + c0 + cq * 4, f32x4{v.x, v.y, v.z, v.w});
+      else if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
       else *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + cq * 4) = v;
     }
   }
+  if (p.tail_cnt != nullptr) publish();
   DPRHOT_TMB(2, 3);
 }
 
@@ -1476,6 +1794,101 @@ __global__ __launch_bounds__(256) void sk_dq_finish_kernel(SkFinArgs p) {
   }
 }
 
+// Finishing role inside the backward launch (round 5; option sk_tail): what sk_dq_finish_kernel does, by the LAST workgroups of the
+// grid, behind a count of the dQ units that have published their slabs.  Why inside: as a launch of its own the fold cost 4.6-4.8 us
+// plus a 0.5 us gap for 4.9 MB -- one cold start (kernel arguments, first wave, first data ~2 us) behind a boundary that also waits
+// for the write-back of the dC units' 25 MB -- on the step's critical path sim -> dQ units -> finish.  Here the finishing workgroups
+// are dispatched as soon as the first units of the launch leave (they are the grid's last blocks: every dQ unit has been handed a CU
+// before any of them is -- in-order dispatch, the argument of scratch/negative/chain.h), thread 0 polls the count with relaxed
+// device-scope loads, and the slabs arrive by sc1 loads from where the dQ units' write-through stores put them: no L2 write-back
+// fence, no invalidate.  A wait beyond 20 ms -- a bug, not a load condition -- poisons dQ with NaN.
+// One row per 256 threads (d <= 1024), NT / 256 rows per workgroup; LDS: the dynamic array's first bytes (never a second
+// __shared__ object next to LDS-DMA code: guide 5, trap 4a).
+template <int NW>
+__device__ __forceinline__ void sk_fin_unit(const SkBwdFArgs& p, int f, uint16_t* sk_smem) {
+  constexpr int NT = NW * 64, RPW = NT / 256;
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 8, t = tid & 255;
+  const int row = min(f * RPW + g, p.B - 1);
+  const bool live = f * RPW + g < p.B;
+  const int nq = p.d >> 2;
+  const bool ok = live && t < nq;
+  const int q4 = t < nq ? t : 0;
+  float* const s_e = reinterpret_cast<float*>(sk_smem) + g * (64 + 512);  // [64] slice factors | [128] float4 tile values of the row
+  float4* const s_t = reinterpret_cast<float4*>(s_e + 64);
+  const int ndq = p.nslices * (p.d / SK_QN);
+  const int nk = p.tiles_per_rank > 0 ? 2 * p.nt : (p.Nc + 63) / 64;
+  DPRHOT_TMB(3, 0);
+  // everything that does not depend on the slabs first: labels, gold rows, tile values (the sim launch wrote them: a launch ago)
+  const int yg = reinterpret_cast<const int*>(p.y)[2 * row] + (int)p.y_offset;
+  const uint2 cg = *reinterpret_cast<const uint2*>(p.C + (size_t)yg * p.d + q4 * 4);
+  const float gl = p.gold[row];
+  float4 tv[2];
+  const float lse = sk_row_lse_tv(p.tile_lse, p.nt, p.B, row, lane, tv);
+  if ((tid & 255) < 64) {
+    s_t[lane] = tv[0];
+    s_t[lane + 64] = tv[1];
+  }
+  __syncthreads();
+  if (t < p.nslices) {
+    const int s0 = t * p.ksteps, ns = min(p.ksteps, nk - s0);
+    float m = -INFINITY;
+    if (ns > 0) {
+      const int tlo = s0 >> 1, thi = min((s0 + ns - 1) >> 1, p.nt - 1);
+      const float* const st = reinterpret_cast<const float*>(s_t);
+      for (int tt = tlo; tt <= thi; ++tt) m = fmaxf(m, st[tt]);
+    }
+    s_e[t] = m == -INFINITY ? 0.f : __expf(m - lse) * p.grad_scale;
+  }
+  DPRHOT_TMB(3, 1);
+  // ---- the wait: every dQ unit has counted itself in
+  bool poisoned = false;
+  if (tid == 0) {
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(p.tail_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ndq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 2000000ull) { poisoned = true; break; }  // 20 ms of the 100 MHz clock
+    }
+    reinterpret_cast<int*>(s_e)[63] = poisoned ? 1 : 0;  // (nslices <= 62 is asserted by the host when this role is on)
+    if (p.tail_fence) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  poisoned = reinterpret_cast<const int*>(reinterpret_cast<const float*>(sk_smem))[63] != 0;
+  DPRHOT_TMB(3, 2);
+  const size_t slab4 = (size_t)p.B * nq, o4 = (size_t)row * nq + q4;
+  const float* const base = p.part + o4 * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int CH = 10;
+  for (int b0 = 0; b0 < p.nslices; b0 += CH) {
+    f32x4 v[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const float* const src = base + (size_t)min(b0 + u, p.nslices - 1) * slab4 * 4;
+      v[u] = p.tail_fence ? sk_ld16_hidden(src) : sk_ld16_sc1(src);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const float e = b0 + u < p.nslices ? s_e[b0 + u] : 0.f;
+      a.x = fmaf(e, v[u][0], a.x); a.y = fmaf(e, v[u][1], a.y); a.z = fmaf(e, v[u][2], a.z); a.w = fmaf(e, v[u][3], a.w);
+    }
+  }
+  DPRHOT_TMB(3, 3);
+  if (ok) {
+    const float gq = (__expf(gl - lse) - 1.0f) * p.grad_scale;
+    const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f);
+    a.x = fmaf(gq, sk_bf_lo(cg.x), a.x) * sc;
+    a.y = fmaf(gq, sk_bf_hi(cg.x), a.y) * sc;
+    a.z = fmaf(gq, sk_bf_lo(cg.y), a.z) * sc;
+    a.w = fmaf(gq, sk_bf_hi(cg.y), a.w) * sc;
+    if (poisoned) a = make_float4(NAN, NAN, NAN, NAN);
+    reinterpret_cast<float4*>(p.dQ)[(size_t)row * nq + q4] = a;
+  }
+  DPRHOT_TMB(3, 4);
+}
+
 // NW = 4: 256 threads.  NW = 8: 512 threads, the same LDS, half the output tile per wave (option sk_w8).  The stamps showed a dQ
 // unit's step bound by ONE wave's instruction stream (wait, barrier, 20 LDS reads, 16 MFMAs in a dependent chain: 0.73 us, of which
 // 0.11 waiting for the slot), and two dQ workgroups sharing a CU running at the speed of one: the CU has issue room for twice the waves.
@@ -1487,9 +1900,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void sk_bwdf_kernel(SkBwdFArgs p) 
   if (b < p.ndq_pad) {
     if (b >= ndq || (p.dbg & 2)) return;  // padding
     sk_dq_unit_f<NG, NW>(p, sk_xcd_order(b, ndq), sk_smem);
-  } else {
+  } else if (b < (int)gridDim.x - p.nfin) {
     if (p.dbg & 1) return;
-    sk_dc_unit_f<NG, NW>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.ndq_pad), sk_smem);
+    sk_dc_unit_f<NG, NW>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.nfin - p.ndq_pad), sk_smem);
+  } else {
+    sk_fin_unit<NW>(p, b - ((int)gridDim.x - p.nfin), sk_smem);
   }
 }
 

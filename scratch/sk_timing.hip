@@ -35,8 +35,8 @@ int main(int argc, char** argv) {
   std::vector<int64_t> hy(B); for (int i = 0; i < B; ++i) hy[i] = i * K; CK(hipMemcpy(y, hy.data(), B * 8, hipMemcpyHostToDevice)); CK(hipMemset(m, 0, n_ctx));
   dprhot_pack_ctx(c, m, n_ctx, d, send, nullptr);
   for (int r = 0; r < W; ++r) CK(hipMemcpy(Cb + (size_t)r * rows_c * d, send, (size_t)rows_c * d * 2, hipMemcpyDeviceToDevice));
-  const char* names[3] = {"sim", "dc ", "dq "};
-  const int nst[3] = {5, 6, 4};
+  const char* names[4] = {"sim", "dc ", "dq ", "fin"};
+  const int nst[4] = {5, 6, 4, 5};
   std::vector<unsigned long long> t(4 * 4096 * 8);
   for (int it = 0; it < 4; ++it) {
     CK(hipMemset(ws, 0, 64));
@@ -48,7 +48,10 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(t.data(), dptr, t.size() * 8, hipMemcpyDeviceToHost));
     if (it < 2) continue;
-    for (int k = 0; k < 3; ++k) {
+    { unsigned long long g0 = ~0ull; for (int k = 0; k < 3; ++k) for (int b = 0; b < 4096; ++b) { const unsigned long long v = t[((size_t)k * 4096 + b) * 8]; if (v && k > 0) g0 = std::min(g0, v); }
+      unsigned long long f0 = ~0ull, f1 = 0; for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)3 * 4096 + b) * 8]; if (r[0] && r[4]) { f0 = std::min(f0, r[0]); f1 = std::max(f1, r[4]); } }
+      if (f1) printf("it%d backward launch: first unit start -> first fin start %.2f us, -> last fin end %.2f us\n", it, (f0 - g0) * 0.01, (f1 - g0) * 0.01); }
+    for (int k = 0; k < (DPRHOT_TIMING >= 2 ? 3 : 4); ++k) {
       unsigned long long t0 = ~0ull, t1 = 0; int nb = 0;
       for (int b = 0; b < 4096; ++b) { const unsigned long long* r = &t[((size_t)k * 4096 + b) * 8]; if (r[0]) { ++nb; t0 = std::min(t0, r[0]); t1 = std::max(t1, r[nst[k] - 1]); } }
       if (nb == 0) { printf("it%d %s: no workgroups\n", it, names[k]); continue; }
