@@ -33,6 +33,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Kernel arguments in device memory instead of host-coherent memory (a documented ROCm runtime switch, read when the HIP runtime
+# initialises): every launch of these microsecond-scale kernels otherwise starts with a scalar load across PCIe -- measured on the
+# cfg3-per-rank step, eager C-ABI loop: 31.0 -> 26.0 us (hipGraph replays keep their arguments on the device either way).
+# dpr_scale_amd/__init__.py sets the same default for the product; an explicit value in the environment wins.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

@@ -296,3 +296,33 @@ def test_operator_takes_the_no_dscores_plan_and_survives_a_retained_graph(dev):
     c.grad = None
     loss.backward()
     assert _err(q.grad, dq1) <= 5e-3 and _err(c.grad, dc1) <= 5e-3
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_finishing_role_inside_the_backward_launch(mode, dev):
+    """Option sk_tail (round 5; measured slower, off by default, kept with this test): the dQ slabs folded by the last workgroups of
+    sk_bwdf_kernel behind a count of the dQ units -- mode 1 write-through slab stores + sc1 loads, mode 2 ordinary stores + release /
+    acquire fences -- must give exactly what the finishing launch gives (same slabs, same order of additions)."""
+    from dpr_scale_amd import _lib
+    from dpr_scale_amd.hotpath import HipKernels
+
+    kn = HipKernels()
+    for W, B, K, d, T in ((8, 128, 8, 768, 1.0), (8, 96, 11, 512, 0.5), (2, 128, 16, 1024, 0.25)):
+        qs, cs, y, ms = _world(W, B, K, d, dev, seed=W * 7 + K)
+        n_ctx = B * K
+        rows_c, Cb, colmask = _packed(kn, qs, cs, ms, dev)
+        if _lib.step_wants_g(B, W * rows_c, d):
+            continue
+        yd = y.to(dev)
+        Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+        outs = []
+        for tail in (0, mode, mode, 0):
+            _lib.set_option("sk_tail", tail)
+            try:
+                rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(qs[1], Cb, Qb, W, 1, n_ctx, yd, 1.0 / T, 1.0 / (T * W * B), want_G=False)
+                outs.append((dq.clone(), dcp.clone(), ls.item()))
+            finally:
+                _lib.set_option("sk_tail", 0)
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and o[2] == outs[0][2]
+        assert torch.isfinite(outs[1][0]).all()
