@@ -835,6 +835,157 @@ def timed_loop(run, steps, W, per_call=1, tail=None):
     return time.perf_counter() - t0
 
 
+class WireStep:
+    """One step as the autograd operator issues it under DDP, on HotPathStep's buffers: pack -> all-gather -> dprhot_train_step_packed_f32
+    (loss mean out of the kernel, dC partials in the wire format) -> dprhot_rescale_grads -> reduce-scatter in the wire format
+    (-> widen to fp32 for a half-width wire) -> all-reduce of the loss means.  The collectives are dpr_scale_amd.dist's, in whatever
+    transport / form dist.configure() names."""
+
+    def __init__(self, hp, wire):
+        self.hp, self.kind = hp, (2 if wire == "fp32" else 0)
+        dev, d = hp.q.device, hp.d
+        dt = torch.float32 if self.kind == 2 else torch.bfloat16
+        self.dCw = hp.dC if self.kind == 2 else torch.empty((hp.Nc, d), dtype=dt, device=dev)
+        self.mine = hp.dc if self.kind == 2 else torch.empty((hp.rows_c, d), dtype=dt, device=dev)
+        self.nsl = hp._lib.train_dq_slabs(hp.B, hp.Nc, d)
+        self.part = torch.empty((max(self.nsl, 1), hp.B, d), dtype=torch.float32, device=dev)
+        self.loss2 = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        # a plan without a bf16 dC epilogue (the latency-bound shapes: only the few-rows plan has one) writes fp32 partials, and the
+        # wire format is produced by one cast launch -- what InBatchContrastive.backward does (hotpath.py: dC_part.to(wire))
+        self.native = True
+        if self.kind != 2:
+            try:
+                self._train(self.kind, self.dCw)
+            except Exception as e:
+                if "dc_kind" not in str(e):
+                    raise
+                self.native = False
+
+    def _train(self, kind, dC):
+        hp, lib = self.hp, self.hp.lib
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        part = P(self.part) if self.nsl > 0 else None
+        rc = lib.dprhot_train_step_packed_f32(P(hp.q), P(hp.Cb), P(hp.Qb), hp.B, hp.W, hp.r, hp.n_ctx, hp.d, P(hp.y), hp.inv_T, hp.gscale, 1.0 / hp.Nq,
+                                              P(hp.go), P(hp.row_loss), P(hp.row_lse), P(self.loss2), P(hp.G) if hp.want_g else None, P(hp.dQ), part,
+                                              P(dC), kind, P(hp.ws), hp.ws_bytes, st)
+        rc = rc or lib.dprhot_rescale_grads(P(hp.dQ), hp.dQ.numel(), part, self.nsl, P(dC), dC.numel(), kind, P(hp.go), P(hp.go), P(self.out2), st)
+        if rc:
+            hp._lib.check(rc, "train step")
+
+    def step(self):
+        hp, lib = self.hp, self.hp.lib
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        hp.k_pack()
+        hp.D.all_gather_rows(hp.send, hp.Cb, hp.group)
+        if self.native:
+            self._train(self.kind, self.dCw)
+        else:
+            self._train(2, hp.dC)
+            hp._lib.check(lib.dprhot_cast_bf16(P(hp.dC), P(self.dCw), hp.dC.numel(), st), "dprhot_cast_bf16")
+        hp.D.reduce_scatter_rows(self.dCw, self.mine, hp.group)
+        if self.kind != 2:
+            hp._lib.check(lib.dprhot_grad_unpack(P(self.mine), self.kind, P(hp.dc), hp.dc.numel(), st), "dprhot_grad_unpack")
+        hp.D.all_reduce_sum(self.loss2[:1], hp.group)
+
+
+def variants_block(a, W, rank, dev, backend, B, K, d, T, hp, measure, state):
+    """N > 1 (or the forced one-rank world): transport x form x wire, each variant with a cross-rank check BEFORE it is timed -- the loss
+    identical on every rank, this rank's c.grad chunk within 8e-3 of max |grad| of the first variant's (torch.distributed, RCCL
+    collective, fp32 wire) -- and under its own watchdog: a variant that does not come back in DPRHOT_VARIANT_TIMEOUT seconds (120)
+    is reported as timed out, rank 0 prints the line with everything measured so far, and every rank exits."""
+    import threading
+
+    from dpr_scale_amd import dist as D
+
+    limit = float(os.environ.get("DPRHOT_VARIANT_TIMEOUT", "120"))
+    out, ref = {}, None
+    current = {"name": None}
+
+    def give_up():
+        if rank == 0 and state.get("line") is not None:
+            out[current["name"]] = {"error": f"timed out after {limit:.0f} s"}
+            line = dict(state["line"])
+            line["variants"] = out
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    def guarded(name, fn):
+        current["name"] = name
+        wd = threading.Timer(limit, give_up)
+        wd.daemon = True
+        wd.start()
+        try:
+            return fn()
+        finally:
+            wd.cancel()
+
+    # the C ABI communicator: opt-in in the product, brought up here (collectively, under its own watchdog inside enable_direct_comm
+    # plus this block's) so that its four variants can be measured; every rank gets it or none does
+    have_direct = False
+    if backend == "nccl" and os.environ.get("DPRHOT_DIRECT_RCCL", "1") != "0":
+        os.environ["DPRHOT_DIRECT_RCCL"] = "1"
+        D.configure(None, None)  # (direct=False would hide the communicator from its own set-up's return value)
+        have_direct = guarded("direct-comm-setup", lambda: D.enable_direct_comm(dev)) is not None
+    reps = max(3, min(7, a.repeats))
+    for transport in ("torch.distributed", "c-abi-communicator"):
+        for form in ("rccl", "allpairs"):
+            for wire in ("fp32", "bf16"):
+                name = f"{transport} | {'RCCL collective' if form == 'rccl' else 'all-pairs'} | {wire} dC wire"
+                if transport != "torch.distributed" and not have_direct:
+                    out[name] = {"skipped": "no C ABI communicator in this world (backend %s)" % backend}
+                    continue
+
+                def run_one():
+                    nonlocal ref
+                    D.configure(topology=form, direct=(transport != "torch.distributed"))
+                    ws = WireStep(hp, wire)
+                    ws.step()
+                    torch.cuda.synchronize()
+                    chk = {}
+                    loss = ws.loss2[:1].clone()
+                    mine_dc = hp.dc[:hp.n_ctx].clone()
+                    if W > 1:
+                        lc = loss if backend == "nccl" else loss.cpu()  # (gloo gathers host tensors)
+                        ls = [torch.empty_like(lc) for _ in range(W)]
+                        dist.all_gather(ls, lc)
+                        lv = torch.cat(ls)
+                        chk["loss_spread"] = float((lv.max() - lv.min()).item())
+                    else:
+                        chk["loss_spread"] = 0.0
+                    chk["loss"] = float(loss.item())
+                    if ref is None:
+                        ref = (loss.clone(), mine_dc)
+                        err = 0.0
+                    else:
+                        e = (mine_dc - ref[1]).abs().max() / ref[1].abs().max().clamp_min(1e-30)
+                        if W > 1:
+                            e = e if backend == "nccl" else e.cpu()
+                            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+                        err = float(e.item())
+                    chk["dc_err_vs_first_variant"] = err
+                    ok = chk["loss_spread"] <= 1e-6 * max(1.0, abs(chk["loss"])) and err <= 8e-3 and \
+                        abs(chk["loss"] - float(ref[0].item())) <= 1e-5 * max(1.0, abs(chk["loss"]))
+                    chk["ok"] = bool(ok)
+                    if not ok:
+                        return {"check": chk, "error": "cross-rank check failed: not timed"}
+                    saved = a.repeats
+                    a.repeats = reps
+                    try:
+                        ts = measure(ws.step)
+                    finally:
+                        a.repeats = saved
+                    el = sorted(ts)[len(ts) // 2]
+                    return {"check": chk, "ms_per_step": round(el / a.steps * 1e3, 5), "value": round(W * B * a.steps / el, 1), "repeats": len(ts)}
+
+                try:
+                    out[name] = guarded(name, run_one)
+                except Exception as e:
+                    out[name] = {"error": repr(e)}
+    D.configure(None, None)
+    return out
+
+
 def core_line(a, W, B, K, d, T, hp, els, driver, collectives, backend, DM):
     """The contract's keys from the R timed regions (median); roofline / kernels / extras are added by the caller."""
     es = sorted(els)
@@ -924,36 +1075,51 @@ def main():
             ts = tt.tolist()
         return ts
 
-    comm, torch_coll = None, None
+    comm, torch_coll, variants, collectives_name = None, None, None, "none"
     if DM:
-        # N > 1: first the step with torch.distributed's own RCCL collectives (the path every PyTorch-ROCm user exercises), so that
-        # a line exists whatever happens next; then the C ABI communicator (collectives enqueued on the step's own stream, no
-        # stream hand-over per call), which is the product path and the one reported when it comes up.  It has only ever run with
-        # one RCCL rank (one-GPU boxes): a watchdog prints the torch.distributed line if its set-up does not return.
+        # N > 1.  `value` is the step in the configuration the PRODUCT defaults to: torch.distributed's own RCCL communicator (the C ABI
+        # communicator is opt-in: DPRHOT_DIRECT_RCCL=1) and the FORM of the path's two collectives that dist.choose_path_collectives
+        # measures faster on this node (RCCL's all-gather / reduce-scatter, or the direct all-pairs exchange) -- the same probe
+        # DenseRetrieverTask.on_pretrain_routine_start runs.  Then, each under its own watchdog, the whole matrix
+        #     transport {torch.distributed, C ABI communicator} x form {RCCL collective, all-pairs} x dC wire {fp32, bf16}
+        # so that one run on a multi-GPU node yields the comparison, not one number (`variants`).
+        import threading
+
+        from dpr_scale_amd import dist as D
         hp = HotPathStep(B, K, d, T, W, rank, dev, comm=None, dist_mode=DM)
+        # first RCCL's own collectives through torch.distributed -- the form every PyTorch-ROCm user exercises -- so that a line exists
+        # whatever happens next; then the probe (both forms; a watchdog prints that first line if it does not come back); then, if the
+        # probe prefers the all-pairs exchange, the step again in that form: `value` is what the product would run on this node
+        D.configure(topology="rccl", direct=False)
         els = measure(hp.step)
+        name_rccl = "torch.distributed, RCCL all-gather / reduce-scatter, fp32 dC wire"
+        state = {"line": core_line(a, W, B, K, d, T, hp, els, "eager", name_rccl + " (the topology probe did not come back)", backend, DM) if rank == 0 else None}
+        D.configure(None, False)
+
+        def give_up_probe():
+            if rank == 0:
+                print(json.dumps(state["line"]), flush=True)
+            os._exit(0)
+
+        wdp = threading.Timer(float(os.environ.get("DPRHOT_VARIANT_TIMEOUT", "120")), give_up_probe)
+        wdp.daemon = True
+        wdp.start()
+        topo = D.choose_path_collectives(dev, hp.rows_c, d) if W > 1 else D.path_topology()
+        wdp.cancel()
+        probe = D._PROBED.get(D._gkey(None))
+        note = (f" (probe: RCCL {probe['us']['rccl']:.1f} us, all-pairs {probe['us']['allpairs']:.1f} us per gather + scatter)" if probe else
+                (" (DPRHOT_PATH_COLLECTIVES)" if os.environ.get("DPRHOT_PATH_COLLECTIVES") else ""))
+        collectives_name = name_rccl + note
         torch_coll = sorted(els)[len(els) // 2]
-        if backend == "nccl" and os.environ.get("DPRHOT_DIRECT_RCCL", "1") != "0":
-            import threading
-
-            def give_up_direct():
-                if rank == 0:
-                    print(json.dumps(core_line(a, W, B, K, d, T, hp, els, "eager", "torch.distributed (C ABI communicator set-up timed out)",
-                                               backend, DM)), flush=True)
-                os._exit(0)
-
-            wd0 = threading.Timer(float(os.environ.get("DPRHOT_DIRECT_RCCL_TIMEOUT", "120")), give_up_direct)
-            wd0.daemon = True
-            wd0.start()
-            from dpr_scale_amd import dist as D
-            # (opt-in in the product since round 4 -- DPRHOT_DIRECT_RCCL=1 -- because next to DDP's own communicator it is untested on
-            #  more than one GPU; this loop has no second communicator in flight and keeps its own watchdog above)
-            os.environ["DPRHOT_DIRECT_RCCL"] = "1"
-            comm = D.enable_direct_comm(dev)  # collective: all ranks get one, or all stay on torch.distributed
-            if comm is not None:
-                hp = HotPathStep(B, K, d, T, W, rank, dev, comm=comm, dist_mode=DM)
-                els = measure(hp.step)
-            wd0.cancel()
+        if topo == "allpairs":
+            els = measure(hp.step)  # (configure(None): the probe's choice is in force)
+            collectives_name = "torch.distributed, all-pairs exchange, fp32 dC wire" + note
+        state["line"] = core_line(a, W, B, K, d, T, hp, els, "eager", collectives_name, backend, DM) if rank == 0 else None
+        if rank == 0 and topo == "allpairs":
+            state["line"]["rccl_collective_form"] = {"ms_per_step": round(torch_coll / a.steps * 1e3, 5), "value": round(W * B * a.steps / torch_coll, 1)}
+        if not os.environ.get("DPRHOT_NO_VARIANTS"):
+            variants = variants_block(a, W, rank, dev, backend, B, K, d, T, hp, measure, state)
+        D.configure(None, None)
         driver = "eager"  # the collectives stay outside graphs
         runs = {"eager": (hp.step, 1)}
     else:
@@ -1025,12 +1191,12 @@ def main():
                         fn()
                     el2 = timed_loop(fn, a.steps, 1, per, hp.step)
                 alt[name] = {"value": round(B * a.steps / el2, 1), "ms_per_step": round(el2 / a.steps * 1e3, 5)}
-        out = core_line(a, W, B, K, d, T, hp, els, driver,
-                        "none" if not DM else ("rccl via the C ABI communicator" if comm is not None else "torch.distributed"), backend, DM)
+        out = core_line(a, W, B, K, d, T, hp, els, driver, collectives_name, backend, DM)
         out.update({"roofline": roof, "kernels": ktimes, "other_driver": alt})
-        if torch_coll is not None and comm is not None:  # the same step with torch.distributed's collectives, timed first
-            out["torch_distributed_collectives"] = {"ms_per_step": round(torch_coll / a.steps * 1e3, 5),
-                                                    "value": round(W * B * a.steps / torch_coll, 1)}
+        if DM and state["line"] is not None and "rccl_collective_form" in state["line"]:
+            out["rccl_collective_form"] = state["line"]["rccl_collective_form"]
+        if variants is not None:
+            out["variants"] = variants
         def extra(key, fn):  # extra information only: a failing block is reported, never fatal
             try:
                 out[key] = fn()
@@ -1112,9 +1278,8 @@ def main():
     # the JSON line is the last line on the shared stdout.
     if DM:
         torch.cuda.synchronize()
-        if comm is not None:
-            from dpr_scale_amd import dist as D2
-            D2.disable_direct_comm()
+        from dpr_scale_amd import dist as D2
+        D2.disable_direct_comm()
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     if DM:

@@ -1778,7 +1778,11 @@ struct RcclApi {
   int (*ReduceScatter)(const void*, void*, size_t, int, int, RcclComm, hipStream_t);
   int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t);
   const char* (*GetErrorString)(int);
-  bool ok;
+  int (*Send)(const void*, size_t, int, int, RcclComm, hipStream_t);
+  int (*Recv)(void*, size_t, int, int, RcclComm, hipStream_t);
+  int (*GroupStart)();
+  int (*GroupEnd)();
+  bool ok, p2p;
 };
 constexpr int kRcclInt8 = 0, kRcclFloat16 = 6, kRcclFloat32 = 7, kRcclBfloat16 = 9, kRcclSum = 0;
 
@@ -1796,7 +1800,12 @@ const RcclApi& rccl() {
     a.ReduceScatter = reinterpret_cast<decltype(a.ReduceScatter)>(dlsym(h, "ncclReduceScatter"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.ReduceScatter && a.AllReduce && a.GetErrorString;
+    a.p2p = a.ok && a.Send && a.Recv && a.GroupStart && a.GroupEnd;
     return a;
   }();
   return api;
@@ -1866,6 +1875,47 @@ int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream) {
   DprhotComm* c = static_cast<DprhotComm*>(h);
   RCCL_TRY(rccl().AllReduce(buf, buf, count, kRcclFloat32, kRcclSum, c->comm, (hipStream_t)stream));
   return DPRHOT_OK;
+}
+
+// ---- the same two collectives as direct all-pairs exchanges (SURVEY.md section 8(e) "Topology") ---------------------------------
+// One RCCL group of W sends and W receives (the self pair included: a device copy): every peer's transfer is its own point-to-point
+// operation, so on the fully connected node the W - 1 transfers of a rank travel over W - 1 different xGMI links at once.
+int dprhot_allgather_allpairs(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
+  REQUIRE(h && send && recv && bytes_per_rank > 0, "bad argument");
+  if (!rccl().p2p) return fail(DPRHOT_E_UNSUPPORTED, "ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd not found in this process's librccl.so");
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  hipStream_t st = (hipStream_t)stream;
+  RCCL_TRY(rccl().GroupStart());
+  int rc = 0;
+  for (int k = 0; k < c->W && rc == 0; ++k) {
+    rc = rccl().Send(send, bytes_per_rank, kRcclInt8, k, c->comm, st);
+    if (rc == 0) rc = rccl().Recv(static_cast<char*>(recv) + (size_t)k * bytes_per_rank, bytes_per_rank, kRcclInt8, k, c->comm, st);
+  }
+  const int rc2 = rccl().GroupEnd();  // (always closed: an open group would swallow the caller's next collective)
+  if (rc != 0) return fail(DPRHOT_E_HIP, "ncclSend / ncclRecv: %s", rccl().GetErrorString(rc));
+  if (rc2 != 0) return fail(DPRHOT_E_HIP, "ncclGroupEnd: %s", rccl().GetErrorString(rc2));
+  return DPRHOT_OK;
+}
+
+int dprhot_reducescatter_allpairs(void* h, const void* send, void* tmp, void* recv, size_t count_per_rank, int kind, int out_kind, void* stream) {
+  REQUIRE(h && send && tmp && recv && count_per_rank > 0, "bad argument");
+  REQUIRE(kind >= GC_BF16 && kind <= GC_FP32 && (out_kind == kind || out_kind == GC_FP32), "kind=%d out_kind=%d (0 bf16, 1 fp16, 2 fp32; out = kind or fp32)", kind, out_kind);
+  REQUIRE(count_per_rank % 8 == 0, "count_per_rank=%zu must be a multiple of 8", count_per_rank);
+  if (!rccl().p2p) return fail(DPRHOT_E_UNSUPPORTED, "ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd not found in this process's librccl.so");
+  DprhotComm* c = static_cast<DprhotComm*>(h);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = kind == GC_FP32 ? 4 : 2;
+  const int dt = kind == GC_BF16 ? kRcclBfloat16 : (kind == GC_FP16 ? kRcclFloat16 : kRcclFloat32);
+  RCCL_TRY(rccl().GroupStart());
+  int rc = 0;
+  for (int k = 0; k < c->W && rc == 0; ++k) {
+    rc = rccl().Send(static_cast<const char*>(send) + (size_t)k * count_per_rank * es, count_per_rank, dt, k, c->comm, st);
+    if (rc == 0) rc = rccl().Recv(static_cast<char*>(tmp) + (size_t)k * count_per_rank * es, count_per_rank, dt, k, c->comm, st);
+  }
+  const int rc2 = rccl().GroupEnd();
+  if (rc != 0) return fail(DPRHOT_E_HIP, "ncclSend / ncclRecv: %s", rccl().GetErrorString(rc));
+  if (rc2 != 0) return fail(DPRHOT_E_HIP, "ncclGroupEnd: %s", rccl().GetErrorString(rc2));
+  return dprhot_grad_sum_shards(tmp, c->W, count_per_rank, kind, out_kind, recv, stream);  // fp32 accumulation, rank order
 }
 
 }  // extern "C"

@@ -88,6 +88,7 @@ class DenseRetrieverTask(LightningModule):
         self.save_hyperparameters()
         self.transform_conf = getattr(transform, "text_transform", transform)
         self.model_conf, self.optim_conf = model, optim
+        self._datamodule_conf = datamodule  # (only read for the size of a step's messages: _path_message_shape)
         self.shared_model = shared_model
         self.k = k
         self.kernels = None  # None = libdprhot.so (the only product path); tests may inject a stand-in
@@ -135,10 +136,35 @@ class DenseRetrieverTask(LightningModule):
                 dev = None
             if dev is not None and dev.type == "cuda":
                 hotpath.D.enable_direct_comm(dev)
+                # which FORM of the path's two collectives on this node -- RCCL's own (rings) or the direct all-pairs exchange -- is
+                # measured once, here, at the step's message sizes, and agreed on by all ranks (dist.choose_path_collectives;
+                # DPRHOT_PATH_COLLECTIVES=rccl|allpairs pins it, DPRHOT_PATH_PROBE=0 skips the probe and keeps RCCL's)
+                if os.environ.get("DPRHOT_PATH_PROBE", "1") != "0" and hotpath.D.world(None)[0] > 1:
+                    rows_c, d = self._path_message_shape()
+                    wire = torch.bfloat16 if os.environ.get("DPRHOT_DC_WIRE", "fp32") == "bf16" else torch.float32
+                    self.path_collectives = hotpath.D.choose_path_collectives(dev, rows_c, d, wire=wire)
         if self.fp16_grads:
             from .. import comm_hooks
 
             self.grad_comm_state = comm_hooks.register(self.trainer.strategy._model, comm_hooks.GradCommState.from_env(default_wire="fp16"))
+
+    def _path_message_shape(self):
+        """(packed rows per rank, hidden size) of a training step's all-gather, from the configs where they say it (batch size, contexts
+        per query: dpr_transform.py:143-161 pads every query to 1 + num_negative contexts), else BASELINE configs[2]'s 1032 x 768."""
+        rows, d = 1032, 768
+        try:
+            bs = int(self._datamodule_conf.get("batch_size"))
+            tr = self.transform_conf
+            k = int(tr.get("num_positive", 1)) + int(tr.get("num_negative", 7))
+            for p in self.query_encoder.parameters():
+                if p.dim() == 2:
+                    d = int(p.shape[-1])  # (the last 2-D weight met is the encoder's output-side matrix in every recipe; only a size estimate)
+            from .. import _lib
+
+            rows = _lib.packed_rows(bs * k, d)
+        except Exception:
+            pass
+        return rows, d
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, **kwargs):

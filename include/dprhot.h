@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 160 /* 0.1.60: + dprhot_grad_pack / _sum_shards / _unpack (gradient hook legs), dprhot_train_step_*, dprhot_rescale_grads */
+#define DPRHOT_VERSION 170 /* 0.1.70: + dprhot_allgather_allpairs / dprhot_reducescatter_allpairs (the path's collectives as direct all-pairs exchanges) */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -326,6 +326,14 @@ int dprhot_grad_unpack(const void* full, int kind, float* bucket, size_t n, void
  *   dprhot_reducescatter_dc recv[0 .. count_per_rank) = sum over ranks of send[rank * count_per_rank ...]  (fp32 dC partials)
  *   dprhot_reducescatter_rows the same for dC partials of any storage kind (0 bf16, 1 fp16, 2 fp32: the wire formats of the backward)
  *   dprhot_allreduce_sum    in place, fp32 (the loss numerator)
+ *   dprhot_allgather_allpairs      the same result as dprhot_allgather_ctx by a DIRECT ALL-PAIRS exchange: one grouped send / receive of
+ *                                  the one send buffer to / from every peer (SURVEY 8(e) "Topology": on the fully connected node every
+ *                                  pair of GPUs owns an xGMI link, so the W - 1 transfers use W - 1 links at once instead of a ring's
+ *                                  W - 1 sequential hops)
+ *   dprhot_reducescatter_allpairs  the same result as dprhot_reducescatter_rows: chunk k of send goes to rank k, the W chunks received
+ *                                  land in tmp [W * count_per_rank] (caller-owned, storage kind `kind`), then ONE kernel adds them in
+ *                                  fp32 in rank order (deterministic; a half-width wire is rounded once per partial, never inside the
+ *                                  sum) into recv, stored as `out_kind` (= kind, or 2 for fp32)
  * One communicator per rank process, used from one thread; every rank issues the same calls in the same order. */
 int dprhot_comm_unique_id(void* id128);
 int dprhot_comm_init(const void* id128, int W, int rank, void** h);
@@ -334,6 +342,8 @@ int dprhot_allgather_ctx(void* h, const void* send, void* recv, size_t bytes_per
 int dprhot_reducescatter_dc(void* h, const float* send, float* recv, size_t count_per_rank, void* stream);
 int dprhot_reducescatter_rows(void* h, const void* send, void* recv, size_t count_per_rank, int kind, void* stream);
 int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream);
+int dprhot_allgather_allpairs(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+int dprhot_reducescatter_allpairs(void* h, const void* send, void* tmp, void* recv, size_t count_per_rank, int kind, int out_kind, void* stream);
 
 #ifdef __cplusplus
 }

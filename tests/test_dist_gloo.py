@@ -269,3 +269,57 @@ def test_eight_ranks_cfg3_operator_on_one_gpu_match_reference():
             assert np.abs(dc_colsum - g["dc_own_colsum"]).max() <= 1e-2 * np.abs(g["dc_own_colsum"]).max()
     # the global column sum is ~0 (rows of softmax - onehot sum to zero): absolute bar at the scale of one rank's chunk
     assert np.abs(colsum - g["dC_colsum"]).max() <= 1e-2 * W * np.abs(g["dc_own_colsum"]).max()
+
+
+def _probe_worker(rank, W, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("DPRHOT_PATH_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from dpr_scale_amd import dist as D
+
+    res = {}
+    # (1) ranks that measured differently must still leave with ONE answer: the slowest rank decides for each form
+    local = {0: [(10.0, 5.0), (100.0, 50.0), (10.0, float("inf"))], 1: [(10.0, 20.0), (90.0, 60.0), (10.0, 1.0)]}[rank % 2]
+    res["decisions"] = [D.decide_topology(a, b)[0] for a, b in local]
+    # (2) the probe itself (CPU tensors over gloo: both forms run), then the collectives follow what it registered
+    topo = D.choose_path_collectives(torch.device("cpu"), 16, 32, iters=3)
+    res["probe"] = topo
+    res["registered"] = D.path_topology()
+    send = torch.full((16, 32), float(rank + 1)).to(torch.bfloat16)
+    out = torch.empty((W * 16, 32), dtype=torch.bfloat16)
+    D.all_gather_rows(send, out)
+    res["gather_ok"] = bool(all(torch.all(out[r * 16:(r + 1) * 16].float() == r + 1) for r in range(W)))
+    part = torch.arange(W * 16 * 32, dtype=torch.float32).reshape(W * 16, 32) * (rank + 1)
+    mine = torch.empty((16, 32))
+    D.reduce_scatter_rows(part, mine)
+    want = torch.arange(W * 16 * 32, dtype=torch.float32).reshape(W * 16, 32)[rank * 16:(rank + 1) * 16] * sum(range(1, W + 1))
+    res["scatter_ok"] = bool(torch.equal(mine, want))
+    # (3) an explicit configure() outranks the probe; clearing it gives the probe's answer back
+    D.configure(topology="allpairs" if topo == "rccl" else "rccl")
+    res["override"] = D.path_topology()
+    D.configure(None, None)
+    res["back"] = D.path_topology()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_topology_probe_agrees_across_ranks():
+    """dist.decide_topology / choose_path_collectives (what DenseRetrieverTask.on_pretrain_routine_start runs before the first
+    step): whatever the ranks measured locally, every rank leaves with the same form of the path's collectives."""
+    W = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_probe_worker, args=(r, W, 29751, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(W))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0]["decisions"] == res[1]["decisions"] == ["rccl", "allpairs", "rccl"]
+    assert res[0]["probe"] == res[1]["probe"] and res[0]["probe"] in ("rccl", "allpairs")
+    for r in range(W):
+        assert res[r]["registered"] == res[r]["probe"] == res[r]["back"] and res[r]["override"] != res[r]["probe"]
+        assert res[r]["gather_ok"] and res[r]["scatter_ok"]
