@@ -1255,8 +1255,9 @@ def main():
             # process): packed layout, the all-gather started under the query tower, the reduce-scatter under its backward
             try:
                 import subprocess
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "overlap_trace.py"), "--B", str(B), "--K", str(K), "--steps", "5"],
-                                   capture_output=True, text=True, timeout=200, env=dict(os.environ, MASTER_PORT="29773"))
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "overlap_trace.py"), "--B", str(B), "--K", str(K), "--steps", "5",
+                                    "--order", "auto", "--warmup", "16"],  # (the product default: the order of the towers is timed over the first 14 steps)
+                                   capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_PORT="29773"))
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 out["end_to_end_forced_dist"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as e:

@@ -27,6 +27,7 @@ SIGNATURES = {
     "dprhot_last_error": (c_char_p, []),
     "dprhot_set_option": (c_int, [c_char_p, c_int]),
     "dprhot_get_option": (c_int, [c_char_p, POINTER(c_int)]),
+    "dprhot_options_epoch": (ctypes.c_longlong, []),
     "dprhot_workspace_bytes": (c_int, [c_int, c_int, c_int, POINTER(c_size_t)]),
     "dprhot_cast_bf16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_prep": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -118,19 +119,17 @@ def version() -> int:
     return lib.dprhot_version()
 
 
-_OPTIONS_EPOCH = 0
 
 
 def options_epoch() -> int:
-    """Bumped by every set_option(): host-side caches of plan facts (slab counts, whether a step wants a G buffer) key on it."""
-    return _OPTIONS_EPOCH
+    """The LIBRARY's own counter (dprhot_options_epoch, bumped by every dprhot_set_option whoever calls it): host-side caches of plan
+    facts (slab counts, whether a step wants a G buffer) key on it."""
+    return int(lib.dprhot_options_epoch())
 
 
 def set_option(name: str, value: int):
     """Process-wide test / A-B switch of the plans (include/dprhot.h); production never calls this."""
-    global _OPTIONS_EPOCH
     check(lib.dprhot_set_option(name.encode(), int(value)), f"dprhot_set_option({name})")
-    _OPTIONS_EPOCH += 1
 
 
 def get_option(name: str) -> int:

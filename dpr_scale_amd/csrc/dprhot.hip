@@ -155,6 +155,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
     {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
 };
+long long g_opt_epoch = 0;  // bumped by every dprhot_set_option: host-side caches of plan facts key on it (dprhot_options_epoch)
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
 const bool g_opt_defaults = [] {
   for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = kOptDefs[i].def;
@@ -798,10 +799,13 @@ int dprhot_set_option(const char* name, int value) {
   for (int i = 0; i < OPT_COUNT; ++i)
     if (strcmp(name, kOptDefs[i].name) == 0) {
       __atomic_store_n(&g_opt[i], value, __ATOMIC_RELAXED);
+      __atomic_add_fetch(&g_opt_epoch, 1, __ATOMIC_RELAXED);
       return DPRHOT_OK;
     }
   return fail(DPRHOT_E_INVALID, "unknown option '%s'", name);
 }
+
+long long dprhot_options_epoch(void) { return __atomic_load_n(&g_opt_epoch, __ATOMIC_RELAXED); }
 
 int dprhot_get_option(const char* name, int* h_value) {
   REQUIRE(name != nullptr && h_value != nullptr, "NULL pointer");

@@ -485,6 +485,10 @@ except Exception:  # pragma: no cover - a broken optional extension must not tak
     _OPX = None
 
 
+# the multi-rank packed step's host side in C++ (csrc/opx.cpp: packed_train_step / packed_backward); DPRHOT_OPX_PACKED=0: the Python wrappers
+_OPX_PACKED = _OPX is not None and hasattr(_OPX, "packed_train_step") and os.environ.get("DPRHOT_OPX_PACKED", "1") != "0"
+
+
 def default_kernels():
     global _DEFAULT
     if _DEFAULT is None:
@@ -577,6 +581,7 @@ class InBatchContrastive(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, c, pos_idx, ctx_mask, temperature, group, kernels, gather=None, pending=None):
         ctx.fast = None
+        ctx.opx_packed = False
         if _OPX is not None and kernels is None and gather is None and q.is_cuda and c.is_cuda and (group is False or D.world(group)[0] == 1):
             # The step a single-GPU run issues every iteration (dpr_task.py:197-212): host side in C++ (csrc/opx.cpp).  Taken when
             # nothing needs the general code below: fp32 contiguous encoder outputs, a whole number of 8-column groups, a byte mask.
@@ -666,15 +671,26 @@ class InBatchContrastive(torch.autograd.Function):
         elif multi and packed_step and hasattr(kn, "train_step_packed_f32"):
             # forward and backward of this rank's rows in ONE library call; gradients scaled by the grad_output the last backward saw
             used = _ExpectedGradScale.get(q.device, (B, Nc, d))
-            try:
-                row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
-                                                                                       1.0 / Nq, used, dc_dtype, defer_dq=True, want_G="auto")
-            except Exception as e:  # a plan without a bf16 dC epilogue: fp32 partials, rounded to the wire format in backward
-                if dc_dtype == torch.float32 or "dc_kind" not in str(e):
-                    raise
-                row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
-                                                                                       1.0 / Nq, used, torch.float32, defer_dq=True,
-                                                                                       want_G="auto")
+            if _OPX_PACKED and kernels is None and q.is_contiguous() and pos_idx.dtype == torch.int64 and pos_idx.is_contiguous() \
+                    and dc_dtype in (torch.float32, _BF16):
+                # host side in C++ (csrc/opx.cpp: packed_train_step): the allocations, the library call and its fall-back to fp32
+                # partials in one function; backward's counterpart is packed_backward
+                loss_sum, row_lse, dQ, dC_part, Qb, G, part = _OPX.packed_train_step(q.detach(), Cb, pos_idx, W, r, n_ctx, inv_T, grad_scale, 1.0 / Nq,
+                                                                                     used, 0 if dc_dtype == _BF16 else 2)
+                G = G if (G is not None and G.numel() > 0) else None  # (an undefined at::Tensor arrives as None)
+                if part is not None and part.numel() > 0:
+                    dQ = (dQ, part)
+                ctx.opx_packed = True
+            else:
+                try:
+                    row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
+                                                                                           1.0 / Nq, used, dc_dtype, defer_dq=True, want_G="auto")
+                except Exception as e:  # a plan without a bf16 dC epilogue: fp32 partials, rounded to the wire format in backward
+                    if dc_dtype == torch.float32 or "dc_kind" not in str(e):
+                        raise
+                    row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.train_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale,
+                                                                                           1.0 / Nq, used, torch.float32, defer_dq=True,
+                                                                                           want_G="auto")
             eager, loss_is_mean = (dQ, dC_part), True
         elif multi and packed_step:  # (stand-in kernels of the CPU tests)
             row_loss, row_lse, loss_sum, G, dQ, dC_part = kn.inbatch_step_packed_f32(q, Cb, Qb, W, r, n_ctx, pos_idx, inv_T, grad_scale)
@@ -742,17 +758,27 @@ class InBatchContrastive(torch.autograd.Function):
         W, r, B, d, n_ctx, rows_c = ctx.dims
         need_dq, need_dc = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         go = grad_out.detach().reshape(1).float().contiguous()  # device scalar: AMP loss scale, no host sync
+        mine_ready = None
         if ctx.eager is not None and ctx.used is not None:
             # computed in forward for grad_output = *ctx.used; ONE launch compares and only rescales when the scale really changed.
             # The tensors are handed to autograd and FORGOTTEN here: AccumulateGrad takes a gradient nobody else references as
             # .grad itself, and clones it otherwise (one copy launch per step, 50 MB of traffic at cfg3 per rank).
             dQ, dC_part = ctx.eager
             ctx.eager = None
-            out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
+            mine_ready = None
+            if ctx.opx_packed and ctx.multi:
+                # csrc/opx.cpp: the rescale launch, dC_part in the wire format (one cast launch where the step wrote fp32 for a bf16 wire)
+                # and the reduce-scatter's receive buffer, in one C++ call
+                part = dQ[1] if isinstance(dQ, tuple) else None
+                nxt, dC_part, mine_ready = _OPX.packed_backward(dQ[0] if isinstance(dQ, tuple) else dQ, part, dC_part, go, ctx.used,
+                                                                0 if _dc_wire_dtype() == _BF16 else 2, rows_c, need_dq, need_dc)
+            else:
+                out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
+                nxt = out2[1:2]
             if isinstance(dQ, tuple):
                 dQ = dQ[0]  # (the slabs have been added up into it)
             ctx.used = None
-            _ExpectedGradScale.publish(go.device, out2[1:2], ctx.site)
+            _ExpectedGradScale.publish(go.device, nxt, ctx.site)
             go = None
         elif ctx.spare is not None:
             # a second backward through a retained graph: the first one gave its gradient tensors away; the backward GEMMs run
@@ -796,7 +822,7 @@ class InBatchContrastive(torch.autograd.Function):
                 dc = (dc if go is None else dc * go).to(ctx.in_dtypes[1])
             else:
                 wire = _dc_wire_dtype()
-                mine = kn.empty((rows_c, d), wire, dC_part)
+                mine = mine_ready if mine_ready is not None else kn.empty((rows_c, d), wire, dC_part)
                 if go is not None:
                     dC_part = dC_part * go  # scale before the collective: nothing is left to do after it
                 if dC_part.dtype != wire:

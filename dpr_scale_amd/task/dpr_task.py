@@ -102,7 +102,9 @@ class DenseRetrieverTask(LightningModule):
         self.setup_done = False
         # multi-GPU step: contexts first (collectives hidden under the query tower) unless the reference's order
         # is asked for (dropout RNG stream identical to the reference's, see training_step)
+        # DPRHOT_TOWER_ORDER = context_first | reference | auto (default): see _tower_order()
         self.context_tower_first = os.environ.get("DPRHOT_TOWER_ORDER", "") != "reference"
+        self._order_trial = None
 
     # ---- model construction / checkpoints (reference :55-92) -------------------------------------------
     def setup(self, stage: str):
@@ -229,11 +231,65 @@ class DenseRetrieverTask(LightningModule):
     def _is_distributed(self):
         return isinstance(getattr(self.trainer, "strategy", None), (DDPStrategy, DDPShardedStrategy))
 
+    # The order of the two towers in the multi-GPU step is MEASURED, not assumed (DPRHOT_TOWER_ORDER=auto, the default).
+    #   context_first  the context tower's rows go into the one all-gather, which runs underneath the query tower; in backward the
+    #                  reduce-scatter of dC runs underneath the query-tower backward (hotpath.ContextGather / defer_context_grad).
+    #   reference      the reference's order (dpr_task.py:94-101: query tower, context tower); both collectives run exposed.
+    # Hiding the collectives is not free: autograd runs the NEWEST tower's backward first, so context_first puts the SMALL tower's
+    # backward (B rows, ~700 launches of ~10 us) right behind the loss, where nothing is queued ahead of it -- the GPU outruns the host's
+    # launches and idles (profiles/r05_forced_dist_breakdown.json: +0.9...1.3 ms of device idle per step at B = 32 on one MI355X, with
+    # NO collective involved: the same operator single-device, context tower first, shows it) -- whereas in the reference's order the
+    # big tower's backward goes first and the small one's launches queue up behind it.  Which effect is larger depends on the host, the
+    # batch and the node's links; so the first steps time both orders with HIP events (no host sync), the ranks agree on the faster
+    # one (all-reduce MAX of the medians; ties keep context_first) and training continues in it.
+    _TRIAL_WARM, _TRIAL_N = 3, 5
+
+    def _tower_order(self):
+        if not self.context_tower_first:
+            return "reference"
+        mode = os.environ.get("DPRHOT_TOWER_ORDER", "auto")
+        if mode != "auto" or not torch.cuda.is_available():
+            return "context_first"
+        tr = self._order_trial
+        if tr is None:
+            tr = self._order_trial = {"step": 0, "events": [], "decided": None, "ms": None}
+        if tr["decided"] is not None:
+            return tr["decided"]
+        i, W0, N = tr["step"], self._TRIAL_WARM, self._TRIAL_N
+        tr["step"] += 1
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        tr["events"].append(ev)
+        if i < W0:
+            return "context_first"
+        if i < W0 + 2 * N + 1:
+            # the two orders ALTERNATE step by step (clocks and caches drift over the first steps of a run: two blocks of steps would
+            # time the drift); step j's interval runs from its start event to the next step's
+            return "context_first" if (i - W0) % 2 == 0 else "reference"
+        evs = tr["events"]
+        evs[W0 + 2 * N].synchronize()  # (recorded a whole step ago: complete)
+
+        def med(first):
+            ts = sorted(evs[j].elapsed_time(evs[j + 1]) for j in range(first, W0 + 2 * N, 2))
+            return 0.5 * (ts[(len(ts) - 1) // 2] + ts[len(ts) // 2])
+
+        t = torch.tensor([med(W0), med(W0 + 1)], dtype=torch.float64, device=evs[0].device if hasattr(evs[0], "device") else "cuda")
+        if hotpath.D.world(None)[0] > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        a_ms, b_ms = t.tolist()
+        tr["ms"] = {"context_first": a_ms, "reference": b_ms}
+        tr["decided"] = "reference" if b_ms < 0.995 * a_ms else "context_first"
+        tr["events"] = []
+        if getattr(self, "global_rank", 0) == 0:
+            print(f"dpr_scale_amd: tower order of the multi-GPU step: {tr['decided']} (context first {a_ms:.2f} ms / step, reference order {b_ms:.2f} ms / step)",
+                  flush=True)
+        return tr["decided"]
+
     def training_step(self, batch, batch_idx):
         pos, mask = batch["pos_ctx_indices"], batch["ctx_mask"]
         T = self.softmax_temperature
         if (self.in_batch_negatives and self._is_distributed() and (hotpath.D.world(None)[0] > 1 or hotpath.D.force_dist())
-                and type(self).forward is DenseRetrieverTask.forward and self.context_tower_first):
+                and type(self).forward is DenseRetrieverTask.forward and self._tower_order() == "context_first"):
             # Multi-GPU (reference :163-195).  Context tower FIRST: its rows go into the one all-gather, which then
             # runs on RCCL's stream underneath the query tower; in backward the reduce-scatter of dC overlaps the
             # query-tower backward the same way (hotpath.ContextGather / defer_context_grad).  The encoders are

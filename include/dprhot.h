@@ -56,6 +56,9 @@ const char* dprhot_last_error(void);
  * Setting one changes the plans of every later call on every thread (workspace sizes included: query them after setting).
  * DPRHOT_E_INVALID for an unknown name. */
 int dprhot_set_option(const char* name, int value);
+/* Bumped by every dprhot_set_option: whoever caches a plan fact of this library (dprhot_step_wants_g, dprhot_train_dq_slabs,
+ * dprhot_workspace_bytes) keys the cache on it -- options set through this C ABI from any binding invalidate every such cache. */
+long long dprhot_options_epoch(void);
 int dprhot_get_option(const char* name, int* h_value);
 
 /* Bytes of scratch the fused entry points (dprhot_inbatch_fwd/_bwd, dprhot_dq) need for this shape. */

@@ -26,8 +26,12 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--seq", type=int, default=256)
     ap.add_argument("--large", action="store_true", help="bert-large towers (BASELINE configs[4])")
+    ap.add_argument("--order", default="context_first", choices=["context_first", "reference", "auto"],
+                    help="DPRHOT_TOWER_ORDER: context_first (default here: the overlap timeline), reference, or auto -- the product's default, "
+                         "which times both orders over its first 14 steps (use --warmup >= 15)")
     a = ap.parse_args()
     os.environ["DPRHOT_FORCE_DIST"] = "1"
+    os.environ["DPRHOT_TOWER_ORDER"] = a.order
     os.environ.setdefault("DPRHOT_DC_WIRE", "bf16")  # (the widen launch behind the wait is a named landmark on the timeline)
     os.environ["DPRHOT_DIRECT_RCCL"] = "1" if a.direct else "0"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -80,7 +84,9 @@ def main():
                                   f"seq_len={a.seq}, B={a.B}, K={a.K}, bf16 autocast, AdamW",
                       "collectives": "C ABI communicator on the side HIP stream" if D.direct_comm() is not None else "torch.distributed (RCCL's stream)",
                       "ms_per_step": round(ms, 3), "pairs_per_s": round(a.B / ms * 1e3, 1), "loss_last": round(float(loss.detach()), 4),
-                      "steps": a.steps, "warmup": a.warmup}), flush=True)
+                      "steps": a.steps, "warmup": a.warmup, "tower_order": a.order,
+                      "tower_order_trial": (task._order_trial or {}).get("decided") and {"decided": task._order_trial["decided"], "ms_per_step": task._order_trial["ms"]}}),
+          flush=True)
     dist.destroy_process_group()
 
 
