@@ -13,5 +13,11 @@ import os as _os
 # The hot path's launches are a few microseconds each and every one begins by loading its arguments: from host-coherent memory
 # that is a trip across PCIe per launch (cfg3-per-rank step, eager: 31.0 -> 26.0 us with the arguments on the device).
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# torch.distributed's RCCL streams at HIGH priority (read when a process group is created).  HIP multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES = 4 hardware queues, and two streams that share one run in order: on the test box ProcessGroupNCCL's stream landed
+# on the compute stream's queue, and the "overlapped" all-gather / reduce-scatter of the multi-GPU step ran with the compute stream idle
+# (profiles/r05_overlap_busy_torch_distributed*.json).  A priority is a property of the hardware queue, so a high-priority stream
+# cannot alias the (normal-priority) compute stream.
+_os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
 
 __version__ = "0.1.0"

@@ -125,7 +125,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SEARCH_GROUP, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -151,7 +151,6 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
     {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
     {"sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},
-    {"search_group", 0, "1: dprhot_search merges warm chunks in groups of up to four (one merge launch per group; measured: 4.76 ms either way at 1024 x 2 M x 768, k = 1000 -- the merged lists are as much longer as the launches are fewer)"},
     {"sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
     {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
 };
@@ -1064,26 +1063,18 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
     }
     // scores that cannot enter the top-k never leave the GEMM tile
     if (nl_ok(nq, cols, d)) {  // the phase-interleaved kernel (gemm8p.h); thresholds arrive with the tile's input words
-      // WARM chunks are merged in groups: behind a prefix of s passages a chunk of f leaves ~k f / s candidates per row, so from
-      // s >= G f on, G chunks filtered against the SAME (not yet updated) thresholds append ~k candidates in all to one list --
-      // one merge launch (it rewrites the whole state: 60-90 us at k = 1000) instead of G.  Full chunks only (one row stride).
-      int G = 1;
-      if (opt(OPT_SEARCH_GROUP) != 0 && step == chunk && cols == chunk) {
-        G = (int)(j0 / chunk < 4 ? j0 / chunk : 4);
-        const int64_t full = (n_ctx - j0) / chunk;
-        if (G > full) G = (int)full;
-        if (G < 1) G = 1;
-      }
-      for (int g = 0; g < G; ++g) {
-        const int64_t jg = j0 + (int64_t)g * chunk;
-        const Epi8Filter e8{values, indices, k, nq, cols, (long long)(id_offset + jg), cnt, S, cand_j, Q, g * chunk};
-        GemmArgs a8{Q, C + (size_t)jg * d, nq, cols, d, d, d, d};
+      // (Round 4 merged warm chunks in groups of up to four -- option search_group: up to four chunks filtered against the same stale
+      //  thresholds appended to ONE candidate list of `chunk` entries per row, with no bound on the append: a corpus whose later
+      //  chunks beat the current k-th value could write past its row.  It had measured no gain -- 4.76 ms either way at 1024 x 2 M,
+      //  k = 1000 -- and is gone; one merge per chunk, at most `cols` candidates per row and chunk, is what the workspace is sized for.)
+      {
+        const Epi8Filter e8{values, indices, k, nq, cols, (long long)(id_offset + j0), cnt, S, cand_j, Q, 0};
+        GemmArgs a8{Q, Cj, nq, cols, d, d, d, d};
         if (int rc = launch_g8(a8, e8, st)) return rc;
       }
       TopkArgs p8{S, nq, cols, (long long)cols, (long long)(id_offset + j0), k, values, indices, 0, cand_j, cnt};
       launch_topk(p8, nq, st);
       HIP_TRY(hipGetLastError());
-      step = (int64_t)G * chunk;
       continue;
     }
     const int tile = (force_tile() < 0 && big_ok(nq, cols, d)) ? kBigTile : pick_tile(nq, cols, d, 1, 2 * kNumCU);

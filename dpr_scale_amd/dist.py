@@ -249,7 +249,11 @@ def _on_side_stream(fn, *tensors):
     dev = tensors[0].device
     side = _SIDE.get(dev.index)
     if side is None:
-        side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+        # HIGH priority: a priority is a property of the hardware queue, so this stream can never be multiplexed onto the compute
+        # stream's queue.  (HIP spreads a process's streams over GPU_MAX_HW_QUEUES = 4 hardware queues; two streams that land on one
+        # queue run in order -- profiles/r05_overlap_busy_*: torch.distributed's RCCL stream shared the compute stream's queue on the
+        # test box and its 400 us collective ran with the compute stream idle, where this side stream ran 12-35 tower kernels under it.)
+        side = _SIDE[dev.index] = torch.cuda.Stream(device=dev, priority=-1)
     side.wait_stream(torch.cuda.current_stream(dev))  # the operands were produced on the compute stream
     with torch.cuda.stream(side):
         fn()
@@ -259,7 +263,62 @@ def _on_side_stream(fn, *tensors):
     return _StreamWork(ev, tensors)
 
 
+# ---- debugging aid for timelines on ONE GPU (scripts/overlap_trace.py --pad-mb): a one-rank world carries each collective as a 2-5 us
+# device copy, over before the tower's first kernel has been launched.  DPRHOT_DEBUG_PAD_MB=N issues, right behind every all-gather /
+# reduce-scatter of the path and through the same transport, the same collective on a scratch buffer of N MiB per rank, and the handle
+# the caller waits on covers both: the collective then TAKES TIME (1 GiB ~ 0.4 ms of device copy), and whether the tower's kernels
+# really run underneath it can be read off a rocprofv3 trace.  Never set in production.
+_PAD = {}
+
+
+class _Both:
+    def __init__(self, *works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+def _pad_mb():
+    try:
+        return int(os.environ.get("DPRHOT_DEBUG_PAD_MB", "0") or 0)
+    except ValueError:
+        return 0
+
+
+def _pad_bufs(device, W, mb):
+    key = (device, W, mb)
+    if key not in _PAD:
+        rows, d = mb * 1024 * 1024 // (2 * 1024), 1024  # bf16 rows of 2 KiB
+        _PAD[key] = (torch.zeros((rows, d), dtype=torch.bfloat16, device=device), torch.empty((W * rows, d), dtype=torch.bfloat16, device=device),
+                     torch.zeros((W * rows, d), dtype=torch.bfloat16, device=device), torch.empty((rows, d), dtype=torch.bfloat16, device=device))
+    return _PAD[key]
+
+
 def all_gather_rows(send: torch.Tensor, out: torch.Tensor, group=None, async_op=False):
+    """out[r*n:(r+1)*n] = send from rank r (see _all_gather_rows)."""
+    w = _all_gather_rows(send, out, group, async_op)
+    mb = _pad_mb()
+    if mb > 0 and send.is_cuda:
+        ps, po, _, _ = _pad_bufs(send.device, world(group)[0], mb)
+        w2 = _all_gather_rows(ps, po, group, async_op)
+        return _Both(w, w2) if async_op else None
+    return w
+
+
+def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_op=False):
+    """out = sum over ranks of inp[r*n:(r+1)*n] for this rank r (see _reduce_scatter_rows)."""
+    w = _reduce_scatter_rows(inp, out, group, async_op)
+    mb = _pad_mb()
+    if mb > 0 and inp.is_cuda:
+        _, _, pi, pm = _pad_bufs(inp.device, world(group)[0], mb)
+        w2 = _reduce_scatter_rows(pi, pm, group, async_op)
+        return _Both(w, w2) if async_op else None
+    return w
+
+
+def _all_gather_rows(send: torch.Tensor, out: torch.Tensor, group=None, async_op=False):
     """out[r*n:(r+1)*n] = send from rank r (equal n on every rank -- guaranteed upstream by
     ContiguousDistributedSampler padding, utils.py:48-60, and DPRTransform padding, dpr_transform.py:143-161)."""
     W, _ = world(group)
@@ -283,7 +342,7 @@ def all_gather_rows(send: torch.Tensor, out: torch.Tensor, group=None, async_op=
     return dist.all_gather_into_tensor(out, send, group=group, async_op=async_op)
 
 
-def reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_op=False):
+def _reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async_op=False):
     """out = sum over ranks of inp[r*n:(r+1)*n] for this rank r."""
     W, r = world(group)
     n = out.shape[0]

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--dump", action="store_true")
     ap.add_argument("--timeline", help="write the operations around the two collectives to this text file")
+    ap.add_argument("--require-busy", type=float, default=0.0, help="also require the compute stream to be busy for at least this fraction of each "
+                                                                   "collective's duration, with >= 10 tower kernels that START AND END inside it "
+                                                                   "(a collective that takes time: overlap_trace.py --pad-mb)")
     a = ap.parse_args()
     con = sqlite3.connect(a.db)
     objs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
@@ -93,9 +96,11 @@ def main():
         op = max(cand, key=lambda o: o["end"] - o["start"])
         dur = op["end"] - op["start"]
         b = busy(op["start"], op["end"])
+        b_after = busy(op["end"], op["end"] + dur)  # the same span right behind it: how busy the tower keeps the stream on its own
         tower = [o for o in ops if o["kind"] == "kernel" and o["stream"] == main_stream and lo <= o["start"] <= hi]
         before = sum(1 for o in tower if o["end"] <= op["start"])
         after = sum(1 for o in tower if o["start"] >= op["end"])
+        inside = sum(1 for o in tower if o["start"] >= op["start"] and o["end"] <= op["end"])
         # does the compute stream wait for it?  the gap between the two tower kernels around the operation against the window's median gap
         gaps = sorted(b2["start"] - a2["end"] for a2, b2 in zip(tower, tower[1:]))
         prev = [o for o in tower if o["start"] <= op["start"]]
@@ -105,7 +110,9 @@ def main():
         return {"operation": op["name"][:120], "kind": op["kind"], "stream": op["stream"], "compute_stream": main_stream, "duration_us": round(dur / 1e3, 2),
                 "window_us": round((hi - lo) / 1e3, 1), "offset_in_window_us": round((op["start"] - lo) / 1e3, 2),
                 "tower_kernels_in_window": len(tower), "tower_kernels_before_it": before, "tower_kernels_after_it": after,
+                "tower_kernels_starting_and_ending_inside_it": inside,
                 "compute_stream_busy_frac_during_it": round(b / max(dur, 1), 3),
+                "compute_stream_busy_frac_in_the_same_span_right_after_it": round(b_after / max(dur, 1), 3),
                 "compute_stream_gap_around_it_us": None if gap_here is None else round(gap_here / 1e3, 2),
                 "median_gap_between_tower_kernels_us": round(gaps[len(gaps) // 2] / 1e3, 2) if gaps else None, "bytes": op.get("bytes")}
 
@@ -121,6 +128,14 @@ def main():
     ok = all(v["stream"] != v["compute_stream"] and v["tower_kernels_after_it"] >= 10 and v["offset_in_window_us"] >= 0
              and v["offset_in_window_us"] + v["duration_us"] < v["window_us"]
              for k, v in out.items() if k != "landmarks")
+    if a.require_busy > 0:
+        # busy for the required fraction of the collective -- or as busy as the tower keeps the stream by itself right behind it (the
+        # towers have host-side gaps of their own: a collective cannot be blamed for those) -- with tower kernels that start AND end
+        # inside the collective's interval
+        ok = ok and all((v["compute_stream_busy_frac_during_it"] >= a.require_busy or
+                         v["compute_stream_busy_frac_during_it"] >= 0.9 * v["compute_stream_busy_frac_in_the_same_span_right_after_it"])
+                        and v["tower_kernels_starting_and_ending_inside_it"] >= 4 for k, v in out.items() if k != "landmarks")
+        out["required_busy_frac"] = a.require_busy
     out["overlap_shown"] = bool(ok)
     print(json.dumps(out, indent=1))
     if a.timeline:

@@ -29,8 +29,12 @@ def main():
     ap.add_argument("--order", default="context_first", choices=["context_first", "reference", "auto"],
                     help="DPRHOT_TOWER_ORDER: context_first (default here: the overlap timeline), reference, or auto -- the product's default, "
                          "which times both orders over its first 14 steps (use --warmup >= 15)")
+    ap.add_argument("--pad-mb", type=int, default=0, help="DPRHOT_DEBUG_PAD_MB: every collective of the path is followed by the same collective on N MiB "
+                                                           "per rank, so that it takes time on a one-rank world (timelines only)")
     a = ap.parse_args()
     os.environ["DPRHOT_FORCE_DIST"] = "1"
+    if a.pad_mb > 0:
+        os.environ["DPRHOT_DEBUG_PAD_MB"] = str(a.pad_mb)
     os.environ["DPRHOT_TOWER_ORDER"] = a.order
     os.environ.setdefault("DPRHOT_DC_WIRE", "bf16")  # (the widen launch behind the wait is a named landmark on the timeline)
     os.environ["DPRHOT_DIRECT_RCCL"] = "1" if a.direct else "0"

@@ -104,7 +104,7 @@ def test_argument_validation_is_host_side():
         assert lib.dprhot_workspace_bytes(*shape, ctypes.byref(big)) == 0
         assert big.value >= -(-(-(-shape[1] // 64)) // 13) * shape[0] * shape[2] * 4
     assert lib.dprhot_set_option(b"sk_fused", 1) == 0
-    for name, default in ((b"sk_w8", 1), (b"sk_sim_w8", 1), (b"sk_pair", 0), (b"search_group", 0), (b"sk_fused", 1), (b"nt_stores", 1)):
+    for name, default in ((b"sk_w8", 1), (b"sk_sim_w8", 1), (b"sk_pair", 0), (b"sk_tail", 0), (b"sk_sim_priv", 1), (b"sk_fused", 1), (b"nt_stores", 1)):
         assert lib.dprhot_get_option(name, ctypes.byref(n)) == 0 and n.value == default, (name, n.value)
     # the few-rows plan's measured boundaries ("Mid-size steps"), seen through the slab count: split-K slabs where
     # the plan applies with more than 512 contexts, none where its dQ units are unsplit or another plan has the shape

@@ -661,17 +661,12 @@ def test_corpus_search_equals_topk_of_full_score_matrix(nq, shards, d, k, chunk,
     q = torch.randn(nq, d, generator=g).to(dev)
     parts = [torch.randn(n, d, generator=g).to(dev) for n in shards]
     parts[0][100:140] = parts[0][60:100]  # duplicated passages: exact score ties
-    grouped = shards[0] >= 6 * chunk  # (the two cases long enough for it: grouped merges are an option, off by default)
-    _lib.set_option("search_group", 1 if grouped else 0)
-    try:
-        s = CorpusSearch(q, k, chunk=chunk, kernels=kn)
-        first = 0
-        for p in parts:
-            s.add(p.to(torch.bfloat16) if first == 0 else p, first)  # bf16-resident and fp32 shards
-            first += p.shape[0]
-        v, i = s.result()
-    finally:
-        _lib.set_option("search_group", 0)
+    s = CorpusSearch(q, k, chunk=chunk, kernels=kn)
+    first = 0
+    for p in parts:
+        s.add(p.to(torch.bfloat16) if first == 0 else p, first)  # bf16-resident and fp32 shards
+        first += p.shape[0]
+    v, i = s.result()
     C = torch.cat(parts)
     S = sim_score(q, C, kernels=kn)
     order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
