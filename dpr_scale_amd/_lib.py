@@ -44,6 +44,8 @@ SIGNATURES = {
     "dprhot_rank_of_gold": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "dprhot_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dprhot_topk_update": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "dprhot_topk_wide_workspace_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
+    "dprhot_topk_update_wide": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "dprhot_search_workspace_bytes": (c_int, [c_int, c_int, POINTER(c_size_t)]),
     "dprhot_search": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_int,
                               c_void_p, c_size_t, c_void_p]),

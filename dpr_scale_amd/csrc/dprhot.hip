@@ -28,6 +28,7 @@
 #include "skinny.h"
 #include "gradcomm.h"
 #include "wide.h"
+#include "wideselect.h"
 
 using namespace dprhot;
 
@@ -1015,6 +1016,63 @@ int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_
 // (candidate columns) + [nq] int32 (candidate counts)
 static size_t search_ws_bytes(int nq, int chunk) {
   return (size_t)nq * (size_t)chunk * 8 + ((size_t)nq * 4 + 255) / 256 * 256;
+}
+
+// ---- k beyond the LDS-resident selection kernels (csrc/wideselect.h): state in HBM, radix select + block sort + merge passes ----
+static size_t wsel_ws_bytes(int rows, int k) {
+  return align256((size_t)rows * WSEL_REC * 4) + 2 * (align256((size_t)rows * k * 4) + align256((size_t)rows * k * 8));
+}
+int dprhot_topk_wide_workspace_bytes(int rows, int k, size_t* h_out) {
+  REQUIRE(h_out != nullptr && rows > 0 && k > 0, "bad argument");
+  *h_out = wsel_ws_bytes(rows, k);
+  return DPRHOT_OK;
+}
+
+int dprhot_topk_update_wide(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values, int64_t* indices, int first,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  REQUIRE(S && values && indices && workspace, "NULL pointer");
+  REQUIRE(rows > 0 && cols > 0 && k > 0 && ld >= cols, "bad shape rows=%d cols=%d k=%d ld=%lld", rows, cols, k, (long long)ld);
+  REQUIRE((long long)k + cols < (1ll << 31), "k + cols must fit 31 bits");
+  if (workspace_bytes < wsel_ws_bytes(rows, k)) return fail(DPRHOT_E_WORKSPACE, "topk_update_wide needs %zu workspace bytes, got %zu", wsel_ws_bytes(rows, k), workspace_bytes);
+  REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = static_cast<char*>(workspace);
+  unsigned* rec = reinterpret_cast<unsigned*>(ws);
+  size_t off = align256((size_t)rows * WSEL_REC * 4);
+  float* Av = reinterpret_cast<float*>(ws + off); off += align256((size_t)rows * k * 4);
+  int64_t* Ai = reinterpret_cast<int64_t*>(ws + off); off += align256((size_t)rows * k * 8);
+  float* Bv = reinterpret_cast<float*>(ws + off); off += align256((size_t)rows * k * 4);
+  int64_t* Bi = reinterpret_cast<int64_t*>(ws + off);
+  WselArgs a{S, rows, cols, (long long)ld, (long long)col_offset, k, values, indices, first, rec, Av, Ai};
+  hipLaunchKernelGGL(wsel_select_kernel, dim3((unsigned)rows), dim3(WSEL_THREADS), 0, st, a);
+  hipLaunchKernelGGL(wsel_collect_kernel, dim3((unsigned)rows), dim3(WSEL_THREADS), 0, st, a);
+  const int nblk = cdiv(k, WSEL_BLOCK);
+  const size_t lds = (size_t)WSEL_BLOCK * 12;
+  static AttrOnce attr_done;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(wsel_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(wsel_sort_kernel, dim3((unsigned)rows, (unsigned)nblk), dim3(WSEL_THREADS), lds, st, Av, Ai, k);
+  int passes = 0;
+  for (long long L = WSEL_BLOCK; L < k; L <<= 1) ++passes;
+  const dim3 mgrid((unsigned)cdiv(k, WSEL_THREADS), (unsigned)rows);
+  const float* sv = Av;
+  const int64_t* si = Ai;
+  if (passes == 0) {  // one block: the sorted block IS the new state (a merge pass against an empty partner run copies it)
+    hipLaunchKernelGGL(wsel_merge_kernel, mgrid, dim3(WSEL_THREADS), 0, st, sv, si, values, indices, k, WSEL_BLOCK, rec);
+  }
+  long long L = WSEL_BLOCK;
+  for (int j = 0; j < passes; ++j, L <<= 1) {
+    const bool last = j == passes - 1;
+    float* dv = last ? values : ((j & 1) == 0 ? Bv : Av);
+    int64_t* di = last ? indices : ((j & 1) == 0 ? Bi : Ai);
+    hipLaunchKernelGGL(wsel_merge_kernel, mgrid, dim3(WSEL_THREADS), 0, st, sv, si, dv, di, k, (int)L, last ? rec : nullptr);
+    sv = dv;
+    si = di;
+  }
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
 }
 
 int dprhot_search_workspace_bytes(int nq, int chunk, size_t* h_out) {

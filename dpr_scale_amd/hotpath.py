@@ -451,6 +451,21 @@ class HipKernels:
         self._lib.check(self.lib.dprhot_topk_update(_ptr(S), rows, int(cols), S.stride(0), int(col_offset), k, _ptr(values),
                                                     _ptr(indices), int(bool(first)), self._stream()), "dprhot_topk_update")
 
+    def topk_update_wide(self, S, cols, col_offset, values, indices, first, ws):
+        """Any k (csrc/wideselect.h): state in HBM.  ws: uint8 workspace of dprhot_topk_wide_workspace_bytes(rows, k) bytes; returns the
+        rows (a tensor of indices, usually empty) the library could not update -- their state is unchanged."""
+        self._require_gpu(S, values, indices, ws)
+        rows, k = values.shape
+        self._lib.check(self.lib.dprhot_topk_update_wide(_ptr(S), rows, int(cols), S.stride(0), int(col_offset), k, _ptr(values), _ptr(indices),
+                                                         1 if first else 0, _ptr(ws), ws.numel(), self._stream()), "dprhot_topk_update_wide")
+        rec = ws[: rows * 32].view(torch.int32).view(rows, 8)
+        return torch.nonzero(rec[:, 5]).flatten()
+
+    def topk_wide_workspace(self, rows, k, like):
+        n = ctypes.c_size_t(0)
+        self._lib.check(self.lib.dprhot_topk_wide_workspace_bytes(int(rows), int(k), ctypes.byref(n)), "dprhot_topk_wide_workspace_bytes")
+        return torch.empty(n.value, dtype=torch.uint8, device=like.device)
+
     def search_workspace(self, nq, chunk, like):
         return torch.empty(self._lib.search_workspace_bytes(nq, chunk), dtype=torch.uint8, device=like.device)
 
@@ -1108,6 +1123,7 @@ class CorpusSearch:
         self.values = torch.full((nq, k), float("-inf"), dtype=torch.float32, device=query_embs.device)
         self.indices = torch.full((nq, k), -1, dtype=torch.int64, device=query_embs.device)
         self.ws = None if self.wide_k else self.kn.search_workspace(nq, self.chunk, query_embs)
+        self.wide_ws = None
         self.first = True
 
     def _add_wide_native(self, Cb, first_id):
@@ -1127,29 +1143,52 @@ class CorpusSearch:
             self.first = False
 
     def _add_wide(self, Cb, first_id):
-        """k beyond 4096: the scores still come from the MFMA path chunk by chunk (dprhot_sim_fwd), the selection is
-        torch's: the chunk's own top-k, then state + chunk sorted in the same total order (score desc, id asc) -- two stable sorts,
-        ids first -- so that the result equals dprhot_topk of the whole matrix for any k.  Exact and rarely used (the reference's
-        recipes stop at --topk 1000); not a hand-written kernel."""
+        """k beyond 4096: the scores come from the MFMA path chunk by chunk (dprhot_sim_fwd), the selection is the library's
+        HBM-resident one (dprhot_topk_update_wide, csrc/wideselect.h: exact radix select over state + chunk, then only the k winners
+        are sorted) -- no torch sort.  A row the library reports back (more than 2048 candidates tied exactly at the k-th score)
+        is folded by _fold_rows_torch below."""
         n, d = Cb.shape
-        for j0 in range(0, n, self.chunk):
-            cols = min(self.chunk, n - j0)
+        step = min(self.chunk, 65536)
+        if self.wide_ws is None and hasattr(self.kn, "topk_update_wide"):
+            self.wide_ws = self.kn.topk_wide_workspace(self.values.shape[0], self.k, Cb)
+        for j0 in range(0, n, step):
+            cols = min(step, n - j0)
             pad = (-cols) % 8
             blk = Cb[j0:j0 + cols]
             if pad:
                 blk = torch.cat([blk, torch.zeros((pad, d), dtype=_BF16, device=Cb.device)], 0)
-            S = self.kn.sim(self.Qb, blk.contiguous(), None, 1.0)[:, :cols]
-            kk = min(self.k, cols)
-            order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :kk]  # ties: lower column first
-            v = torch.gather(S, 1, order)
-            ids = order + (first_id + j0)
-            allv, alli = torch.cat([self.values, v], 1), torch.cat([self.indices, ids], 1)
-            alli_key = torch.where(alli < 0, torch.full_like(alli, torch.iinfo(torch.int64).max), alli)  # empty slots last
-            o1 = torch.sort(alli_key, dim=1, stable=True).indices
-            allv, alli = torch.gather(allv, 1, o1), torch.gather(alli, 1, o1)
-            o2 = torch.sort(allv, dim=1, descending=True, stable=True).indices[:, :self.k]
-            self.values, self.indices = torch.gather(allv, 1, o2).contiguous(), torch.gather(alli, 1, o2).contiguous()
-        self.first = False
+            S = self.kn.sim(self.Qb, blk.contiguous(), None, 1.0)
+            if self.wide_ws is not None:
+                bad = self.kn.topk_update_wide(S, cols, first_id + j0, self.values, self.indices, self.first, self.wide_ws)
+                if bad.numel() > 0:
+                    if self.first:
+                        self.values[bad] = float("-inf")
+                        self.indices[bad] = -1
+                    self._fold_rows_torch(bad, S[:, :cols], first_id + j0)
+            else:
+                if self.first:
+                    self.values.fill_(float("-inf"))
+                    self.indices.fill_(-1)
+                self._fold_rows_torch(None, S[:, :cols], first_id + j0)
+            self.first = False
+
+    def _fold_rows_torch(self, rows, S, first_col):
+        """Exact fold of one chunk into the state of `rows` (None: all) with torch's stable sorts, in the same total order (score desc,
+        id asc): the library's escape for degenerate rows, and the whole path for stand-in kernels."""
+        sel = slice(None) if rows is None else rows
+        S = S[sel]
+        vals, idx = self.values[sel], self.indices[sel]
+        cols = S.shape[1]
+        kk = min(self.k, cols)
+        order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :kk]  # ties: lower column first
+        v = torch.gather(S, 1, order)
+        ids = order + first_col
+        allv, alli = torch.cat([vals, v], 1), torch.cat([idx, ids], 1)
+        alli_key = torch.where(alli < 0, torch.full_like(alli, torch.iinfo(torch.int64).max), alli)  # empty slots last
+        o1 = torch.sort(alli_key, dim=1, stable=True).indices
+        allv, alli = torch.gather(allv, 1, o1), torch.gather(alli, 1, o1)
+        o2 = torch.sort(allv, dim=1, descending=True, stable=True).indices[:, :self.k]
+        self.values[sel], self.indices[sel] = torch.gather(allv, 1, o2), torch.gather(alli, 1, o2)
 
     def add(self, corpus_embs, first_id=0):
         n, d = corpus_embs.shape

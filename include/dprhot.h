@@ -255,6 +255,15 @@ int dprhot_topk(const float* S, int rows, int cols, int k, float* values, int64_
 int dprhot_topk_update(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values,
                        int64_t* indices, int first, void* stream);
 
+/* The same update for ANY k (run_retrieval_pytorch.py:69 takes any --topk): the state lives in HBM, nothing has to fit in LDS
+ * (csrc/wideselect.h: exact radix select over state + chunk, then only the k winners are sorted -- blocks of 4096 in LDS, merge
+ * passes over HBM; ties exact at any multiplicity: the select continues over the ids).  workspace:
+ * dprhot_topk_wide_workspace_bytes(rows, k) bytes; its first rows * 8 32-bit words are one record per row whose word 5 is an error
+ * word -- a row with a non-zero one keeps its old state (no such condition is defined at present: always 0). */
+int dprhot_topk_wide_workspace_bytes(int rows, int k, size_t* h_bytes);
+int dprhot_topk_update_wide(const float* S, int rows, int cols, int64_t ld, int64_t col_offset, int k, float* values, int64_t* indices,
+                            int first, void* workspace, size_t workspace_bytes, void* stream);
+
 /* search_index (run_retrieval_pytorch.py:141-166) for one resident corpus shard: scores = Q x C^T on bf16 MFMA
  * (fp32 scores; the reference scores in fp16), chunk columns at a time, each chunk folded into the running
  * top-k -- the [nq, n_ctx] score matrix never exists.  Q [nq,d], C [n_ctx,d] bf16; passage ids are
