@@ -126,7 +126,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -154,6 +154,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},
     {"sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
     {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
+    {"sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
 };
 long long g_opt_epoch = 0;  // bumped by every dprhot_set_option: host-side caches of plan facts key on it (dprhot_options_epoch)
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
@@ -702,6 +703,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
     SkBwdFArgs b{a.P, Qb, Cb, B, Nc, d, tile_lse, gold, y, y_offset, nts, tpr, g_packed.rows_c, g_packed.n_ctx, grad_scale, h_scale, d_scale,
                  dC_part, g_dc_bf16 ? 1 : 0, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, loss_sum, g_loss_scale,
                  row_loss, row_lse, fz.ksteps, fz.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0, opt(OPT_SK_DBG)};
+    b.reg_scale = opt(OPT_SK_DC_REGSCALE) != 0 ? 1 : 0;
     const size_t lds = sk_bwdf_lds();
     static AttrOnce attr_done[4];
     auto launch = [&](auto kern, int slot, int threads) -> int {

@@ -1092,6 +1092,7 @@ struct SkBwdFArgs {
   // themselves in; the last workgroups of the grid wait for that count and fold the slabs.  nullptr: sk_dq_finish_kernel does it.
   unsigned* tail_cnt = nullptr;  // zeroed by the sim launch (SkSimArgs::zero_me)
   int nfin = 0;                  // finishing workgroups (rows / (threads / 256))
+  int reg_scale = 0;             // 1 (round 5): the dC units scale the Q FRAGMENTS by f in registers (no scale pass over the LDS image, one barrier less)
   int tail_fence = 0;            // 1: ordinary slab stores + ONE release fence per dQ unit, acquire fence + ordinary loads in the finishing role (A/B of the publish form)
 };
 
@@ -1582,7 +1583,8 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
     }
   }
   __syncthreads();
-  {
+  const bool rs = p.reg_scale != 0;
+  if (!rs) {
     // Q rows x f in place (both bf16): 16-byte chunk c of the image belongs to row c >> 4 whatever the column swizzle; consecutive
     // lanes take consecutive chunks
     uint4* const img = reinterpret_cast<uint4*>(Qs);
@@ -1597,8 +1599,8 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
       w.w = pk_bf16(sk_bf_lo(w.w) * fr, sk_bf_hi(w.w) * fr);
       img[c] = w;
     }
+    __syncthreads();
   }
-  __syncthreads();
   const bool solo = mine && cnt[yrel] == 1;
   if (mine && !solo) dupf[0] = 1;  // two rows with one gold column (read behind the next barrier)
   // loss numerator (every unit that stamps it, and unit 0 which publishes it): fixed order
@@ -1624,6 +1626,21 @@ __device__ __forceinline__ void sk_dc_unit_f(const SkBwdFArgs& p, int unit, uint
     for (int a = 0; a < 4; ++a) af[a] = load_frag<128, 64, false, true>(Gs, wm * 64 + a * 16, kk, lane);
 #pragma unroll
     for (int b = 0; b < NBF; ++b) bf[b] = load_frag<128, 64, false, true>(Qs, wn * (SK_DN / WN) + b * 16, kk, lane);
+    if (rs) {
+      // the fragment's element j is query row k = kk * 32 + g4 * 8 + j (load_frag): times f of that row, rounded to bf16 exactly as the
+      // scale pass rounds (same product, same RNE) -- the image stays as the DMA left it, no pass over it, no barrier behind one
+      const f32x4 f0 = *reinterpret_cast<const f32x4*>(fi + kk * 32 + g4 * 8), f1 = *reinterpret_cast<const f32x4*>(fi + kk * 32 + g4 * 8 + 4);
+#pragma unroll
+      for (int b = 0; b < NBF; ++b) {
+        union { bf16x8 v; unsigned w[4]; } u;
+        u.v = bf[b];
+        u.w[0] = pk_bf16(sk_bf_lo(u.w[0]) * f0[0], sk_bf_hi(u.w[0]) * f0[1]);
+        u.w[1] = pk_bf16(sk_bf_lo(u.w[1]) * f0[2], sk_bf_hi(u.w[1]) * f0[3]);
+        u.w[2] = pk_bf16(sk_bf_lo(u.w[2]) * f1[0], sk_bf_hi(u.w[2]) * f1[1]);
+        u.w[3] = pk_bf16(sk_bf_lo(u.w[3]) * f1[2], sk_bf_hi(u.w[3]) * f1[3]);
+        bf[b] = u.v;
+      }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll

@@ -298,6 +298,32 @@ def test_operator_takes_the_no_dscores_plan_and_survives_a_retained_graph(dev):
     assert _err(q.grad, dq1) <= 5e-3 and _err(c.grad, dc1) <= 5e-3
 
 
+def test_dc_units_scaling_fragments_in_registers_is_bit_identical(dev):
+    """Option sk_dc_regscale (round 5; measured no faster, off by default): f x q formed per fragment element in registers instead of by
+    a pass over the LDS image -- the same products, the same rounding: bit-identical gradients."""
+    from dpr_scale_amd import _lib
+    from dpr_scale_amd.hotpath import HipKernels
+
+    kn = HipKernels()
+    for W, B, K, d, T in ((8, 128, 8, 768, 1.0), (8, 64, 16, 512, 0.25), (2, 128, 16, 1024, 0.25)):
+        qs, cs, y, ms = _world(W, B, K, d, dev, seed=W * 11 + K, dup=True)
+        n_ctx = B * K
+        rows_c, Cb, colmask = _packed(kn, qs, cs, ms, dev)
+        if _lib.step_wants_g(B, W * rows_c, d):
+            continue
+        yd = y.to(dev)
+        Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+        outs = []
+        for rs in (0, 1):
+            _lib.set_option("sk_dc_regscale", rs)
+            try:
+                rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(qs[0], Cb, Qb, W, 0, n_ctx, yd, 1.0 / T, 1.0 / (T * W * B), want_G=False)
+                outs.append((dq.clone(), dcp.clone()))
+            finally:
+                _lib.set_option("sk_dc_regscale", 0)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_finishing_role_inside_the_backward_launch(mode, dev):
     """Option sk_tail (round 5; measured slower, off by default, kept with this test): the dQ slabs folded by the last workgroups of
