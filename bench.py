@@ -1255,11 +1255,24 @@ def main():
             # process): packed layout, the all-gather started under the query tower, the reduce-scatter under its backward
             try:
                 import subprocess
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "overlap_trace.py"), "--B", str(B), "--K", str(K), "--steps", "5",
-                                    "--order", "auto", "--warmup", "16"],  # (the product default: the order of the towers is timed over the first 14 steps)
-                                   capture_output=True, text=True, timeout=300, env=dict(os.environ, MASTER_PORT="29773"))
+                # ONE child process, the two branches alternating (three rounds of ten steps each; the first forced round also holds the
+                # task's 14-step trial of the tower order): a 125 ms step measured in two different processes differs by more than the
+                # +-0.3 ms in question (clock state, allocator history), so both sides of the comparison come from the same process
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "forced_dist_breakdown.py"), "--no-prof", "--steps", "10", "--warmup", "16",
+                                    "--modes", "forced_auto,single,forced_auto,single,forced_auto,single"],
+                                   capture_output=True, text=True, timeout=400, env=dict(os.environ, MASTER_PORT="29773"))
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                out["end_to_end_forced_dist"] = json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+                if line:
+                    fj = json.loads(line[-1])
+                    out["end_to_end_forced_dist"] = {
+                        "what": "DenseRetrieverTask.training_step through its MULTI-GPU branch on a one-rank RCCL world (packed layout, ContextGather, packed step, "
+                                "reduce-scatter, deferred context gradient; tower order chosen by the task's own trial) against the single-device branch, "
+                                "alternating in ONE process: " + fj["workload"],
+                        "ms_per_step": fj["median_wall_ms_per_step"].get("forced_auto"), "single_branch_ms_per_step_same_process": fj["median_wall_ms_per_step"].get("single"),
+                        "forced_minus_single_ms": fj.get("forced_auto_minus_single_ms"), "tower_order_trial": fj.get("tower_order_trial"),
+                        "rounds": fj["runs"]}
+                else:
+                    out["end_to_end_forced_dist"] = {"error": (r.stderr or r.stdout)[-300:]}
             except Exception as e:
                 out["end_to_end_forced_dist"] = {"error": repr(e)}
         wd.cancel()

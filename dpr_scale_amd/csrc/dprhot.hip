@@ -675,7 +675,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   const bool fused = G == nullptr && S_out == nullptr && fz.ok;
   if (G == nullptr && !fused) return fail(DPRHOT_E_INVALID, "few-rows step: G == NULL needs the fused-dScores plan (dprhot_step_wants_g)");
   // the finishing role inside the backward launch (sk_fin_unit): two-kinds form only; a dbg switch that silences units would strand it
-  const bool tail = fused && !fz.pair && opt(OPT_SK_TAIL) != 0 && opt(OPT_SK_DBG) == 0 && fz.nslices <= 62 && d <= 1024;
+  const bool tail = fused && !fz.pair && opt(OPT_SK_TAIL) != 0 && (opt(OPT_SK_DBG) & 7) == 0 && fz.nslices <= 62 && d <= 1024;
   unsigned* const tail_cnt = reinterpret_cast<unsigned*>(ws + wl.header + 128);
   if (fused) {
     a.S = nullptr;
@@ -746,7 +746,12 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());
-    if (!tail) {
+    if (!tail && (opt(OPT_SK_DBG) & 8)) {
+      // TIMING EXPERIMENT ONLY (sk_dbg & 8): the plain slab sum in the finishing launch's place (wrong dQ) -- which launch carries the gaps?
+      const size_t n4 = (size_t)B * d / 4;
+      hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, fz.nslices, n4, h_scale, d_scale, dQ);
+      HIP_TRY(hipGetLastError());
+    } else if (!tail) {
       // one workgroup per row where the row fits 256 threads (d <= 1024): the row's statistics are derived once, not once per part
       const int fthreads = d / 4 >= 256 ? 256 : cdiv(d / 4, 64) * 64;
       const int parts = cdiv(d / 4, fthreads);

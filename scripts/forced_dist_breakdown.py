@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--prof", type=int, default=3)
     ap.add_argument("--wire", default="bf16")
     ap.add_argument("--modes", default="single,single_ctx1st,forced,single,forced")
+    ap.add_argument("--no-prof", action="store_true", help="wall times only (bench.py's end_to_end_forced_dist block: forced_auto against single, one process)")
     a = ap.parse_args()
     os.environ["DPRHOT_DC_WIRE"] = a.wire
     os.environ["DPRHOT_DIRECT_RCCL"] = "0"
@@ -106,7 +107,17 @@ def main():
         finally:
             task.context_tower_first = True
 
-    fns = {"single": step_single, "single_ctx1st": step_single_ctx1st, "forced": step_forced, "forced_ref": step_forced_ref}
+    def step_forced_auto():  # the product's default: the task's own trial picks the order over its first 14 steps, then keeps it
+        os.environ["DPRHOT_FORCE_DIST"] = "1"
+        os.environ["DPRHOT_TOWER_ORDER"] = "auto"
+        task.context_tower_first = True
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return task.training_step(batch, 0)
+        finally:
+            os.environ["DPRHOT_TOWER_ORDER"] = "context_first"
+
+    fns = {"single": step_single, "single_ctx1st": step_single_ctx1st, "forced": step_forced, "forced_ref": step_forced_ref, "forced_auto": step_forced_auto}
 
     def full(fn):
         loss = fn()
@@ -127,6 +138,9 @@ def main():
             full(fn)
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t0) / a.steps * 1e3
+        if a.no_prof:
+            out["runs"].append({"mode": mode, "wall_ms_per_step": round(wall_ms, 3)})
+            continue
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
             for _ in range(a.prof):
                 full(fn)
@@ -169,7 +183,14 @@ def main():
     by_mode = {}
     for r in out["runs"]:
         by_mode.setdefault(r["mode"], []).append(r)
-    if "single" in by_mode and "forced" in by_mode:
+    if a.no_prof:
+        med = lambda rs: sorted(r["wall_ms_per_step"] for r in rs)[len(rs) // 2]  # noqa: E731
+        out["median_wall_ms_per_step"] = {m: med(rs) for m, rs in by_mode.items()}
+        tr = getattr(task, "_order_trial", None)
+        out["tower_order_trial"] = None if not tr or tr.get("decided") is None else {"decided": tr["decided"], "ms_per_step": tr["ms"]}
+        if "single" in by_mode and "forced_auto" in by_mode:
+            out["forced_auto_minus_single_ms"] = round(med(by_mode["forced_auto"]) - med(by_mode["single"]), 3)
+    elif "single" in by_mode and "forced" in by_mode:
         mean = lambda rs, key: sum(r[key] for r in rs) / len(rs)  # noqa: E731
         out["forced_minus_single"] = {
             "wall_ms": round(mean(by_mode["forced"], "wall_ms_per_step") - mean(by_mode["single"], "wall_ms_per_step"), 3),

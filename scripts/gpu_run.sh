@@ -41,11 +41,11 @@ for task in "$@"; do
     tests)  ( timeout 1500 python -m pytest tests -m gpu -x -q --timeout 420 ${arg:+-k "$arg"} ) > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -n 15 $OUT/pytest_gpu.txt ;;
     smoke)  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 3 ;;
     bench)  ( timeout 1500 python bench.py $arg ) > $OUT/bench_n1.log 2>&1; echo "bench rc=$?"; tail -n 1 $OUT/bench_n1.log > $OUT/bench_n1.json; cut -c1-1500 $OUT/bench_n1.json ;;
-    prof-bench) three_passes bench r04_bench_cfg2 python $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --repeats 3 --only step --driver eager ;;
-    prof-rank)  three_passes rank r04_cfg3rank python $GRAFT_REPO_ROOT/scripts/bench_rankstep.py --shapes ${arg:-128:8:768:8} --eager --reps 50 ;;
-    prof-router) three_passes router r04_router python $GRAFT_REPO_ROOT/bench.py --only router ;;
-    prof-8192)  three_passes big r04_8192 python $GRAFT_REPO_ROOT/bench_sweep.py --shapes 8192x8192 ;;
-    prof-op)    three_passes op r04_operator python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --repeats 3 --only operator ;;
+    prof-bench) three_passes bench r05_bench_cfg2 python $GRAFT_REPO_ROOT/bench.py --steps 500 --warmup 50 --repeats 3 --only step --driver eager ;;
+    prof-rank)  three_passes rank r05_cfg3rank python $GRAFT_REPO_ROOT/scripts/bench_rankstep.py --shapes ${arg:-128:8:768:8} --eager --reps 50 ;;
+    prof-router) three_passes router r05_router python $GRAFT_REPO_ROOT/bench.py --only router ;;
+    prof-8192)  three_passes big r05_8192 python $GRAFT_REPO_ROOT/bench_sweep.py --shapes 8192x8192 ;;
+    prof-op)    three_passes op r05_operator python $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 --repeats 3 --only operator ;;
     pmc8192)
       i=0
       for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
