@@ -126,7 +126,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -155,6 +155,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
     {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
     {"sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
+    {"g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
 };
 long long g_opt_epoch = 0;  // bumped by every dprhot_set_option: host-side caches of plan facts key on it (dprhot_options_epoch)
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
@@ -257,7 +258,8 @@ int launch_g8(const GemmArgs& a, const Epi& epi, hipStream_t st) {
     attr_done = true;
   }
   const int nbx = cdiv(a.N, G2_B), nby = cdiv(a.M, G2_B);
-  const int grid = nbx * nby < kNumCU ? nbx * nby : kNumCU;
+  const bool stores_tile = std::is_same<Epi, Epi8G>::value || std::is_same<Epi, Epi8Store>::value;
+  const int grid = (nbx * nby < kNumCU || (stores_tile && opt(OPT_G8_ONE_TILE) != 0)) ? nbx * nby : kNumCU;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g8_lds_total, st, a, epi, nbx, nby);
   HIP_TRY(hipGetLastError());
   return DPRHOT_OK;
