@@ -148,7 +148,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
     {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
     {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured faster (B x Nc >= 2^19), 2 = wherever the plan exists (tests), 0 = never"},
-    {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward): 1 dC units leave at once, 2 dQ units leave at once, 4 dQ units load no gold rows"},
+    {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward; bits): 1 dC units leave at once, 2 dQ units leave at once, 4 (unused), 8 the plain slab sum in the finishing launch's place (wrong dQ), 16 the dQ slabs leave with ordinary instead of non-temporal stores"},
     {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
     {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
     {"sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},

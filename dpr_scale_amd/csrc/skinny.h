@@ -1485,7 +1485,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     if (row < p.B) {
       const float4 v = *reinterpret_cast<const float4*>(T + row * TS + cq * 4);
       if (p.tail_cnt != nullptr && !p.tail_fence) sk_st16_sc1(out + (size_t)row * p.d + c0 + cq * 4, f32x4{v.x, v.y, v.z, v.w});
-      else if (p.nt_store) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
+      else if (p.nt_store && !(p.dbg & 16)) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(out + (size_t)row * p.d + c0 + cq * 4));
       else *reinterpret_cast<float4*>(out + (size_t)row * p.d + c0 + cq * 4) = v;
     }
   }
