@@ -82,7 +82,43 @@ def main():
         if not torch.equal(i, order):
             bad += 1
             print(f"SEARCH MISMATCH case {case}: nq={nq} n={n} d={d} k={k} chunk={chunk}")
-    print(f"fuzz_topk: {a.cases} top-k cases + 12 search cases, {bad} mismatches")
+    # k beyond the LDS-resident kernels: dprhot_topk_update_wide (csrc/wideselect.h) folded over random pieces, all value modes of above
+    nwide = max(a.cases // 6, 20)
+    for case in range(nwide):
+        cols = rnd(4100, 90000)
+        k = min(rnd(4097, 30000), cols)
+        rows = rnd(1, 5)
+        mode = rnd(0, 4)
+        if mode == 0:
+            S = torch.randn(rows, cols, generator=g)
+        elif mode == 1:
+            S = torch.randint(0, rnd(1, 40), (rows, cols), generator=g).float()  # thousands of ties, also at the k-th value
+        elif mode == 2:
+            S = torch.randn(rows, cols, generator=g).to(torch.bfloat16).float()
+        elif mode == 3:
+            S = torch.full((rows, cols), float("-inf"))
+            n = rnd(0, cols)
+            idx = torch.randperm(cols, generator=g)[:n]
+            S[:, idx] = torch.randn(rows, n, generator=g)
+        else:
+            S = torch.zeros(rows, cols)
+            S[:, ::3] = -0.0
+        S = S.to(dev)
+        order = torch.sort(S, dim=1, descending=True, stable=True).indices[:, :k]
+        cuts = sorted(set([0, cols] + [rnd(0, cols) for _ in range(rnd(0, 4))]))
+        v2 = torch.empty((rows, k), dtype=torch.float32, device=dev)
+        i2 = torch.empty((rows, k), dtype=torch.int64, device=dev)
+        ws = kn.topk_wide_workspace(rows, k, S)
+        first = True
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            if hi > lo:
+                badrows = kn.topk_update_wide(S[:, lo:], hi - lo, 7 + lo, v2, i2, first, ws)
+                assert badrows.numel() == 0
+                first = False
+        if not (torch.equal(i2, order + 7) and torch.equal(v2, S.gather(1, order))):
+            bad += 1
+            print(f"WIDE MISMATCH case {case}: rows={rows} cols={cols} k={k} mode={mode} cuts={cuts}")
+    print(f"fuzz_topk: {a.cases} top-k cases + 12 search cases + {nwide} wide-k cases, {bad} mismatches")
     return 1 if bad else 0
 
 
