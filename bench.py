@@ -923,6 +923,7 @@ def variants_block(a, W, rank, dev, backend, B, K, d, T, hp, measure, state):
     # the C ABI communicator: opt-in in the product, brought up here (collectively, under its own watchdog inside enable_direct_comm
     # plus this block's) so that its four variants can be measured; every rank gets it or none does
     have_direct = False
+    env_direct = os.environ.get("DPRHOT_DIRECT_RCCL")
     if backend == "nccl" and os.environ.get("DPRHOT_DIRECT_RCCL", "1") != "0":
         os.environ["DPRHOT_DIRECT_RCCL"] = "1"
         D.configure(None, None)  # (direct=False would hide the communicator from its own set-up's return value)
@@ -983,6 +984,16 @@ def variants_block(a, W, rank, dev, backend, B, K, d, T, hp, measure, state):
                 except Exception as e:
                     out[name] = {"error": repr(e)}
     D.configure(None, None)
+    # The communicator was brought up for this block only.  What runs after it (the end-to-end leg: DDP's own communicator next to the
+    # path's collectives) is the product's default configuration, in which the C ABI communicator is opt-in: take it down again, on
+    # every rank, and put the environment switch back where the caller had it.
+    if have_direct:
+        torch.cuda.synchronize()
+        D.disable_direct_comm()
+    if env_direct is None:
+        os.environ.pop("DPRHOT_DIRECT_RCCL", None)
+    else:
+        os.environ["DPRHOT_DIRECT_RCCL"] = env_direct
     return out
 
 
