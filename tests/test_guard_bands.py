@@ -211,3 +211,69 @@ def test_the_checker_itself_sees_one_stray_byte_on_either_side(guarded):
         with pytest.raises(AssertionError, match=where.upper()):
             g.check("control")
         g.regions = []
+
+
+@pytest.mark.parametrize("B,Nc,d", [(64, 1000, 768), (16, 64, 30522), (128, 1032, 30528), (300, 4100, 128)])
+def test_differentiable_scoring_stays_inside_its_buffers(B, Nc, d, guarded):
+    """sim_score with gradients (citadel_task.py:249-262: loss(sim_score(q, c, mask), y)), vocabulary-wide vectors included (the
+    fp32 LDS-DMA sim launch of csrc/wide.h; 30522 is zero-padded to a multiple of 8 first)."""
+    from dpr_scale_amd.hotpath import cross_entropy_mean, sim_score
+
+    kn, g = guarded
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(B + Nc + d)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(dev).requires_grad_(True)
+    c = (torch.randn(Nc, d, generator=gen) * d ** -0.25).to(dev).requires_grad_(True)
+    y = torch.randint(0, Nc, (B,), generator=gen).to(dev)
+    m = (torch.rand(Nc, generator=gen) < 0.1).to(dev)
+    m[y] = False
+    S = sim_score(q, c, m, 1.0, kn)
+    loss = cross_entropy_mean(S.detach(), y, kn)
+    S.backward(torch.ones_like(S) / S.numel())
+    assert torch.isfinite(loss) and torch.isfinite(q.grad).all() and torch.isfinite(c.grad).all()
+    assert g.check(f"sim_score {B}x{Nc}x{d}") >= 3
+
+
+@pytest.mark.parametrize("B,K,d", [(32, 8, 768), (64, 3, 100), (7, 5, 256)])
+def test_windowed_and_pairwise_scoring_stay_inside_their_buffers(B, K, d, guarded):
+    """in_batch_negatives = False (dpr_task.py:198-207) and the per-query score block the router loss uses."""
+    from dpr_scale_amd.hotpath import pairwise_score, windowed_contrastive_loss
+
+    kn, g = guarded
+    dev = torch.device("cuda", 0)
+    q, c, y, m = _inputs(B, K, d, dev, seed=3 * B + K)
+    loss = windowed_contrastive_loss(q, c, y, m, 1.0, kn)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(q.grad).all() and torch.isfinite(c.grad).all()
+    if d % 8 == 0:
+        P = pairwise_score(q, c, m, kn)
+        P.masked_fill(~torch.isfinite(P), 0.0).sum().backward()
+        assert P.shape == (B, K)
+    assert g.check(f"windowed / pairwise {B}x{K}x{d}") >= 3
+
+
+@pytest.mark.parametrize("n,W", [(8 * 1000, 2), (110_000_000 // 8 * 8, 8), (8 * 12345, 3)])
+@pytest.mark.parametrize("wire", [torch.bfloat16, torch.float16, torch.float32])
+def test_gradient_bucket_legs_stay_inside_their_buffers(n, W, wire, guarded):
+    """The three local legs of the DDP hook (comm_hooks._HipLegs: pack with pre-division, fp32 sum of the W shards, widen)."""
+    from dpr_scale_amd.comm_hooks import _HipLegs
+
+    _, g = guarded
+    dev = torch.device("cuda", 0)
+    legs = _HipLegs()
+    shard = (n + W - 1) // W
+    shard = (shard + 7) // 8 * 8
+    buf = torch.randn(n, device=dev)
+    send = torch.empty(W * shard, dtype=wire, device=dev)
+    legs.pack(buf, 1.0 / W, send)
+    red = torch.empty(shard, dtype=wire, device=dev)
+    legs.sum_shards(send, W, red)  # (this rank's view of an exchange in which every peer sent the same bytes)
+    red32 = torch.empty(shard, dtype=torch.float32, device=dev)
+    legs.sum_shards(send, W, red32)
+    full = torch.empty(W * shard, dtype=wire, device=dev)
+    full.copy_(send)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    legs.unpack(full, out)
+    tol = 0.0 if wire == torch.float32 else (2 ** -8 if wire == torch.bfloat16 else 2 ** -10)
+    assert torch.allclose(out, buf / W, rtol=tol, atol=1e-6)
+    assert g.check(f"gradient legs n={n} W={W} {wire}") == 5
