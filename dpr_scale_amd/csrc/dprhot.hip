@@ -1442,7 +1442,14 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
   REQUIRE(G && Q && C, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0) {
+  // Few query rows against a very long context axis (B <= 1024, Nc >= 56 Ki: 8192 global queries x 8 contexts seen from one of 8
+  // ranks): the pair launch loses to its own two halves launched one after the other -- its dC tiles are K = B deep, 4 to 16 K steps
+  // between a pipeline fill and a 256 KiB store, next to dQ units four times as long (the K slices of dQ stop at 16).  Measured, pair
+  // against dQ + dC, us: 256 x 65536 x 768 252 / 146, 512 x 65536 356 / 235, 1024 x 65536 500 / 382, 1024 x 65536 x 1024 600 / 457;
+  // ties or pair ahead at 1024 x 49152 (296 / 287), 2048 x 65536 (628 / 626), 1024 x 32768 (188 / 203), 4096 x 65536 (803 / 1204)
+  // (scratch/bwd_parts.py).
+  const bool long_axis = B <= 1024 && Nc >= 56 * 1024 && !sk_plan(B, Nc, d).ok && !wide_bwd_ok(B, Nc, d) && opt(OPT_NO_BIG_BWD) == 0;
+  if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0 || long_axis) {
     if (dC_part != nullptr)
       if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
     if (dQ != nullptr)

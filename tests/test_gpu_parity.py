@@ -1373,3 +1373,30 @@ def test_cpp_autograd_node_equals_the_python_operator(dev):
     with torch.no_grad():
         loss = hotpath.inbatch_contrastive_loss(t(q, dev), t(c, dev), ty, tm, meta["T"])
     assert loss.grad_fn is None and abs(loss.item() - g["loss"]) <= LOSS_RTOL * max(1.0, abs(g["loss"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Nc,d,separate", [(1024, 65536, 768, True), (256, 57344, 768, True), (1024, 49152, 768, False)])
+def test_backward_over_a_very_long_context_axis(B, Nc, d, separate, kn, dev):
+    """dprhot_inbatch_bwd's plan rule for few query rows against >= 56 Ki gathered contexts (the two GEMMs one after the other
+    instead of the pair launch: 500 -> 382 us at 1024 x 65536 x 768): both gradients against fp32 matmuls of the same bf16 operands,
+    and the launch that runs is the one the rule names.  Autograd of dpr_task.py:98-105 into q and c."""
+    from torch.profiler import ProfilerActivity, profile
+
+    gen = torch.Generator().manual_seed(B + Nc)
+    G = (torch.randn(B, Nc, generator=gen) * 0.01).to(torch.bfloat16).to(dev)
+    Qb = torch.randn(B, d, generator=gen).to(torch.bfloat16).to(dev)
+    Cb = torch.randn(Nc, d, generator=gen).to(torch.bfloat16).to(dev)
+    go = torch.full((1,), 0.5, device=dev)
+    dQ, dC = kn.inbatch_bwd(G, Qb, Cb, 2.0, go)
+    torch.cuda.synchronize()
+    ref_dq = G.float() @ Cb.float()
+    ref_dc = G.float().t() @ Qb.float()
+    assert float((dQ - ref_dq).abs().max() / ref_dq.abs().max()) <= 2e-5
+    assert float((dC - ref_dc).abs().max() / ref_dc.abs().max()) <= 2e-5
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        kn.inbatch_bwd(G, Qb, Cb, 2.0, go)
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    if names:
+        assert any("gemm8p_bwd_kernel" in n for n in names) != separate, names
