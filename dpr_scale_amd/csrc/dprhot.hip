@@ -1442,14 +1442,10 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
   REQUIRE(G && Q && C, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  // Few query rows against a very long context axis (B <= 1024, Nc >= 56 Ki: 8192 global queries x 8 contexts seen from one of 8
-  // ranks): the pair launch loses to its own two halves launched one after the other -- its dC tiles are K = B deep, 4 to 16 K steps
-  // between a pipeline fill and a 256 KiB store, next to dQ units four times as long (the K slices of dQ stop at 16).  Measured, pair
-  // against dQ + dC, us: 256 x 65536 x 768 252 / 146, 512 x 65536 356 / 235, 1024 x 65536 500 / 382, 1024 x 65536 x 1024 600 / 457;
-  // ties or pair ahead at 1024 x 49152 (296 / 287), 2048 x 65536 (628 / 626), 1024 x 32768 (188 / 203), 4096 x 65536 (803 / 1204)
-  // (scratch/bwd_parts.py).
-  const bool long_axis = B <= 1024 && Nc >= 56 * 1024 && !sk_plan(B, Nc, d).ok && !wide_bwd_ok(B, Nc, d) && opt(OPT_NO_BIG_BWD) == 0;
-  if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0 || long_axis) {
+  // (the long context axis under fewer than 512 rows: both GEMMs on the 128 x 128 engine -- see `long_axis` below; 256 x 65536 x 768:
+  //  146 us against 174 with the dQ units on the 256 x 256 kernel and 252 for the pair)
+  const bool long_axis_small = B < 512 && Nc >= 56 * 1024 && !sk_plan(B, Nc, d).ok && !wide_bwd_ok(B, Nc, d) && big_bwd_ok(B, Nc, d);
+  if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0 || long_axis_small) {
     if (dC_part != nullptr)
       if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
     if (dQ != nullptr)
@@ -1525,7 +1521,17 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g2_lds_total));
       attr_done = true;
     }
-    const int nbx1 = cdiv(d, G2_B), nby1 = cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
+    // Few query rows against a long context axis (512 <= B <= 2048, Nc >= 32 B: e.g. 8192 global queries x 8 contexts seen from one
+    // of 8 ranks): the dC tiles of the pair launch are only K = B deep -- 8 to 32 K steps between a pipeline fill and a 256 KiB store
+    // -- next to dQ units several times as long (the K slices of dQ stop at 16), and the launch loses to dC on the 128 x 128 engine in a
+    // launch of its own (dprhot_dc) followed by this launch with its dQ units only.  Measured, pair / dC apart, us (d = 768,
+    // scratch/bwd_hybrid_ab.py, profiles/r05_bwd_long_axis.txt): 1024 x 32768 181 / 154, 1024 x 49152 292 / 236, 1024 x 65536 482 / 299,
+    // 512 x 16384 73 / 70, 512 x 32768 117 / 112, 512 x 65536 356 / 202, 2048 x 65536 611 / 555, 1024 x 32768 x 1024 217 / 197; the
+    // pair stays where it wins: 1024 x 8192 43 / 71, 1024 x 16384 82 / 96, 2048 x 16384 122 / 146, 2048 x 32768 228 / 289, 512 x 8192 33 / 50.
+    const bool long_axis = B >= 512 && B <= 2048 && (long)Nc >= 32L * B;
+    if (long_axis)
+      if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
+    const int nbx1 = cdiv(d, G2_B), nby1 = long_axis ? 0 : cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
     a1.kchunk = B;  // dC: one K range (B % 64 == 0)
     const int grid = nbx1 * nby1 + nbx2 * nby2 * p.splits;
     const bool no8 = opt(OPT_NO_8PB) != 0;

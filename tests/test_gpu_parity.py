@@ -1376,11 +1376,14 @@ def test_cpp_autograd_node_equals_the_python_operator(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Nc,d,separate", [(1024, 65536, 768, True), (256, 57344, 768, True), (1024, 49152, 768, False)])
+@pytest.mark.parametrize("B,Nc,d,separate", [(1024, 65536, 768, True), (512, 16384, 768, True), (256, 57344, 768, True), (2048, 65536, 768, True), (1024, 16384, 768, False),
+                                                    (2048, 32768, 768, False)])
 def test_backward_over_a_very_long_context_axis(B, Nc, d, separate, kn, dev):
-    """dprhot_inbatch_bwd's plan rule for few query rows against >= 56 Ki gathered contexts (the two GEMMs one after the other
-    instead of the pair launch: 500 -> 382 us at 1024 x 65536 x 768): both gradients against fp32 matmuls of the same bf16 operands,
-    and the launch that runs is the one the rule names.  Autograd of dpr_task.py:98-105 into q and c."""
+    """dprhot_inbatch_bwd's plan rule for few query rows against a long context axis (512 <= B <= 2048 and Nc >= 32 B: dC through the
+    128 x 128 engine in a launch of its own, dQ on the pair kernel's units; below 512 rows and from 56 Ki contexts both on the 128 x 128
+    engine: 482 -> 298 us at 1024 x 65536 x 768):
+    both gradients against fp32 matmuls of the same bf16 operands, and the launches that run are the ones the rule names.  Autograd of
+    dpr_task.py:98-105 into q and c."""
     from torch.profiler import ProfilerActivity, profile
 
     gen = torch.Generator().manual_seed(B + Nc)
@@ -1399,4 +1402,5 @@ def test_backward_over_a_very_long_context_axis(B, Nc, d, separate, kn, dev):
         torch.cuda.synchronize()
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     if names:
-        assert any("gemm8p_bwd_kernel" in n for n in names) != separate, names
+        assert any("gemm_bf16_kernel" in n for n in names) == separate, names  # (the 128 x 128 engine: dC, and dQ below 512 rows)
+        assert any("gemm8p_bwd_kernel" in n for n in names) == (not separate or B >= 512), names
