@@ -1261,11 +1261,13 @@ def test_rank_and_loss_with_a_hidden_size_that_is_not_a_multiple_of_8(kn, dev):
     assert abs(loss.item() - ref) <= LOSS_RTOL * max(1.0, abs(ref))
 
 
-def test_packed_multi_rank_step_at_a_no_logits_shape(kn, dev):
+@pytest.mark.parametrize("W,B,K,d", [(2, 1024, 16, 128), (2, 512, 32, 256), (8, 1024, 8, 256)])
+def test_packed_multi_rank_step_at_a_no_logits_shape(W, B, K, d, kn, dev):
     """Large per-rank batch over several ranks, emulated on one GPU: dprhot_inbatch_step_packed_f32 then runs the no-logits forward
     with the column mask read from the gathered buffer's mask rows (Epi8Base::mask_byte, packed layout) and stamps the loss numerator
     into dC_part.  Checked against the unpacked formulation of the same step (mask vector from dprhot_unpack_mask, logits stored)."""
-    W, B, K, d = 2, 1024, 16, 128  # Nc = 2 * packed_rows(16384, 128) ~ 33 k columns: 4 x 129 tiles
+    # (2, 1024, 16, 128): Nc = 2 * packed_rows(16384, 128) ~ 33 k columns, 4 x 129 tiles.  The other two are long-context-axis shapes of
+    # the 256 x 256 backward (Nc >= 32 B): dC -- and with it the loss stamp -- leaves through the 128 x 128 engine in a launch of its own
     n_ctx = B * K
     rows_c = kn.packed_rows(n_ctx, d)
     gen = torch.Generator(device="cpu").manual_seed(9)
