@@ -61,44 +61,147 @@ def decide_topology(us_rccl, us_allpairs, group=None, device=None):
     return ("allpairs" if int(flag.item()) == 1 else "rccl"), {"rccl": rccl_us, "allpairs": ap_us}
 
 
-def choose_path_collectives(device, rows_c, d, group=None, iters=20, wire=torch.float32):
+def path_is_pinned():
+    """True when the form of the path's collectives was fixed by hand (configure() or DPRHOT_PATH_COLLECTIVES): nothing to measure."""
+    return _CFG["topology"] is not None or os.environ.get("DPRHOT_PATH_COLLECTIVES", "") in ("allpairs", "rccl")
+
+
+def _agree(flag, group, device):
+    """COLLECTIVE: True iff `flag` is true on every rank (all-reduce MIN)."""
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()) == 1)
+
+
+class probe_watchdog:
+    """`with probe_watchdog(seconds, what):` -- a collective start-up measurement that has not come back after `seconds` cannot be
+    recovered from inside the process (a rank waiting in a collective its peers never issue waits for ever): the watchdog says so and
+    ends the process with exit code 70 instead of leaving a silent hang.  bench.py arms its own (it has a line to print first);
+    DenseRetrieverTask arms this one around dist.choose_path_collectives.  seconds <= 0 disarms."""
+
+    def __init__(self, seconds, what="dpr_scale_amd.dist: the collective start-up probe"):
+        self.seconds, self.what, self.timer = float(seconds), what, None
+
+    def _fire(self):
+        import sys
+
+        sys.stderr.write(f"{self.what} did not come back within {self.seconds:.0f} s: a rank is waiting in a collective its peers never "
+                         "issued.  Set DPRHOT_PATH_PROBE=0 (keep RCCL's collectives) or DPRHOT_PATH_COLLECTIVES=rccl|allpairs to skip the "
+                         "measurement; exiting (70)\n")
+        sys.stderr.flush()
+        os._exit(70)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
+def choose_path_collectives(device, rows_c, d, group=None, iters=20, wire=torch.float32, wires=None, preflight=None):
     """COLLECTIVE, once per group (DenseRetrieverTask.on_pretrain_routine_start): time the path's two collectives at the step's real
     message sizes -- all-gather of one packed block [rows_c, d] bf16 per rank, reduce-scatter of [W * rows_c, d] partials in the wire
     format -- in both forms, `iters` iterations each behind two warm-up rounds, and keep the faster form for this group
-    (decide_topology).  An explicit DPRHOT_PATH_COLLECTIVES or configure() still wins.  World size 1: nothing to choose."""
+    (decide_topology).  `wires`: the dC wire formats to consider (round 6: the probe chooses the WIRE too -- (torch.float32,
+    torch.bfloat16): same timing per wire; bf16 is taken only when its best form beats fp32's best form by 5 %, agreed on like the form);
+    default: `wire` alone.  The chosen wire is in _PROBED[...]["wire"] / path_wire().
+    A form pinned by hand (configure() / DPRHOT_PATH_COLLECTIVES) is not measured at all -- the other form is never issued.
+    World size 1: nothing to choose.  `preflight(form, wire) -> bool`: the caller's own LOCAL check of a candidate (no collectives in it).
+
+    No rank may leave a form while its peers are still inside it (ADVICE r5 / VERDICT r5 #9): per candidate (form, wire)
+      1. pre-flight, LOCAL: the buffers are allocated and the transport is asked whether it has the form -- the one-sided failures
+         (out of memory on the scratch copy, a communicator without send/recv) happen here, before any collective;
+      2. the ranks AGREE on the pre-flight (all-reduce MIN); a candidate any rank cannot run is abandoned by every rank, unissued;
+      3. ONE trial iteration + synchronise, and the ranks agree again;
+      4. the timed loop -- no try/except: a failure now is raised (loudly, under the caller's watchdog), never swallowed."""
     W, _ = world(group)
     k = _gkey(group)
     if W <= 1 or k in _PROBED:
         return _PROBED.get(k, {"topology": "rccl"})["topology"]
     import time
 
-    dt = torch.bfloat16
-    send = torch.zeros((rows_c, d), dtype=dt, device=device)
-    gathered = torch.empty((W * rows_c, d), dtype=dt, device=device)
-    part = torch.zeros((W * rows_c, d), dtype=wire, device=device)
-    mine = torch.empty((rows_c, d), dtype=wire, device=device)
-    sync = torch.cuda.synchronize if send.is_cuda else (lambda: None)
+    wires = tuple(wires) if wires else (wire,)
+    pinned = path_topology(group) if path_is_pinned() else None
+    forms = (pinned,) if pinned else ("rccl", "allpairs")
+    sync = torch.cuda.synchronize if torch.device(device).type == "cuda" else (lambda: None)
     saved = _CFG["topology"]
     us = {}
     try:
-        for form in ("rccl", "allpairs"):
-            _CFG["topology"] = form
-            try:
-                for it in range(iters + 2):
-                    if it == 2:
-                        sync()
-                        t0 = time.perf_counter()
+        for w in wires:
+            for form in forms:
+                _CFG["topology"] = form
+                bufs, ok = None, True
+                try:  # 1. local pre-flight: nothing collective in here
+                    bufs = (torch.zeros((rows_c, d), dtype=torch.bfloat16, device=device), torch.empty((W * rows_c, d), dtype=torch.bfloat16, device=device),
+                            torch.zeros((W * rows_c, d), dtype=w, device=device), torch.empty((rows_c, d), dtype=w, device=device))
+                    if form == "allpairs":
+                        torch.empty((W * rows_c, d), dtype=w, device=device)  # the exchange's scratch copy must fit too
+                        c = direct_comm(group)
+                        ok = c is None or getattr(c, "has_allpairs", True)
+                    if preflight is not None:  # the caller's own local checks (tests inject a one-sided failure here)
+                        ok = ok and bool(preflight(form, w))
+                except Exception:
+                    ok = False
+                if not _agree(ok, group, device):  # 2.
+                    us[(form, w)] = float("inf")
+                    continue
+                send, gathered, part, mine = bufs
+                err = None
+                try:  # 3. one guarded trial iteration
+                    all_gather_rows(send, gathered, group)
+                    reduce_scatter_rows(part, mine, group)
+                    sync()
+                except Exception as e:
+                    err = e
+                if not _agree(err is None, group, device):
+                    us[(form, w)] = float("inf")
+                    continue
+                for _ in range(2):  # 4. warm-up, then the timed iterations
                     all_gather_rows(send, gathered, group)
                     reduce_scatter_rows(part, mine, group)
                 sync()
-                us[form] = (time.perf_counter() - t0) / iters * 1e6
-            except Exception:
-                us[form] = float("inf")  # (a failure must still reach decide_topology: it is collective)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    all_gather_rows(send, gathered, group)
+                    reduce_scatter_rows(part, mine, group)
+                sync()
+                us[(form, w)] = (time.perf_counter() - t0) / iters * 1e6
+                del bufs, send, gathered, part, mine
     finally:
         _CFG["topology"] = saved
-    topo, agreed = decide_topology(us["rccl"], us["allpairs"], group, device)
-    _PROBED[k] = {"topology": topo, "us": agreed}
+    per_wire = {}
+    for w in wires:
+        if pinned:
+            t = torch.tensor([us[(pinned, w)]], dtype=torch.float64, device=device if device is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            per_wire[w] = (pinned, {pinned: float(t.item())})
+        else:
+            per_wire[w] = decide_topology(us[("rccl", w)], us[("allpairs", w)], group, device)
+    best = {w: min(per_wire[w][1].values()) for w in wires}  # (identical on every rank: decide_topology's all-reduce MAX)
+    chosen = wires[0]
+    if len(wires) > 1:
+        cand = min(wires[1:], key=lambda w: best[w])
+        take = best[cand] < 0.95 * best[wires[0]]  # the narrower wire costs a rounding per partial: it has to win by 5 %
+        if _agree(take, group, device):
+            chosen = cand
+    topo, agreed = per_wire[chosen]
+    _PROBED[k] = {"topology": topo, "us": agreed, "wire": chosen, "pinned": bool(pinned),
+                  "us_by_wire": {str(w).replace("torch.", ""): per_wire[w][1] for w in wires}}
     return topo
+
+
+def path_wire(group=None, default=None):
+    """The dC wire format choose_path_collectives settled on for `group` (None / `default` when it has not run or had one wire only)."""
+    p = _PROBED.get(_gkey(group))
+    return p.get("wire", default) if p else default
 
 
 class _Then:
@@ -367,8 +470,21 @@ def _reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async
         work = dist.all_to_all_single(tmp.view(torch.float16) if bytes_only else tmp, inp.view(torch.float16) if bytes_only else inp,
                                       group=group, async_op=async_op)
 
-        def add_up():  # fixed order, fp32 accumulation (a bf16 wire is rounded once per partial, never inside the sum)
-            torch.sum(tmp.view(W, n, *inp.shape[1:]).float() if tmp.dtype != torch.float32 else tmp.view(W, n, *inp.shape[1:]), dim=0, out=out)
+        def add_up():
+            # fp32 accumulation in rank order r = 0 .. W-1, ONE rounding into out's type: the same arithmetic as the C-ABI form
+            # (dprhot_grad_sum_shards -- on the device it IS that kernel: no W x n x d fp32 copy of a bf16 wire, no run-dependent order)
+            if tmp.is_cuda and tmp.dtype in DirectComm.KINDS and out.dtype in DirectComm.KINDS and out.numel() % 8 == 0 and tmp.is_contiguous() and out.is_contiguous():
+                import ctypes
+
+                from . import _lib
+                _lib.check(_lib.lib.dprhot_grad_sum_shards(tmp.data_ptr(), int(W), out.numel(), DirectComm.KINDS[tmp.dtype], DirectComm.KINDS[out.dtype],
+                                                           out.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "dprhot_grad_sum_shards")
+                return
+            chunks = tmp.view(W, n, *inp.shape[1:])
+            acc = chunks[0].float().clone()
+            for kk in range(1, W):
+                acc += chunks[kk].float()
+            out.copy_(acc)
 
         if async_op:
             return _Then(work, add_up)

@@ -51,10 +51,27 @@ def _fp32_g_mode():
     return os.environ.get("DPRHOT_FP32_G") == "1"
 
 
-def _dc_wire_dtype():
-    """DPRHOT_DC_WIRE=bf16: the reduce-scatter of the dC partials ships bf16 (10.5 MiB per rank at cfg3 instead of 21 MiB,
-    SURVEY.md section 8(d)); the partial sums of the W ranks are then added in bf16 by RCCL.  Default: fp32."""
-    return _BF16 if os.environ.get("DPRHOT_DC_WIRE", "fp32") == "bf16" else torch.float32
+def _dc_wire_dtype(group=None):
+    """The format the dC partials travel in.  DPRHOT_DC_WIRE=bf16: the reduce-scatter ships bf16 (10.5 MiB per rank at cfg3 instead of
+    21 MiB; one more rounding per partial); =fp32: never.  Unset / auto: what dist.choose_path_collectives
+    MEASURED for this group when it was given both wires (DenseRetrieverTask.on_pretrain_routine_start; bf16 only where it won by 5 %),
+    fp32 where no probe ran."""
+    env = os.environ.get("DPRHOT_DC_WIRE", "auto")
+    if env == "bf16":
+        return _BF16
+    if env == "fp32" or group is False:
+        return torch.float32
+    return D.path_wire(group, torch.float32)
+
+
+_ZERO_ROW = {}  # device -> one fp32 zero, never written: `expand`ed it is a gradient of zeros that costs no launch
+
+
+def _zeros_view(shape, device):
+    z = _ZERO_ROW.get(device)
+    if z is None:
+        z = _ZERO_ROW[device] = torch.zeros((1, 1), dtype=torch.float32, device=device)
+    return z.expand(*shape)
 
 
 def _ptr(t):
@@ -452,14 +469,18 @@ class HipKernels:
                                                     _ptr(indices), int(bool(first)), self._stream()), "dprhot_topk_update")
 
     def topk_update_wide(self, S, cols, col_offset, values, indices, first, ws):
-        """Any k (csrc/wideselect.h): state in HBM.  ws: uint8 workspace of dprhot_topk_wide_workspace_bytes(rows, k) bytes; returns the
-        rows (a tensor of indices, usually empty) the library could not update -- their state is unchanged."""
+        """Any k (csrc/wideselect.h): state in HBM.  ws: uint8 workspace of dprhot_topk_wide_workspace_bytes(rows, k) bytes.  No host sync:
+        the ABI reserves word 5 of every row's record as an error word ("keeps its old state"), but no such condition is defined (always 0,
+        include/dprhot.h) -- CorpusSearch.result() checks the words of the LAST call once instead of syncing after every chunk."""
         self._require_gpu(S, values, indices, ws)
         rows, k = values.shape
         self._lib.check(self.lib.dprhot_topk_update_wide(_ptr(S), rows, int(cols), S.stride(0), int(col_offset), k, _ptr(values), _ptr(indices),
                                                          1 if first else 0, _ptr(ws), ws.numel(), self._stream()), "dprhot_topk_update_wide")
-        rec = ws[: rows * 32].view(torch.int32).view(rows, 8)
-        return torch.nonzero(rec[:, 5]).flatten()
+
+    @staticmethod
+    def topk_wide_errors(ws, rows):
+        """The error words of the last dprhot_topk_update_wide call on `ws` (one int32 per row; host sync when inspected)."""
+        return ws[: rows * 32].view(torch.int32).view(rows, 8)[:, 5]
 
     def topk_wide_workspace(self, rows, k, like):
         n = ctypes.c_size_t(0)
@@ -574,7 +595,8 @@ class _DeferContextGrad(torch.autograd.Function):
             w.wait()
         post, ctx.pending.post = ctx.pending.post, None
         if post is not None:
-            post(grad)
+            out = post(grad)  # (may hand on a different tensor: the half-width wire's widened rows)
+            grad = out if out is not None else grad
         return grad, None
 
 
@@ -676,7 +698,7 @@ class InBatchContrastive(torch.autograd.Function):
         used = None
         S_dbg = None
         loss_is_mean = False  # the kernel already multiplied the numerator by 1 / Nq
-        dc_dtype = _dc_wire_dtype() if multi else torch.float32
+        dc_dtype = _dc_wire_dtype(group) if multi else torch.float32
         if not multi and _fp32_g_mode() and wants_grad:
             if q_f32:
                 row_loss, row_lse, loss_sum, G, S_dbg = kn.inbatch_fwd_f32(q, c if c_direct else None, Qb, Cb, pos_idx, y_off, colmask,
@@ -786,7 +808,7 @@ class InBatchContrastive(torch.autograd.Function):
                 # and the reduce-scatter's receive buffer, in one C++ call
                 part = dQ[1] if isinstance(dQ, tuple) else None
                 nxt, dC_part, mine_ready = _OPX.packed_backward(dQ[0] if isinstance(dQ, tuple) else dQ, part, dC_part, go, ctx.used,
-                                                                0 if _dc_wire_dtype() == _BF16 else 2, rows_c, need_dq, need_dc)
+                                                                0 if _dc_wire_dtype(group) == _BF16 else 2, rows_c, need_dq, need_dc)
             else:
                 out2 = kn.rescale_grads(dQ if need_dq else None, dC_part if need_dc else None, go, ctx.used)
                 nxt = out2[1:2]
@@ -836,7 +858,7 @@ class InBatchContrastive(torch.autograd.Function):
                 dc = dC_part[:n_ctx]
                 dc = (dc if go is None else dc * go).to(ctx.in_dtypes[1])
             else:
-                wire = _dc_wire_dtype()
+                wire = _dc_wire_dtype(group)
                 mine = mine_ready if mine_ready is not None else kn.empty((rows_c, d), wire, dC_part)
                 if go is not None:
                     dC_part = dC_part * go  # scale before the collective: nothing is left to do after it
@@ -852,13 +874,15 @@ class InBatchContrastive(torch.autograd.Function):
                     # them stays right) and post() adds the widened rows to whatever arrives instead of overwriting it.
                     ctx.pending.work = D.reduce_scatter_rows(dC_part, mine, group, async_op=True)
                     if widen:
-                        dc = torch.zeros((n_ctx, d), dtype=torch.float32, device=mine.device)  # filled by pending.post, after the wait
+                        # nothing to return yet: a gradient of zeros that costs no launch (one cached zero, expanded).  post() hands
+                        # the widened rows on in its place, or adds them to whatever autograd made of it (zeros + somebody else's term)
+                        dc = _zeros_view((n_ctx, d), mine.device)
 
-                        def post(g, kn=kn, mine=mine, dc=dc):
-                            if g.data_ptr() == dc.data_ptr() and g.shape == dc.shape and g.is_contiguous():
-                                kn.widen(mine, g)
-                            else:
-                                g.add_(kn.widen(mine, torch.empty_like(dc)).to(g.dtype))
+                        def post(g, kn=kn, mine=mine, zptr=dc.data_ptr(), shape=(n_ctx, d)):
+                            if g.data_ptr() == zptr and g.stride() == (0, 0):
+                                return kn.widen(mine, kn.empty(shape, torch.float32, mine))
+                            g.add_(kn.widen(mine, kn.empty(shape, torch.float32, mine)).to(g.dtype))
+                            return g
 
                         ctx.pending.post = post
                     else:
@@ -1144,9 +1168,9 @@ class CorpusSearch:
 
     def _add_wide(self, Cb, first_id):
         """k beyond 4096: the scores come from the MFMA path chunk by chunk (dprhot_sim_fwd), the selection is the library's
-        HBM-resident one (dprhot_topk_update_wide, csrc/wideselect.h: exact radix select over state + chunk, then only the k winners
-        are sorted) -- no torch sort.  A row the library reports back (more than 2048 candidates tied exactly at the k-th score)
-        is folded by _fold_rows_torch below."""
+        HBM-resident one (dprhot_topk_update_wide, csrc/wideselect.h: exact radix select over state + chunk, ties at the k-th score
+        resolved by passage id, then only the k winners are sorted) -- no torch sort, no host sync per chunk.  _fold_rows_torch below is
+        the path of the stand-in kernels only."""
         n, d = Cb.shape
         step = min(self.chunk, 65536)
         if self.wide_ws is None and hasattr(self.kn, "topk_update_wide"):
@@ -1159,12 +1183,7 @@ class CorpusSearch:
                 blk = torch.cat([blk, torch.zeros((pad, d), dtype=_BF16, device=Cb.device)], 0)
             S = self.kn.sim(self.Qb, blk.contiguous(), None, 1.0)
             if self.wide_ws is not None:
-                bad = self.kn.topk_update_wide(S, cols, first_id + j0, self.values, self.indices, self.first, self.wide_ws)
-                if bad.numel() > 0:
-                    if self.first:
-                        self.values[bad] = float("-inf")
-                        self.indices[bad] = -1
-                    self._fold_rows_torch(bad, S[:, :cols], first_id + j0)
+                self.kn.topk_update_wide(S, cols, first_id + j0, self.values, self.indices, self.first, self.wide_ws)
             else:
                 if self.first:
                     self.values.fill_(float("-inf"))
@@ -1213,4 +1232,8 @@ class CorpusSearch:
             self.first = False
 
     def result(self):
+        if self.wide_ws is not None and hasattr(self.kn, "topk_wide_errors"):
+            err = self.kn.topk_wide_errors(self.wide_ws, self.values.shape[0])
+            if bool(err.any()):  # (one sync, where the caller is about to read the result anyway; no condition sets the word today)
+                raise RuntimeError("dprhot_topk_update_wide reported rows it could not update: " + str(torch.nonzero(err).flatten().tolist()[:8]))
         return self.values, self.indices

@@ -86,6 +86,11 @@ class DenseRetrieverTask(LightningModule):
     ):
         super().__init__()
         self.save_hyperparameters()
+        # the two runtime switches the path was measured with, set explicitly here (no longer by `import dpr_scale_amd`); where their
+        # runtime is already up this only warns -- launchers call dpr_scale_amd.configure_runtime() first
+        from .. import configure_runtime
+
+        configure_runtime()
         self.transform_conf = getattr(transform, "text_transform", transform)
         self.model_conf, self.optim_conf = model, optim
         self._datamodule_conf = datamodule  # (only read for the size of a step's messages: _path_message_shape)
@@ -102,9 +107,10 @@ class DenseRetrieverTask(LightningModule):
         self.setup_done = False
         # multi-GPU step: contexts first (collectives hidden under the query tower) unless the reference's order
         # is asked for (dropout RNG stream identical to the reference's, see training_step)
-        # DPRHOT_TOWER_ORDER = context_first | reference | auto (default): see _tower_order()
+        # DPRHOT_TOWER_ORDER = context_first (default) | reference | auto (the timing trial, opt-in): see _tower_order()
         self.context_tower_first = os.environ.get("DPRHOT_TOWER_ORDER", "") != "reference"
         self._order_trial = None
+        self.path_probe = None  # what on_pretrain_routine_start measured for the path's collectives (saved with the checkpoint)
 
     # ---- model construction / checkpoints (reference :55-92) -------------------------------------------
     def setup(self, stage: str):
@@ -141,10 +147,27 @@ class DenseRetrieverTask(LightningModule):
                 # which FORM of the path's two collectives on this node -- RCCL's own (rings) or the direct all-pairs exchange -- is
                 # measured once, here, at the step's message sizes, and agreed on by all ranks (dist.choose_path_collectives;
                 # DPRHOT_PATH_COLLECTIVES=rccl|allpairs pins it, DPRHOT_PATH_PROBE=0 skips the probe and keeps RCCL's)
-                if os.environ.get("DPRHOT_PATH_PROBE", "1") != "0" and hotpath.D.world(None)[0] > 1:
+                # Round 6: the probe also chooses the dC WIRE (fp32 or bf16; bf16 only where its best form wins by 5 %) unless
+                # DPRHOT_DC_WIRE names one or the run asked for reproducibility (_wants_reproducible: a format picked by a stopwatch
+                # is not reproducible); a form pinned by hand is not measured at all; every candidate is agreed on by all ranks before
+                # and after its first iteration, and the whole probe runs under a watchdog (DPRHOT_PROBE_TIMEOUT_S, default 300 s: a
+                # probe that does not come back ends the process with a message instead of a silent hang).
+                D = hotpath.D
+                if os.environ.get("DPRHOT_PATH_PROBE", "1") != "0" and D.world(None)[0] > 1:
                     rows_c, d = self._path_message_shape()
-                    wire = torch.bfloat16 if os.environ.get("DPRHOT_DC_WIRE", "fp32") == "bf16" else torch.float32
-                    self.path_collectives = hotpath.D.choose_path_collectives(dev, rows_c, d, wire=wire)
+                    env_wire = os.environ.get("DPRHOT_DC_WIRE", "auto")
+                    if env_wire in ("bf16", "fp32") or self._wants_reproducible():
+                        wires = (torch.bfloat16 if env_wire == "bf16" else torch.float32,)
+                    else:
+                        wires = (torch.float32, torch.bfloat16)
+                    if not (D.path_is_pinned() and len(wires) == 1):
+                        with D.probe_watchdog(float(os.environ.get("DPRHOT_PROBE_TIMEOUT_S", "300")), "dpr_scale_amd: the probe of the path's collectives"):
+                            self.path_collectives = D.choose_path_collectives(dev, rows_c, d, wires=wires)
+                        rec = D._PROBED.get(D._gkey(None))
+                        if rec is not None:
+                            self.path_probe = {"topology": rec["topology"], "wire": str(rec.get("wire")).replace("torch.", ""), "us": rec.get("us_by_wire")}
+                            if getattr(self, "global_rank", 0) == 0:
+                                print(f"dpr_scale_amd: collectives of the contrastive path: {self.path_probe}", flush=True)
         if self.fp16_grads:
             from .. import comm_hooks
 
@@ -231,49 +254,63 @@ class DenseRetrieverTask(LightningModule):
     def _is_distributed(self):
         return isinstance(getattr(self.trainer, "strategy", None), (DDPStrategy, DDPShardedStrategy))
 
-    # The order of the two towers in the multi-GPU step is MEASURED, not assumed (DPRHOT_TOWER_ORDER=auto, the default).
-    #   context_first  the context tower's rows go into the one all-gather, which runs underneath the query tower; in backward the
-    #                  reduce-scatter of dC runs underneath the query-tower backward (hotpath.ContextGather / defer_context_grad).
-    #   reference      the reference's order (dpr_task.py:94-101: query tower, context tower); both collectives run exposed.
+    # The order of the two towers in the multi-GPU step.
+    #   context_first  (default) the context tower's rows go into the one all-gather, which runs underneath the query tower; in backward
+    #                  the reduce-scatter of dC runs underneath the query-tower backward (hotpath.ContextGather / defer_context_grad).
+    #   reference      the reference's order (dpr_task.py:94-101: query tower, context tower); both collectives run exposed; dropout
+    #                  masks are drawn in the reference's sequence (seed-for-seed comparison).
+    #   auto           OPT-IN (DPRHOT_TOWER_ORDER=auto): the first steps time both orders and training continues in the faster one.
     # Hiding the collectives is not free: autograd runs the NEWEST tower's backward first, so context_first puts the SMALL tower's
     # backward (B rows, ~700 launches of ~10 us) right behind the loss, where nothing is queued ahead of it -- the GPU outruns the host's
     # launches and idles (profiles/r05_forced_dist_breakdown.json: +0.9...1.3 ms of device idle per step at B = 32 on one MI355X, with
-    # NO collective involved: the same operator single-device, context tower first, shows it) -- whereas in the reference's order the
-    # big tower's backward goes first and the small one's launches queue up behind it.  Which effect is larger depends on the host, the
-    # batch and the node's links; so the first steps time both orders with HIP events (no host sync), the ranks agree on the faster
-    # one (all-reduce MAX of the medians; ties keep context_first) and training continues in it.
+    # NO collective involved) -- whereas in the reference's order the big tower's backward goes first and the small one's launches
+    # queue up behind it.  Which effect is larger depends on the host, the batch and the node's links: hence the trial.
+    # Round 6: the trial is no longer the default -- the two orders draw dropout masks in a different sequence, so a run
+    # whose first steps alternate them and whose final order depends on a stopwatch is not reproducible from its seed, which the
+    # reference is; it is also refused when the run asked for reproducibility (_wants_reproducible).  When it does run, the orders
+    # alternate per ACCUMULATION CYCLE (accumulate_grad_batches steps), so that each order meets the optimizer / DDP-sync step equally
+    # often, and the decision is stored with the checkpoint (on_save_checkpoint: "dprhot_runtime").
     _TRIAL_WARM, _TRIAL_N = 3, 5
+
+    def _wants_reproducible(self):
+        """The run asked for seed-for-seed reproducibility: deterministic algorithms switched on, or Lightning's seed_everything
+        (PL_GLOBAL_SEED) / Trainer(deterministic=True)."""
+        if torch.are_deterministic_algorithms_enabled() or os.environ.get("PL_GLOBAL_SEED"):
+            return True
+        return bool(getattr(getattr(self, "trainer", None), "deterministic", False))
 
     def _tower_order(self):
         if not self.context_tower_first:
             return "reference"
-        mode = os.environ.get("DPRHOT_TOWER_ORDER", "auto")
-        if mode != "auto" or not torch.cuda.is_available():
+        mode = os.environ.get("DPRHOT_TOWER_ORDER", "context_first")
+        if mode != "auto" or not torch.cuda.is_available() or self._wants_reproducible():
             return "context_first"
         tr = self._order_trial
         if tr is None:
-            tr = self._order_trial = {"step": 0, "events": [], "decided": None, "ms": None}
+            acc = int(getattr(getattr(self, "trainer", None), "accumulate_grad_batches", 1) or 1)
+            tr = self._order_trial = {"step": 0, "events": [], "decided": None, "ms": None, "acc": max(1, acc)}
         if tr["decided"] is not None:
             return tr["decided"]
-        i, W0, N = tr["step"], self._TRIAL_WARM, self._TRIAL_N
+        i, N, acc = tr["step"], self._TRIAL_N, tr["acc"]
+        W0 = -(-self._TRIAL_WARM // acc) * acc  # whole accumulation cycles of warm-up
         tr["step"] += 1
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         tr["events"].append(ev)
         if i < W0:
             return "context_first"
-        if i < W0 + 2 * N + 1:
-            # the two orders ALTERNATE step by step (clocks and caches drift over the first steps of a run: two blocks of steps would
-            # time the drift); step j's interval runs from its start event to the next step's
-            return "context_first" if (i - W0) % 2 == 0 else "reference"
+        if i < W0 + 2 * N * acc + 1:
+            # the two orders ALTERNATE cycle by cycle (clocks and caches drift over the first steps of a run: two blocks of cycles would
+            # time the drift); cycle j's interval runs from the start event of its first step to that of the next cycle's first step
+            return "context_first" if ((i - W0) // acc) % 2 == 0 else "reference"
         evs = tr["events"]
-        evs[W0 + 2 * N].synchronize()  # (recorded a whole step ago: complete)
+        evs[W0 + 2 * N * acc].synchronize()  # (recorded a whole step ago: complete)
 
         def med(first):
-            ts = sorted(evs[j].elapsed_time(evs[j + 1]) for j in range(first, W0 + 2 * N, 2))
+            ts = sorted(evs[W0 + j * acc].elapsed_time(evs[W0 + (j + 1) * acc]) / acc for j in range(first, 2 * N, 2))
             return 0.5 * (ts[(len(ts) - 1) // 2] + ts[len(ts) // 2])
 
-        t = torch.tensor([med(W0), med(W0 + 1)], dtype=torch.float64, device=evs[0].device if hasattr(evs[0], "device") else "cuda")
+        t = torch.tensor([med(0), med(1)], dtype=torch.float64, device="cuda")
         if hotpath.D.world(None)[0] > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         a_ms, b_ms = t.tolist()
@@ -284,6 +321,14 @@ class DenseRetrieverTask(LightningModule):
             print(f"dpr_scale_amd: tower order of the multi-GPU step: {tr['decided']} (context first {a_ms:.2f} ms / step, reference order {b_ms:.2f} ms / step)",
                   flush=True)
         return tr["decided"]
+
+    def on_save_checkpoint(self, checkpoint) -> None:
+        """What this run measured and decided at start-up rides with the checkpoint (an extra key: the reference's layout -- state_dict,
+        hyper_parameters -- is untouched): the tower order (fixed, or the trial's decision and its timings) and the probe of the path's
+        collectives (form, wire)."""
+        tr = self._order_trial or {}
+        checkpoint["dprhot_runtime"] = {"tower_order": tr.get("decided") or ("context_first" if self.context_tower_first else "reference"),
+                                        "tower_order_trial_ms": tr.get("ms"), "path_collectives": self.path_probe}
 
     def training_step(self, batch, batch_idx):
         pos, mask = batch["pos_ctx_indices"], batch["ctx_mask"]

@@ -5,7 +5,7 @@ import sys
 
 sys.path.insert(0, '.')
 import torch
-import bench
+import bench_blocks as bench
 from dpr_scale_amd import _lib
 
 dev = torch.device('cuda', 0)

@@ -48,6 +48,9 @@ def main():
     from dpr_scale_amd.hydra_compat import Conf
     from dpr_scale_amd.task.dpr_task import DenseRetrieverTask
 
+    import dpr_scale_amd
+
+    dpr_scale_amd.configure_runtime()  # before the first HIP call (kernel arguments on the device) and before the process group exists
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)

@@ -147,8 +147,11 @@ def test_multi_rank_operator_host_side_in_cpp_equals_the_python_one_and_all_pair
 
 
 def test_tower_order_of_the_multi_gpu_step_is_measured_and_settles():
-    """DenseRetrieverTask._tower_order (DPRHOT_TOWER_ORDER=auto, the default): over the first 14 steps of the multi-GPU branch the two
-    orders of the towers alternate, timed with HIP events; then the step settles on one of them and stays there."""
+    """DenseRetrieverTask._tower_order.  Default: a FIXED order (context_first: the collectives under the query tower), no trial -- a
+    seeded run is reproducible.  DPRHOT_TOWER_ORDER=auto (opt-in): over the first 14 steps of the multi-GPU branch the two
+    orders of the towers alternate, timed with HIP events; then the step settles on one of them and stays there; with
+    accumulate_grad_batches = 2 the orders alternate per accumulation cycle; a run that asked for reproducibility refuses the trial;
+    the decision rides with the checkpoint."""
     import torch.distributed as dist
 
     from dpr_scale_amd import lightning_compat
@@ -161,6 +164,7 @@ def test_tower_order_of_the_multi_gpu_step_is_measured_and_settles():
     os.environ["MASTER_PORT"] = "29745"
     os.environ["DPRHOT_FORCE_DIST"] = "1"
     os.environ.pop("DPRHOT_TOWER_ORDER", None)
+    os.environ.pop("PL_GLOBAL_SEED", None)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         cfg = {"vocab_size": 1000, "hidden_size": 128, "num_hidden_layers": 2, "num_attention_heads": 2, "intermediate_size": 256,
@@ -180,6 +184,12 @@ def test_tower_order_of_the_multi_gpu_step_is_measured_and_settles():
 
         batch = {"query_ids": tok(B), "contexts_ids": tok(B * K), "pos_ctx_indices": (torch.arange(B) * K).to(dev),
                  "ctx_mask": torch.zeros(B * K, dtype=torch.bool, device=dev)}
+        # default: fixed order, no trial state, nothing timed
+        assert [task._tower_order() for _ in range(4)] == ["context_first"] * 4 and task._order_trial is None
+        os.environ["DPRHOT_TOWER_ORDER"] = "auto"
+        os.environ["PL_GLOBAL_SEED"] = "7"  # seed_everything was called: the trial is refused
+        assert task._tower_order() == "context_first" and task._order_trial is None
+        os.environ.pop("PL_GLOBAL_SEED")
         orders, losses = [], []
         real = task._tower_order
 
@@ -199,6 +209,26 @@ def test_tower_order_of_the_multi_gpu_step_is_measured_and_settles():
         assert orders[:3] == ["context_first"] * 3 and orders[3:14] == ["context_first", "reference"] * 5 + ["context_first"]
         assert orders[14:] == [tr["decided"]] * 6
         assert all(abs(x - losses[0]) <= 1e-4 * max(1.0, abs(losses[0])) for x in losses)  # (dropout 0: the order changes nothing else)
+        ck = {}
+        task.on_save_checkpoint(ck)
+        assert ck["dprhot_runtime"]["tower_order"] == tr["decided"] and ck["dprhot_runtime"]["tower_order_trial_ms"] == tr["ms"]
+        # accumulate_grad_batches = 2: whole cycles of warm-up (4 steps), then the orders alternate cycle by cycle
+        task._order_trial = None
+        task.trainer.accumulate_grad_batches = 2
+        seq = []
+
+        def spy2():
+            o = real()
+            seq.append(o)
+            return o
+
+        task._tower_order = spy2
+        for _ in range(28):
+            task.training_step(batch, 0).backward()
+            task.zero_grad(set_to_none=True)
+        assert seq[:4] == ["context_first"] * 4 and seq[4:24] == (["context_first"] * 2 + ["reference"] * 2) * 5 and seq[24] == "context_first"
+        assert seq[25:] == [task._order_trial["decided"]] * 3
     finally:
         os.environ.pop("DPRHOT_FORCE_DIST", None)
+        os.environ.pop("DPRHOT_TOWER_ORDER", None)
         dist.destroy_process_group()

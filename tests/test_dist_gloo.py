@@ -323,3 +323,83 @@ def test_topology_probe_agrees_across_ranks():
     for r in range(W):
         assert res[r]["registered"] == res[r]["probe"] == res[r]["back"] and res[r]["override"] != res[r]["probe"]
         assert res[r]["gather_ok"] and res[r]["scatter_ok"]
+
+
+def _probe2_worker(rank, W, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("DPRHOT_PATH_COLLECTIVES", None)
+    dist.init_process_group("gloo", rank=rank, world_size=W)
+    from dpr_scale_amd import dist as D
+
+    issued = {"a2a": 0}
+    real_a2a = dist.all_to_all_single
+
+    def counting(*a, **k):
+        issued["a2a"] += 1
+        return real_a2a(*a, **k)
+
+    dist.all_to_all_single = counting
+    res = {}
+    cpu = torch.device("cpu")
+    # (a) a candidate ONE rank cannot run (its local pre-flight fails there) is abandoned by EVERY rank before anybody issues one of its
+    #     collectives: no all-to-all leaves any rank, the form arrives as inf and loses, the ranks agree
+    topo = D.choose_path_collectives(cpu, 16, 32, iters=2, preflight=lambda form, w: not (form == "allpairs" and rank == W - 1))
+    rec = D._PROBED[D._gkey(None)]
+    res["a"] = (topo, issued["a2a"], rec["us"]["allpairs"] == float("inf"), rec["us"]["rccl"] < float("inf"))
+    # (c) the probe chooses the WIRE too: both wires timed in both forms, one answer on every rank
+    D._PROBED.clear()
+    issued["a2a"] = 0
+    topo = D.choose_path_collectives(cpu, 16, 32, iters=2, wires=(torch.float32, torch.bfloat16))
+    rec = D._PROBED[D._gkey(None)]
+    res["c"] = (topo, str(D.path_wire()), sorted(rec["us_by_wire"]), issued["a2a"] > 0)
+    # (d) a form pinned by hand is not measured: the other form is never issued
+    D._PROBED.clear()
+    issued["a2a"] = 0
+    D.configure(topology="rccl")
+    topo = D.choose_path_collectives(cpu, 16, 32, iters=2)
+    res["d"] = (topo, issued["a2a"], D._PROBED[D._gkey(None)]["pinned"])
+    D.configure(None, None)
+    # (b) the all-pairs reduce-scatter adds the W received chunks in fp32 in RANK ORDER, one rounding at the end -- bit for bit, on a
+    #     bf16 wire too (what dprhot_grad_sum_shards does on the device; test_direct_comm.py holds the device-side equality)
+    D._PROBED.clear()
+    D.configure(topology="allpairs")
+    g = torch.Generator().manual_seed(100 + rank)
+    for wire in (torch.float32, torch.bfloat16):
+        part = (torch.randn(W * 8, 16, generator=g) * 3).to(wire)
+        mine = torch.empty((8, 16), dtype=wire)
+        D.reduce_scatter_rows(part, mine)
+        allp = [torch.empty_like(part) for _ in range(W)]
+        half = wire == torch.bfloat16  # (gloo moves no bf16: the bit patterns travel as fp16)
+        dist.all_gather([t.view(torch.float16) if half else t for t in allp], part.view(torch.float16) if half else part)
+        acc = allp[0][rank * 8:(rank + 1) * 8].float().clone()
+        for k in range(1, W):
+            acc += allp[k][rank * 8:(rank + 1) * 8].float()
+        res["b_" + str(wire)] = bool(torch.equal(mine, acc.to(wire)))
+    D.configure(None, None)
+    dist.all_to_all_single = real_a2a
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,port", [(2, 29761), (4, 29762)])
+def test_probe_abandons_a_form_together_chooses_the_wire_and_skips_pinned_forms(W, port):
+    """VERDICT r5 #5 / ADVICE r5 (dist.choose_path_collectives): (a) no rank leaves a form while its peers are inside it -- a one-sided
+    pre-flight failure is agreed on BEFORE any collective of that form is issued; (b) the torch.distributed all-pairs reduce-scatter is the
+    rank-order fp32 sum the C-ABI form computes; (c) the probe chooses the dC wire as well; (d) a pinned form is not measured."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_probe2_worker, args=(r, W, port, q)) for r in range(W)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(W))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(W):
+        assert res[r]["a"] == ("rccl", 0, True, True), res[r]["a"]
+        assert res[r]["c"][:3] == res[0]["c"][:3] and res[r]["c"][1] in ("torch.float32", "torch.bfloat16") and res[r]["c"][3]
+        assert res[r]["c"][2] == ["bfloat16", "float32"]
+        assert res[r]["d"] == ("rccl", 0, True)
+        assert res[r]["b_torch.float32"] and res[r]["b_torch.bfloat16"]
