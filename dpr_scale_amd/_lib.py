@@ -96,6 +96,7 @@ SIGNATURES = {
     "dprhot_reducescatter_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "dprhot_allreduce_sum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_allgather_allpairs": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dprhot_comm_has_allpairs": (c_int, [c_void_p]),
     "dprhot_reducescatter_allpairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "dprhot_inbatch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1955,6 +1955,11 @@ int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream) {
 // ---- the same two collectives as direct all-pairs exchanges (SURVEY.md section 8(e) "Topology") ---------------------------------
 // One RCCL group of W sends and W receives (the self pair included: a device copy): every peer's transfer is its own point-to-point
 // operation, so on the fully connected node the W - 1 transfers of a rank travel over W - 1 different xGMI links at once.
+int dprhot_comm_has_allpairs(void* h) {
+  REQUIRE(h != nullptr, "bad argument");
+  return rccl().p2p ? 1 : 0;
+}
+
 int dprhot_allgather_allpairs(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream) {
   REQUIRE(h && send && recv && bytes_per_rank > 0, "bad argument");
   if (!rccl().p2p) return fail(DPRHOT_E_UNSUPPORTED, "ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd not found in this process's librccl.so");

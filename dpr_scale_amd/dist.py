@@ -428,7 +428,7 @@ def _all_gather_rows(send: torch.Tensor, out: torch.Tensor, group=None, async_op
     assert out.shape[0] == W * send.shape[0], (out.shape, send.shape, W)
     comm = direct_comm(group)
     if comm is not None and send.is_cuda:
-        fn = (lambda: comm.all_gather_allpairs(send, out)) if _allpairs(group) else (lambda: comm.all_gather_rows(send, out))
+        fn = (lambda: comm.all_gather_allpairs(send, out)) if (_allpairs(group) and comm.has_allpairs) else (lambda: comm.all_gather_rows(send, out))
         if async_op:
             return _on_side_stream(fn, send, out)
         fn()
@@ -451,9 +451,10 @@ def _reduce_scatter_rows(inp: torch.Tensor, out: torch.Tensor, group=None, async
     n = out.shape[0]
     assert inp.shape[0] == W * n
     comm = direct_comm(group)
-    if comm is not None and inp.is_cuda and inp.dtype in comm.KINDS and (inp.dtype == out.dtype or (_allpairs(group) and out.dtype == torch.float32)) \
-            and (not _allpairs(group) or out.numel() % 8 == 0):
-        if _allpairs(group):
+    ap_comm = _allpairs(group) and comm is not None and comm.has_allpairs
+    if comm is not None and inp.is_cuda and inp.dtype in comm.KINDS and (inp.dtype == out.dtype or (ap_comm and out.dtype == torch.float32)) \
+            and (not ap_comm or out.numel() % 8 == 0):
+        if ap_comm:
             tmp = torch.empty_like(inp)  # chunk k: what rank k computed for MY columns (summed in fp32, rank order, by the library)
             fn = lambda: comm.reduce_scatter_allpairs(inp, tmp, out)  # noqa: E731
             tensors = (inp, tmp, out)
@@ -520,6 +521,7 @@ class DirectComm:
         from . import _lib
 
         self._lib, self.W, self.rank = _lib, world_size, rank
+        self.has_allpairs = True  # try_direct_comm's self-check turns it off, on every rank alike, where the exchanges do not work
         h = ctypes.c_void_p()
         _lib.check(_lib.lib.dprhot_comm_init(unique_id, world_size, rank, ctypes.byref(h)), "dprhot_comm_init")
         self.h = h
@@ -616,27 +618,28 @@ def try_direct_comm(device, group=None, alive=None, handshake=None):
         if comm is not None:
             comm.close()
         return None
-    # self-check against torch.distributed: a small case, then the message sizes of a cfg3 step (1032 packed rows x 768), both forms
-    good = True
+    # self-check against torch.distributed: a small case, then the message sizes of a cfg3 step (1032 packed rows x 768).  RCCL's own
+    # collectives decide whether there is a communicator at all; the all-pairs exchanges (ncclSend / ncclRecv groups) are checked
+    # SEPARATELY and only decide whether THIS communicator offers that form (a library without send/recv is "no all-pairs",
+    # not "no communicator") -- each verdict agreed on by all ranks.
+    good, good_ap = True, True
+    cases = []
     try:
         g = torch.Generator(device="cpu").manual_seed(77 + r)
         for rows, cols in ((24, 16), (1032, 768)):
             if not alive():
                 break
             send = torch.randn(rows, cols, generator=g).to(device).to(torch.bfloat16)
-            a, a2, b = (torch.empty((W * rows, cols), dtype=torch.bfloat16, device=device) for _ in range(3))
+            a, b = (torch.empty((W * rows, cols), dtype=torch.bfloat16, device=device) for _ in range(2))
             comm.all_gather_rows(send, a)
-            comm.all_gather_allpairs(send, a2)
             dist.all_gather_into_tensor(b, send, group=hs)
             part = torch.randn(W * rows, cols, generator=g).to(device)
-            m1, m2, m3 = (torch.empty((rows, cols), device=device) for _ in range(3))
-            tmp = torch.empty_like(part)
+            m1, m2 = (torch.empty((rows, cols), device=device) for _ in range(2))
             comm.reduce_scatter_rows(part, m1)
-            comm.reduce_scatter_allpairs(part, tmp, m3)
             dist.reduce_scatter_tensor(m2, part, op=dist.ReduceOp.SUM, group=hs)
             torch.cuda.synchronize()
-            good = good and bool(torch.equal(a, b)) and bool(torch.equal(a2, b)) and bool(torch.allclose(m1, m2, rtol=1e-5, atol=1e-5)) \
-                and bool(torch.allclose(m3, m2, rtol=1e-5, atol=1e-5))
+            good = good and bool(torch.equal(a, b)) and bool(torch.allclose(m1, m2, rtol=1e-5, atol=1e-5))
+            cases.append((send, b, part, m2))
         s1 = torch.full((1,), float(r + 1), device=device)
         comm.all_reduce_sum(s1)
         torch.cuda.synchronize()
@@ -644,6 +647,32 @@ def try_direct_comm(device, group=None, alive=None, handshake=None):
     except Exception:
         good = False
     if not all_ok(good):
+        comm.close()
+        return None
+    # (a local pre-flight first: a rank whose library lacks the entry points must say so BEFORE its peers enter a send/recv group)
+    try:
+        from . import _lib
+
+        pre = bool(_lib.lib.dprhot_comm_has_allpairs(comm.h)) if hasattr(_lib.lib, "dprhot_comm_has_allpairs") else True
+    except Exception:
+        pre = False
+    if all_ok(pre):
+        try:
+            for send, b, part, m2 in cases:
+                if not alive():
+                    break
+                a2 = torch.empty_like(b)
+                comm.all_gather_allpairs(send, a2)
+                tmp, m3 = torch.empty_like(part), torch.empty_like(m2)
+                comm.reduce_scatter_allpairs(part, tmp, m3)
+                torch.cuda.synchronize()
+                good_ap = good_ap and bool(torch.equal(a2, b)) and bool(torch.allclose(m3, m2, rtol=1e-5, atol=1e-5))
+        except Exception:
+            good_ap = False
+        comm.has_allpairs = all_ok(good_ap)
+    else:
+        comm.has_allpairs = False
+    if not alive():
         comm.close()
         return None
     return comm

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 170 /* 0.1.70: + dprhot_allgather_allpairs / dprhot_reducescatter_allpairs (the path's collectives as direct all-pairs exchanges) */
+#define DPRHOT_VERSION 171 /* 0.1.71: + dprhot_comm_has_allpairs (local pre-flight of the all-pairs exchanges); option sk_dq_atomic */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -346,6 +346,9 @@ int dprhot_grad_unpack(const void* full, int kind, float* bucket, size_t n, void
  *                                  land in tmp [W * count_per_rank] (caller-owned, storage kind `kind`), then ONE kernel adds them in
  *                                  fp32 in rank order (deterministic; a half-width wire is rounded once per partial, never inside the
  *                                  sum) into recv, stored as `out_kind` (= kind, or 2 for fp32)
+ *   dprhot_comm_has_allpairs       LOCAL, no communication: 1 when this process's RCCL has ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd
+ *                                  (the two all-pairs entry points would run), 0 when not -- what a rank checks BEFORE its peers enter a
+ *                                  send / receive group (dist.try_direct_comm, dist.choose_path_collectives)
  * One communicator per rank process, used from one thread; every rank issues the same calls in the same order. */
 int dprhot_comm_unique_id(void* id128);
 int dprhot_comm_init(const void* id128, int W, int rank, void** h);
@@ -356,6 +359,7 @@ int dprhot_reducescatter_rows(void* h, const void* send, void* recv, size_t coun
 int dprhot_allreduce_sum(void* h, float* buf, size_t count, void* stream);
 int dprhot_allgather_allpairs(void* h, const void* send, void* recv, size_t bytes_per_rank, void* stream);
 int dprhot_reducescatter_allpairs(void* h, const void* send, void* tmp, void* recv, size_t count_per_rank, int kind, int out_kind, void* stream);
+int dprhot_comm_has_allpairs(void* h);
 
 #ifdef __cplusplus
 }
