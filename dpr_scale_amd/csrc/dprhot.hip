@@ -126,7 +126,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -156,6 +156,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
     {"sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
     {"g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
+    {"nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
 };
 long long g_opt_epoch = 0;  // bumped by every dprhot_set_option: host-side caches of plan facts key on it (dprhot_options_epoch)
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
@@ -258,7 +259,7 @@ int launch_g8(const GemmArgs& a, const Epi& epi, hipStream_t st) {
     attr_done = true;
   }
   const int nbx = cdiv(a.N, G2_B), nby = cdiv(a.M, G2_B);
-  const bool stores_tile = std::is_same<Epi, Epi8G>::value || std::is_same<Epi, Epi8Store>::value;
+  const bool stores_tile = std::is_same<Epi, Epi8G>::value || std::is_same<Epi, Epi8Store>::value || std::is_same<Epi, Epi8StatsP>::value;
   const int grid = (nbx * nby < kNumCU || (stores_tile && opt(OPT_G8_ONE_TILE) != 0)) ? nbx * nby : kNumCU;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G2_THREADS), g8_lds_total, st, a, epi, nbx, nby);
   HIP_TRY(hipGetLastError());
@@ -1404,6 +1405,33 @@ int dprhot_sim_rank_loss(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int 
 int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
                        const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss, float* row_lse,
                        float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
+  if (S_out == nullptr && G != nullptr && nl_ok(B, Nc, d) && opt(OPT_NL_P16) != 0) {
+    // no-logits forward in ONE pass of the GEMM (round 6): strip statistics + fp16 softmax numerators into the G buffer (Epi8StatsP),
+    // then one row kernel: logsumexp / loss, and the numerators rescaled into the bf16 dScores in place
+    REQUIRE(Q && C && y && loss_sum, "NULL pointer");
+    if (int rc = check_shape(B, Nc, d)) return rc;
+    REQUIRE(aligned16(Q) && aligned16(C) && aligned16(G), "pointers must be 16-byte aligned");
+    const WsLayout wl = ws_layout(B, Nc, d);
+    if (workspace == nullptr || workspace_bytes < wl.total)
+      return fail(DPRHOT_E_WORKSPACE, "inbatch_fwd needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+    REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    Epi8StatsP epi;
+    static_cast<Epi8Base&>(epi) = g8_base(Q, B, Nc, y, y_offset, colmask, inv_T, reinterpret_cast<float*>(ws + wl.gold));
+    epi.part_m = reinterpret_cast<float*>(ws + wl.part_m);
+    epi.part_s = reinterpret_cast<float*>(ws + wl.part_s);
+    epi.npart = cdiv(Nc, G2_B) * 4;
+    epi.P = G;
+    GemmArgs a8{Q, C, B, Nc, d, d, d, d};
+    if (int rc = (opt(OPT_NL_P16) == 2 ? launch_g8<Epi8StatsP, 4>(a8, epi, st) : launch_g8<Epi8StatsP, 2>(a8, epi, st))) return rc;
+    hipLaunchKernelGGL(g8_lse_p2g_kernel, dim3((unsigned)B), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart,
+                       reinterpret_cast<const float*>(ws + wl.gold), B, Nc, y, y_offset, grad_scale, reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss,
+                       reinterpret_cast<float*>(ws + wl.rloss), G);
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum);
+    HIP_TRY(hipGetLastError());
+    return DPRHOT_OK;
+  }
   if (S_out == nullptr && nl_ok(B, Nc, d)) {
     // no-logits forward: statistics pass -> logsumexp / loss -> dScores pass (logits recomputed); S is never in memory
     if (int rc = dprhot_sim_stats(Q, B, C, Nc, d, y, y_offset, colmask, inv_T, nullptr, workspace, workspace_bytes, stream)) return rc;

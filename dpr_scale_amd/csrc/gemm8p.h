@@ -564,6 +564,100 @@ struct Epi8Stats : Epi8Base {
   }
 };
 
+// Training forward WITH the dScores wanted, in ONE pass of the GEMM (round 6): Epi8Stats' strip statistics, and the tile's own
+// softmax numerators P = exp(S - strip max) leave the tile as fp16 (2 bytes per score, into the buffer that will hold G).  The row
+// kernel g8_lse_p2g_kernel then derives the row logsumexp from the strip statistics and rescales the row IN PLACE:
+//     G_ij = (P_ij * exp(strip max - lse_i) - onehot) * grad_scale  -> bf16.
+// One GEMM pass + one streaming pass (4 bytes per score) instead of two GEMM passes (Epi8Stats, then Epi8G recomputing every logit):
+// 8192^2 x 768: ~115 + ~50 us against 101 + 111.  fp16, not bf16, and scaled by 2^14: every strip holds a 1.0 (its maximum), so the
+// numerators live in (0, 2^14] -- 11 significant bits down to 2^-14 * 2^14 = 1 ... i.e. relative 2^-12 down to 6e-5 * 2^-14 = 3.7e-9 of
+// the strip maximum, absolute 2^-38 below that: the ONE rounding that matters stays G's own bf16 rounding, as in Epi8G.
+constexpr float kG8PScale = 16384.f, kG8PInvScale = 1.f / 16384.f;
+typedef _Float16 g8_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned g8_cvt_pk_f16(float a, float b) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+  g8_h2 v;
+  v[0] = (_Float16)a;
+  v[1] = (_Float16)b;
+  return __builtin_bit_cast(unsigned, v);
+}
+struct Epi8StatsP : Epi8Stats {
+  uint16_t* P;  // [M][N] fp16 bit patterns
+  __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
+    meta_fix(t);
+    const int i = t.lane & 31, h = t.lane >> 5;
+    float madd[8][4];
+    col_madd(t, madd);
+    const bool anygold = sim.y != nullptr && tile_has_gold(t);
+    const float s2 = sim.inv_T * kG8Log2e;
+    const f32x2 s2v = {s2, s2};
+    const f32x2 psc = {kG8PScale, kG8PScale};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x2 v[8][2];  // log2 units
+      float mx = -INFINITY;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x2 x = {acc.v[a][b][q * 4 + u * 2], acc.v[a][b][q * 4 + u * 2 + 1]};
+            const f32x2 md = {madd[b * 4 + q][u * 2], madd[b * 4 + q][u * 2 + 1]};
+            v[b * 4 + q][u] = x * s2v + md;
+            mx = fmaxf(mx, fmaxf(v[b * 4 + q][u][0], v[b * 4 + q][u][1]));
+          }
+      mx = g8_max_x32(mx);
+      const float mref = mx == -INFINITY ? 0.f : mx;
+      const f32x2 mr = {mref, mref};
+      f32x2 sm2 = {0.f, 0.f};
+      const int m = t.m0 + t.wm * 128 + a * 32 + i;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        unsigned pk[4][2];  // run q: two dwords = 4 fp16 = columns q*8 + h*4 ..
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x2 d = v[b * 4 + q][u] - mr;
+            const f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};  // exp2(-inf) == 0 at masked columns
+            sm2 += e;  // (same values, same order as Epi8Stats: the statistics of the two plans are bit-identical)
+            const f32x2 es = e * psc;
+            pk[q][u] = g8_cvt_pk_f16(es[0], es[1]);
+          }
+        // lanes i and i + 32 trade half-runs: every lane stores whole 16-byte runs (Epi8G, guide T21)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+          const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+          const int n = t.n0 + t.wn * 64 + b * 32 + (2 * pr + h) * 8;
+          if (m < sim.M && n < sim.N) *reinterpret_cast<uint4*>(P + (size_t)m * sim.N + n) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+        }
+      }
+      const float sm = g8_sum_x32(sm2[0] + sm2[1]);
+      if (h == 0 && m < sim.M) {
+        const size_t at = (size_t)m * npart + t.bx * (t.ncol >> 6) + t.wn;
+        part_m[at] = mx * kG8Ln2;
+        part_s[at] = sm;
+      }
+      if (anygold) {
+        const int yi = g8_lds_read(t.meta + 256 + t.wm * 128 + a * 32 + i);
+        const int rel = yi - (t.n0 + t.wn * 64 + h * 4);
+        const int idx = ((rel >> 5) << 4) | (((rel >> 3) & 3) << 2) | (rel & 3);  // register index b*16 + q*4 + j
+        float gv = 0.f, gm = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool hit = idx == b * 16 + r;
+            gv = hit ? acc.v[a][b][r] : gv;
+            gm = hit ? madd[b * 4 + (r >> 2)][r & 3] : gm;
+          }
+        if (rel >= 0 && rel < 64 && (rel & 4) == 0 && m < sim.M) sim.gold[m] = gm != 0.f ? -INFINITY : gv * sim.inv_T;
+      }
+    }
+  }
+};
+
 // Backward, first half (autograd of dpr_task.py:211-212 into the scores): the logits are recomputed (same GEMM, bit-identical
 // accumulators) and leave the tile as G = (softmax - onehot) * grad_scale in bf16, 2 bytes per score instead of the 4 + 4 + 2 of
 // store / re-read / G.  row_lse: natural-log logsumexp of every row (g8_lse_kernel).
@@ -883,6 +977,60 @@ __global__ __launch_bounds__(256) void g8_lse_kernel(const float* __restrict__ p
     loss_ws[row] = loss;
     if (row_lse != nullptr) row_lse[row] = lse;
     if (row_loss != nullptr) row_loss[row] = loss;
+  }
+}
+
+// Second half of the one-pass forward (Epi8StatsP): one workgroup per row.  Wave 0 derives the row logsumexp EXACTLY as g8_lse_kernel
+// does (same lanes, same order: the loss of the two plans is bit-identical); then the row's fp16 numerators become the bf16 dScores in
+// place, 16 bytes per thread and step: G = (P * 2^-14 * exp(strip max - lse) - onehot) * grad_scale.  The gold column gets its -1 whether
+// masked or not, as in Epi8G; a row with no unmasked column (lse = -inf) has P == 0 everywhere and gets factor 0, not NaN.
+typedef _Float16 g8_h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void g8_lse_p2g_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s, int npart,
+                                                         const float* __restrict__ gold, int M, int N, const int64_t* __restrict__ y,
+                                                         int64_t y_offset, float grad_scale, float* __restrict__ lse_ws, float* __restrict__ row_lse,
+                                                         float* __restrict__ row_loss, float* __restrict__ loss_ws, uint16_t* __restrict__ PG) {
+  __shared__ float bc;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const float* pm = part_m + (size_t)row * npart;
+  if (tid < 64) {
+    const float* ps = part_s + (size_t)row * npart;
+    float mx = -INFINITY;
+    for (int k = lane; k < npart; k += 64) mx = fmaxf(mx, pm[k]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    if (mx != -INFINITY)
+      for (int k = lane; k < npart; k += 64) {
+        const float m = pm[k];
+        if (m != -INFINITY) sm += ps[k] * __expf(m - mx);
+      }
+    sm = wave_sum(sm);
+    if (lane == 0) {
+      const float lse = mx == -INFINITY ? -INFINITY : mx + logf(sm);
+      const float loss = lse - gold[row];
+      lse_ws[row] = lse;
+      loss_ws[row] = loss;
+      if (row_lse != nullptr) row_lse[row] = lse;
+      if (row_loss != nullptr) row_loss[row] = loss;
+      bc = lse;
+    }
+  }
+  __syncthreads();
+  const float lse = bc;
+  const int yc = (int)(y[row] + y_offset);
+  const float fs = grad_scale * kG8PInvScale;
+  uint16_t* prow = PG + (size_t)row * N;
+  for (int c8 = tid; c8 * 8 < N; c8 += 256) {
+    const int col = c8 * 8;
+    const uint4 raw = *reinterpret_cast<const uint4*>(prow + col);
+    const float f = lse == -INFINITY ? 0.f : __expf(pm[col >> 6] - lse) * fs;
+    const g8_h8 hv = __builtin_bit_cast(g8_h8, raw);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      g[j] = (float)hv[j] * f;
+      if (col + j == yc) g[j] -= grad_scale;
+    }
+    *reinterpret_cast<uint4*>(prow + col) = make_uint4(cvt_pk_bf16(g[0], g[1]), cvt_pk_bf16(g[2], g[3]), cvt_pk_bf16(g[4], g[5]), cvt_pk_bf16(g[6], g[7]));
   }
 }
 
