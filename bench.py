@@ -632,12 +632,14 @@ def main():
         if isinstance(rs, dict) and "sim_gemm" in rs:
             def f(k, what):
                 return rs[k].get(what) if isinstance(rs.get(k), dict) else None
-            roof["at_scale"] = {"shape": "8192 x 8192 x %d" % d, "bound": "mfma", "checked": rs.get("checked"),
+            roof["at_scale"] = {"shape": "8192 x 8192 x %d" % d, "bound": "mfma", "checked": rs.get("checked"), "timing": rs.get("timing"),
                                 "sim_gemm_us": f("sim_gemm", "us"), "sim_gemm_frac": f("sim_gemm", "frac"),
                                 "dscores_us": f("dscores_gemm", "us"), "dscores_frac": f("dscores_gemm", "frac"),
                                 "backward_us": f("backward_gemms", "us"), "backward_frac": f("backward_gemms", "frac"),
-                                "hipblaslt_us": hb["8192x8192"]["us"] if isinstance(hb, dict) and "8192x8192" in hb else None,
-                                "hipblaslt_frac": hb["8192x8192"]["frac_of_bf16_peak"] if isinstance(hb, dict) and "8192x8192" in hb else None}
+                                "forward_one_pass_us": f("forward_one_pass", "us"), "forward_two_pass_us": rs.get("forward_two_pass_us"),
+                                "step_us": rs.get("step_us"), "step_mfma_frac": rs.get("step_mfma_frac"),
+                                "hipblaslt_us": f("hipblaslt_matmul", "us"), "hipblaslt_frac": f("hipblaslt_matmul", "frac"),
+                                "hipblaslt_alone_us": hb["8192x8192"]["us"] if isinstance(hb, dict) and "8192x8192" in hb else None}
         if "cpu" in a.blocks and not DM:
             out["cpu_baseline"] = cpu_baseline_reference(B, K, d, T)   # the faithful one: the reference's ops, 8 threads
             out["cpu_baseline_port"] = cpu_baseline(B, K, d, T, budget_s=6.0)  # the C restatement on every host thread

@@ -430,14 +430,20 @@ struct Epi8Base {
   __device__ __forceinline__ static int run_col(const Tile8& t, int b, int q) { return t.wn * 64 + b * 32 + q * 8 + (t.lane >> 5) * 4; }
   // madd[b*4 + q][j]: 0, or -inf where that column is masked
   __device__ __forceinline__ void col_madd(const Tile8& t, float (&madd)[8][4]) const {
+    // the eight runs of the lane sit at run_col(t, 0, 0) + b * 32 + q * 8 words: ONE address, eight reads in flight, one wait (round 6:
+    // eight read + wait pairs were eight dependent trips to the LDS, ~1 k cycles per tile, in front of an epilogue nothing overlaps)
+    g8_i32x4 f[8];
+    asm volatile(
+        "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
+        "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\tds_read_b128 %7, %8 offset:224\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5]), "=&v"(f[6]), "=&v"(f[7])
+        : "v"(g8_lds_addr(t.meta + run_col(t, 0, 0)))
+        : "memory");
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const g8_i32x4 f = g8_lds_read4(t.meta + run_col(t, b, q));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) madd[b * 4 + q][j] = f[j] != 0 ? -INFINITY : 0.f;
-      }
+      for (int j = 0; j < 4; ++j) madd[c][j] = f[c][j] != 0 ? -INFINITY : 0.f;
   }
 };
 

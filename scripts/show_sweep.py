@@ -4,8 +4,11 @@ for l in src:
     if not l.startswith('{'):
         continue
     d = json.loads(l)
-    out = 'B=%5d Nc=%6d %s |' % (d['B'], d['Nc'], d.get('forward_plan', ''))
-    for k in ['sim_stats_f32', 'prep', 'sim_stats_bf16', 'softmax_finish', 'dscores', 'bwd_pair']:
+    out = 'B=%5d Nc=%6d %-9s |' % (d['B'], d['Nc'], d.get('forward_plan', ''))
+    for k, nm in (('prep', 'prep'), ('sim_stats_f32', 'simf32'), ('sim_stats_bf16', 'sim'), ('softmax_finish', 'fin'), ('dscores', 'dsc'), ('fwd_bf16', 'fwd'), ('bwd_pair', 'bwd'),
+                  ('step', 'STEP')):
         if k in d:
-            out += ' %s %8.1fus %6.1fTF %5.0fGB/s |' % (k.replace('sim_stats_', 'sim').replace('softmax_finish', 'fin').replace('bwd_pair', 'bwd'), d[k]['us'], d[k]['TFLOPs'], d[k]['GBps'])
+            out += ' %s %7.1f |' % (nm, d[k]['us'])
+    if 'hbm_floor_us' in d:
+        out += ' floor %6.1f  step/floor %.2f' % (d['hbm_floor_us'], d['hbm_floor_us'] / d['step_us'])
     print(out)
