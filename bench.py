@@ -171,7 +171,7 @@ class HotPathStep:
                        else self._prepared(self.lib.dprhot_inbatch_step_f32, self.a_step))
         # no-logits shapes (large B x Nc: the workspace then holds no logit buffer): softmax_finish only derives logsumexp / loss
         # from the strip statistics, the dScores come from a third launch that recomputes the logits (dprhot_dscores)
-        self.nl = self.ws_bytes < 4 * B * Nc
+        self.nl = self._lib.fwd_no_logits(B, Nc, d)
         self.a_fin = (None, B, Nc, d, P(self.y), off, self.gscale, P(self.row_loss), P(self.row_lse), P(self.loss_sum),
                       None if self.nl else P(self.G), ws, wsb, st)
         self.a_dsc = (P(self.Qb), B, P(self.Cb), Nc, d, P(self.y), off, P(self.mask_all), self.inv_T, self.gscale, None, P(self.G),

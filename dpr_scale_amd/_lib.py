@@ -97,6 +97,7 @@ SIGNATURES = {
     "dprhot_allreduce_sum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_allgather_allpairs": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_comm_has_allpairs": (c_int, [c_void_p]),
+    "dprhot_fwd_no_logits": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
     "dprhot_reducescatter_allpairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "dprhot_inbatch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -162,6 +163,13 @@ def train_dq_slabs(B: int, Nc: int, d: int) -> int:
 def step_wants_g(B: int, Nc: int, d: int) -> bool:
     out = c_int(1)
     check(lib.dprhot_step_wants_g(B, Nc, d, ctypes.byref(out)), "dprhot_step_wants_g")
+    return bool(out.value)
+
+
+def fwd_no_logits(B: int, Nc: int, d: int) -> bool:
+    """True when this shape's forward never stores the logits (dprhot_fwd_no_logits)."""
+    out = c_int(0)
+    check(lib.dprhot_fwd_no_logits(B, Nc, d, ctypes.byref(out)), "dprhot_fwd_no_logits")
     return bool(out.value)
 
 

@@ -126,7 +126,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_COUNT };
 struct OptDef { const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -156,6 +156,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
     {"sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
     {"g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
+    {"sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
     {"nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
 };
 long long g_opt_epoch = 0;  // bumped by every dprhot_set_option: host-side caches of plan facts key on it (dprhot_options_epoch)
@@ -680,10 +681,16 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   // the finishing role inside the backward launch (sk_fin_unit): two-kinds form only; a dbg switch that silences units would strand it
   const bool tail = fused && !fz.pair && opt(OPT_SK_TAIL) != 0 && (opt(OPT_SK_DBG) & 7) == 0 && fz.nslices <= 62 && d <= 1024;
   unsigned* const tail_cnt = reinterpret_cast<unsigned*>(ws + wl.header + 128);
+  // round 6: no finishing launch at all -- the dQ units add their tiles into dQ, zero-filled by the sim launch (two-kinds form, dQ wanted)
+  const bool dq_atomic = fused && !fz.pair && !tail && opt(OPT_SK_DQ_ATOMIC) != 0 && dQ != nullptr && (opt(OPT_SK_DBG) & 15) == 0;
   if (fused) {
     a.S = nullptr;
     a.P = reinterpret_cast<uint16_t*>(ws + wl.logits);
     if (tail) a.zero_me = tail_cnt;
+    if (dq_atomic) {
+      a.zero_dq = dQ;
+      a.zero_n4 = (int)((size_t)B * d / 4);
+    }
   }
   const int grid1 = sk.nrb * nts;
   int rc = DPRHOT_OK;
@@ -707,6 +714,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
                  dC_part, g_dc_bf16 ? 1 : 0, g_packed.stamp_src != nullptr ? g_packed.rows_c : 0, g_packed.n_ctx, loss_sum, g_loss_scale,
                  row_loss, row_lse, fz.ksteps, fz.nslices, part, dQ, ndq_pad, opt(OPT_NT_STORES) ? 1 : 0, opt(OPT_SK_DBG)};
     b.reg_scale = opt(OPT_SK_DC_REGSCALE) != 0 ? 1 : 0;
+    b.dq_atomic = dq_atomic ? 1 : 0;
     const size_t lds = sk_bwdf_lds();
     static AttrOnce attr_done[4];
     auto launch = [&](auto kern, int slot, int threads) -> int {
@@ -754,7 +762,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       const size_t n4 = (size_t)B * d / 4;
       hipLaunchKernelGGL(sk_dq_reduce_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, st, part, fz.nslices, n4, h_scale, d_scale, dQ);
       HIP_TRY(hipGetLastError());
-    } else if (!tail) {
+    } else if (!tail && !dq_atomic) {
       // one workgroup per row where the row fits 256 threads (d <= 1024): the row's statistics are derived once, not once per part
       const int fthreads = d / 4 >= 256 ? 256 : cdiv(d / 4, 64) * 64;
       const int parts = cdiv(d / 4, fthreads);
@@ -1607,6 +1615,13 @@ int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants) {
   // are never more and their slices never longer.  A pure function of the shape, like every plan here.
   const SkPlan sk = sk_plan(B, Nc, d);
   *h_wants = sk_fused_plan(sk, cdiv(Nc, SK_COLS), cdiv(Nc, 64), B, Nc, d).ok ? 0 : 1;
+  return DPRHOT_OK;
+}
+
+int dprhot_fwd_no_logits(int B, int Nc, int d, int* h_nl) {
+  REQUIRE(h_nl != nullptr, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  *h_nl = nl_ok(B, Nc, d) ? 1 : 0;
   return DPRHOT_OK;
 }
 

@@ -119,7 +119,14 @@ struct SkSimArgs {
   // has to see whole rows.
   uint16_t* P = nullptr;
   unsigned* zero_me = nullptr;  // a counter of the NEXT launch of the step (sk_bwdf_kernel's finishing role): zeroed here, one launch ahead
+  float* zero_dq = nullptr;     // round 6 (option sk_dq_atomic): dQ [B][d], zero-filled HERE -- this launch runs first and its stores are idle
+  int zero_n4 = 0;              //   at the start -- because the NEXT launch's dQ units ADD their slabs into it (no finishing launch)
 };
+__device__ __forceinline__ void sk_zero_fill(const SkSimArgs& p, int nthreads) {
+  if (p.zero_dq == nullptr) return;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int e = (int)blockIdx.x * nthreads + (int)threadIdx.x; e < p.zero_n4; e += (int)gridDim.x * nthreads) reinterpret_cast<f32x4*>(p.zero_dq)[e] = z;
+}
 
 constexpr int SK_ASTAGE = 2 * SK_ROWS * SK_KC;  // elements: two [32 rows][64 k] images of the q rows
 inline size_t sk_sim_lds() { return (size_t)SK_ASTAGE * 2 + (size_t)SK_SLOTS * SK_COLS * SK_KC * 2; }  // = 8 slots x 64 columns
@@ -153,6 +160,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sk_sim_kernel(SkSimArgs p) {
   const int m0 = rb * SK_ROWS;
   const int n0 = p.tiles_per_rank > 0 ? (ct / p.tiles_per_rank) * p.p_rows_c + (ct % p.tiles_per_rank) * COLS : ct * COLS;
   if (p.zero_me != nullptr && blockIdx.x == 0 && tid == 0) *p.zero_me = 0u;
+  sk_zero_fill(p, NT);
   DPRHOT_TMB(0, 0);
 
   // ---- every global read of the unit's first phase, back to back: the q rows (registers: thread t holds the 8 values
@@ -421,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void sk_simp_kernel(SkSimArgs p) {
   const int m0 = rb * SK_ROWS;
   const int n0 = p.tiles_per_rank > 0 ? (ct / p.tiles_per_rank) * p.p_rows_c + (ct % p.tiles_per_rank) * COLS : ct * COLS;
   if (p.zero_me != nullptr && blockIdx.x == 0 && tid == 0) *p.zero_me = 0u;
+  sk_zero_fill(p, NT);
   DPRHOT_TMB(0, 0);
 
   // ---- every global read of the prologue back to back: the q rows (fp32; OLDEST, so that a counted wait releases them while the
@@ -1094,6 +1103,12 @@ struct SkBwdFArgs {
   int nfin = 0;                  // finishing workgroups (rows / (threads / 256))
   int reg_scale = 0;             // 1 (round 5): the dC units scale the Q FRAGMENTS by f in registers (no scale pass over the LDS image, one barrier less)
   int tail_fence = 0;            // 1: ordinary slab stores + ONE release fence per dQ unit, acquire fence + ordinary loads in the finishing role (A/B of the publish form)
+  // Round 6 (option sk_dq_atomic): NO finishing launch and no slabs.  A dQ unit derives the rows' logsumexp itself -- at its END, from
+  // loads issued under its last step, not in front of its loop where rounds 4's forms lost -- scales its slab by exp(m_is - lse_i) *
+  // scale, adds the gold term g_i C[y_i] of the rows whose gold column lies in its slice, and ADDS the tile into dQ with
+  // global_atomic_add_f32 (dQ was zero-filled by the sim launch: SkSimArgs::zero_dq).  The order of the (<= 16) additions per element
+  // depends on the run: dQ is then reproducible to rounding, not to the bit (the reference's cuBLAS split-K is no different).
+  int dq_atomic = 0;
 };
 
 constexpr int SK_FT = 8;                            // statistics tiles a dQ unit may touch ((ksteps + 1) / 2 + 1 <= SK_FT: sk_fused_ok)
@@ -1239,6 +1254,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       __hip_atomic_fetch_add(p.tail_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
+  if (ns <= 0 && p.dq_atomic) return;  // (an empty slice adds nothing)
   if (ns <= 0) {  // a remapped tiling with fewer steps than the plan's slices cover: this slice is empty, its slab is zero
     for (int e = tid; e < p.B * (SK_QN / 4); e += NT) {
       float* const dst = out + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4;
@@ -1259,6 +1275,14 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     const int t = min(t0 + ph + PH * u, p.nt - 1);
     lt[u] = sk_ld4_hidden(p.tile_lse + ((size_t)(t >> 2) * p.B + prow) * 4 + (t & 3));
   }
+
+  // (sk_dq_atomic: the row's gold logit and label, also ahead of every DMA; its tile values are issued under the LAST step)
+  float gl_a = 0.f, yf_a = 0.f, m_keep = -INFINITY;
+  if (p.dq_atomic) {
+    gl_a = sk_ld4_hidden(p.gold + prow);
+    yf_a = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
+  }
+  SkRowStats<NG * 2 / PH, PH> st_a;
 
   // ---- ring DMAs: per-lane source coordinates (one instruction = 1 KiB = 8 rows of 128 bytes)
   unsigned arow[IA];
@@ -1342,6 +1366,9 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     constexpr bool FIRST = decltype(first_tag)::value;
     SK_LT(4);
     sk_wait_younger<PER>(min(s + SK_QSLOTS - 2, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
+    // (sk_dq_atomic: ALL tile values of the row, behind the last counted wait of the unit -- they land under this step's reads, MFMAs and
+    //  the final barrier, and are consumed in the epilogue behind a vmcnt(0) of their own)
+    if (p.dq_atomic && s == ns - 1) st_a.issue(p.tile_lse, p.nt, p.B, prow, ph);
     SK_LT(0);
     const int slot = s % SK_QSLOTS;
     uint16_t* As = sk_smem + slot * SLOT;
@@ -1436,6 +1463,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       for (int u = 0; u < SK_FT / PH; ++u) m = fmaxf(m, ph + PH * u <= tlast ? lt[u] : -INFINITY);
       m = fmaxf(m, ss_dpp<0xB1>(m));  // the other tiles of the row (lane ^ 1, then lane ^ 2)
       if constexpr (PH == 4) m = fmaxf(m, ss_dpp<0x4E>(m));
+      m_keep = m;
       const int row = tid / PH;
       if (row < p.B) {
 #pragma unroll
@@ -1478,6 +1506,44 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(wr * 32 + a * 16 + g4 * 4 + r) * TS + (wc * NB + b) * 16 + i16] = acc[a][b][r];
+  if (p.dq_atomic) {
+    // ---- no slab: the tile is scaled to the row softmax HERE and added into dQ.  Per row (the PH threads that hold its statistics):
+    //      e_i = exp(m_is - lse_i) * scale (0 for a slice without an unmasked column), and -- when the row's gold column lies in this
+    //      slice -- g_i = (exp(S_gold,i - lse_i) - 1) * scale with its column, the term sk_dq_finish_kernel adds once per row.
+    //      Table e [128] | g [128] | gold column or -1 [128] in the dead ring, behind the staged tile (NOT in the weight table's place:
+    //      a slower wave may still be reading its weights in add_scaled above).
+    float* const fs = reinterpret_cast<float*>(sk_smem) + 10240;  // byte 40960: the tile ends at 128 * 68 * 4 = 34816, the ring at 73728
+    static_assert(SK_MAXB * (SK_QN + 4) * 4 <= 40960 && 40960 + 3 * 128 * 4 <= SK_QSLOTS * (SK_QA + SK_QB) * 2, "sk_dq_atomic table");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    st_a.pin();
+    asm volatile("" : "+v"(gl_a), "+v"(yf_a));
+    const float lse = st_a.finish(p.nt, ph);
+    const float sc = p.h_scale * (p.d_scale ? *p.d_scale : 1.0f) * p.grad_scale;
+    if (ph == 0 && tid / PH < p.B) {
+      const int row = tid / PH;
+      const int yg = __float_as_int(yf_a) + (int)p.y_offset;
+      const int gstep = sk_step_of_col(p, yg);
+      const bool mine = gstep >= s0 && gstep < s0 + ns;
+      fs[row] = m_keep == -INFINITY ? 0.f : __expf(m_keep - lse) * sc;
+      fs[128 + row] = mine ? (__expf(gl_a - lse) - 1.0f) * sc : 0.f;
+      reinterpret_cast<int*>(fs)[256 + row] = mine ? yg : -1;
+    }
+    sk_barrier();  // the staged tile and the table
+    float* const dq = p.dQ + c0;
+#pragma unroll 4
+    for (int it = 0; it < SK_MAXB * SK_QN / NT; ++it) {
+      const int e = tid + it * NT, row = e >> 6, col = e & 63;  // one wave = one row: 256 contiguous bytes per atomic instruction
+      if (row < p.B) {
+        float v = T[row * TS + col] * fs[row];
+        const int yg = reinterpret_cast<const int*>(fs)[256 + row];
+        if (yg >= 0) v = fmaf(fs[128 + row], __uint_as_float((unsigned)p.C[(size_t)yg * p.d + c0 + col] << 16), v);  // (wave-uniform branch)
+        (void)__hip_atomic_fetch_add(dq + (size_t)row * p.d + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_atomic_add_f32, no return
+      }
+    }
+    DPRHOT_TMB(2, 3);
+    return;
+  }
   sk_barrier();
 #pragma unroll
   for (int it = 0; it < SK_MAXB * 16 / NT; ++it) {

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 171 /* 0.1.71: + dprhot_comm_has_allpairs (local pre-flight of the all-pairs exchanges); option sk_dq_atomic */
+#define DPRHOT_VERSION 171 /* 0.1.71: + dprhot_comm_has_allpairs, dprhot_fwd_no_logits; options nl_p16, sk_dq_atomic */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -220,6 +220,10 @@ int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprh
  * (row, tile) themselves -- three launches instead of four at BASELINE cfg3 per rank (dpr_task.py:197-212 and its backward).  A
  * non-NULL G is always honoured (and costs the dScores launch). */
 int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants);
+/* *h_nl = 1 when the forward of this shape never stores the logits (the "no-logits" plan: >= 256 tiles of 256 x 256 -- or the option
+ * big_min -- K % 128 == 0; dprhot_softmax_finish then yields logsumexp / loss only and G comes from dprhot_inbatch_fwd / dprhot_dscores),
+ * 0 when the logits live in the workspace.  A pure function of the shape and the options, like every plan. */
+int dprhot_fwd_no_logits(int B, int Nc, int d, int* h_nl);
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,
                             const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale,
                             float h_scale, const float* d_scale, float* S_out, float* row_loss, float* row_lse,

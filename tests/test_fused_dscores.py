@@ -352,3 +352,52 @@ def test_finishing_role_inside_the_backward_launch(mode, dev):
         for o in outs[1:]:
             assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and o[2] == outs[0][2]
         assert torch.isfinite(outs[1][0]).all()
+
+
+@pytest.mark.parametrize("w8", [1, 0])
+@pytest.mark.parametrize("W,B,K,d,T,peaky,dup", PACKED_CASES)
+def test_dq_units_adding_into_dq_without_a_finishing_launch(W, B, K, d, T, peaky, dup, w8, dev):
+    """Option sk_dq_atomic (round 6): the dQ units derive the rows' logsumexp at their END, scale their tile to the row softmax, add the
+    gold term of the rows whose gold column lies in their slice and ADD the tile into dQ (global_atomic_add_f32; dQ zero-filled by the
+    sim launch) -- no slabs, no sk_dq_finish_kernel.  Against fp64 (the bar of the slab form) and against the slab form itself: the same
+    terms in another order of addition, so equal to fp32 rounding (<= 1e-5 of max |dQ|), dC / loss / logsumexp BIT-identical (untouched);
+    a second run may differ in the last bit (run-dependent order), never beyond rounding; poisoned dQ buffers (NaN) must not leak."""
+    from dpr_scale_amd import _lib
+    from dpr_scale_amd.hotpath import HipKernels
+
+    kn = HipKernels()
+    defaults = {k: _lib.get_option(k) for k in ("sk_fused", "sk_w8", "sk_pair", "sk_dq_atomic")}
+    try:
+        _lib.set_option("sk_fused", 2)
+        _lib.set_option("sk_w8", w8)
+        _lib.set_option("sk_pair", 0)
+        qs, cs, y, ms = _world(W, B, K, d, dev, seed=W * 100 + K, peaky=peaky, dup=dup)
+        n_ctx = B * K
+        rows_c, Cb, colmask = _packed(kn, qs, cs, ms, dev)
+        Nc = W * rows_c
+        if _lib.step_wants_g(B, Nc, d):
+            pytest.skip("this shape's plan keeps the dScores launch")
+        yd = y.to(dev)
+        Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+        inv_T, Nq = 1.0 / T, W * B
+        for r in (0, W - 1):
+            _lib.set_option("sk_dq_atomic", 0)
+            rl0, lse0, ls0, _, dq0, dcp0 = kn.inbatch_step_packed_f32(qs[r], Cb, Qb, W, r, n_ctx, yd, inv_T, inv_T / Nq, want_G=False)
+            dq0, dcp0 = dq0.clone(), dcp0.clone()
+            _lib.set_option("sk_dq_atomic", 1)
+            outs = []
+            for rep in range(3):
+                rl, lse, ls, G, dq, dcp = kn.inbatch_step_packed_f32(qs[r], Cb, Qb, W, r, n_ctx, yd, inv_T, inv_T / Nq, want_G=False)
+                assert G is None
+                outs.append(dq.clone())
+                assert torch.equal(dcp, dcp0) and torch.equal(lse, lse0) and ls.item() == ls0.item()
+            ref_ls, ref_lse, ref_dq, ref_dc = _reference(qs[r], Cb.float(), colmask, yd + r * rows_c, T, Nq)
+            e_dq, e_dq0 = _err(outs[0], ref_dq), _err(dq0, ref_dq)
+            print(f"W{W} B{B} K{K} d{d} T{T} r{r} w8={w8}: dQ err atomic {e_dq:.2e} / slabs {e_dq0:.2e}; atomic vs slabs {_err(outs[0], dq0):.2e}")
+            assert torch.isfinite(outs[0]).all() and e_dq <= GRAD_BAR and e_dq <= max(1.5 * e_dq0, 1e-4)
+            assert _err(outs[0], dq0) <= 1e-5
+            for o in outs[1:]:
+                assert _err(o, outs[0]) <= 2e-6
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
