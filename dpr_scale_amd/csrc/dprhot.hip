@@ -682,7 +682,7 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
   const bool tail = fused && !fz.pair && opt(OPT_SK_TAIL) != 0 && (opt(OPT_SK_DBG) & 7) == 0 && fz.nslices <= 62 && d <= 1024;
   unsigned* const tail_cnt = reinterpret_cast<unsigned*>(ws + wl.header + 128);
   // round 6: no finishing launch at all -- the dQ units add their tiles into dQ, zero-filled by the sim launch (two-kinds form, dQ wanted)
-  const bool dq_atomic = fused && !fz.pair && !tail && opt(OPT_SK_DQ_ATOMIC) != 0 && dQ != nullptr && (opt(OPT_SK_DBG) & 15) == 0;
+  const bool dq_atomic = fused && !fz.pair && !tail && opt(OPT_SK_DQ_ATOMIC) != 0 && opt(OPT_SK_W8) != 0 && dQ != nullptr && (opt(OPT_SK_DBG) & 15) == 0;
   if (fused) {
     a.S = nullptr;
     a.P = reinterpret_cast<uint16_t*>(ws + wl.logits);
@@ -752,7 +752,18 @@ int sk_step(const float* q, const dprhot_bf16* Cb, dprhot_bf16* Qb, int B, int N
       }
     } else {
       const bool w8 = opt(OPT_SK_W8) != 0;
-      if (nts <= 64) rc = w8 ? launch(sk_bwdf_kernel<8, 8>, 2, 512) : launch(sk_bwdf_kernel<8, 4>, 0, SK_THREADS);
+      if (dq_atomic && w8) {  // (eight-wave units only: the form production runs)
+        static AttrOnce attr_at[2];
+        auto launch_at = [&](auto kern, int slot) -> int {
+          if (!attr_at[slot]) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_at[slot] = true;
+          }
+          hipLaunchKernelGGL(kern, dim3((unsigned)(ndq_pad + ndc)), dim3(512), lds, st, b);
+          return DPRHOT_OK;
+        };
+        rc = nts <= 64 ? launch_at(sk_bwdf_kernel<8, 8, true>, 0) : launch_at(sk_bwdf_kernel<16, 8, true>, 1);
+      } else if (nts <= 64) rc = w8 ? launch(sk_bwdf_kernel<8, 8>, 2, 512) : launch(sk_bwdf_kernel<8, 4>, 0, SK_THREADS);
       else rc = w8 ? launch(sk_bwdf_kernel<16, 8>, 3, 512) : launch(sk_bwdf_kernel<16, 4>, 1, SK_THREADS);
       if (rc) return rc;
     }

@@ -1221,7 +1221,7 @@ struct SkRowStats {
 // ring runs dry behind them), and the launch came out exactly as long as the two launches it replaced (29.4 us per step both ways).
 // The factor FMAs of step s run under the MFMAs of step s + 1 (two scratch accumulators), and a slot is refilled as soon as every
 // wave holds its fragments.
-template <int NG, int NW = 4>
+template <int NG, int NW = 4, bool ATOMIC = false>
 __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint16_t* sk_smem) {
   constexpr int NT = NW * 64;  // threads
   constexpr int PH = NW / 2;   // threads per row of the weight table
@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       __hip_atomic_fetch_add(p.tail_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-  if (ns <= 0 && p.dq_atomic) return;  // (an empty slice adds nothing)
+  if (ns <= 0 && ATOMIC) return;  // (an empty slice adds nothing)
   if (ns <= 0) {  // a remapped tiling with fewer steps than the plan's slices cover: this slice is empty, its slab is zero
     for (int e = tid; e < p.B * (SK_QN / 4); e += NT) {
       float* const dst = out + (size_t)(e >> 4) * p.d + c0 + (e & 15) * 4;
@@ -1277,12 +1277,14 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
   }
 
   // (sk_dq_atomic: the row's gold logit and label, also ahead of every DMA; its tile values are issued under the LAST step)
+  // (ATOMIC is a template parameter, not a run-time switch: the statistics registers of the epilogue below must not enter the register
+  //  allocation of the slab form -- as a run-time branch they made every sk_bwdf_kernel spill, and a spill's scratch traffic inside
+  //  the loop breaks its hand-counted vmcnt waits: wrong tiles, caught by tests/test_fused_dscores.py)
   float gl_a = 0.f, yf_a = 0.f, m_keep = -INFINITY;
-  if (p.dq_atomic) {
+  if constexpr (ATOMIC) {
     gl_a = sk_ld4_hidden(p.gold + prow);
     yf_a = sk_ld4_hidden(reinterpret_cast<const int*>(p.y) + 2 * prow);
   }
-  SkRowStats<NG * 2 / PH, PH> st_a;
 
   // ---- ring DMAs: per-lane source coordinates (one instruction = 1 KiB = 8 rows of 128 bytes)
   unsigned arow[IA];
@@ -1366,9 +1368,6 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     constexpr bool FIRST = decltype(first_tag)::value;
     SK_LT(4);
     sk_wait_younger<PER>(min(s + SK_QSLOTS - 2, ns - 1) - s);  // slot s has landed (and, in step 0, the tile values issued ahead of it)
-    // (sk_dq_atomic: ALL tile values of the row, behind the last counted wait of the unit -- they land under this step's reads, MFMAs and
-    //  the final barrier, and are consumed in the epilogue behind a vmcnt(0) of their own)
-    if (p.dq_atomic && s == ns - 1) st_a.issue(p.tile_lse, p.nt, p.B, prow, ph);
     SK_LT(0);
     const int slot = s % SK_QSLOTS;
     uint16_t* As = sk_smem + slot * SLOT;
@@ -1463,7 +1462,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
       for (int u = 0; u < SK_FT / PH; ++u) m = fmaxf(m, ph + PH * u <= tlast ? lt[u] : -INFINITY);
       m = fmaxf(m, ss_dpp<0xB1>(m));  // the other tiles of the row (lane ^ 1, then lane ^ 2)
       if constexpr (PH == 4) m = fmaxf(m, ss_dpp<0x4E>(m));
-      m_keep = m;
+      if constexpr (ATOMIC) m_keep = m;
       const int row = tid / PH;
       if (row < p.B) {
 #pragma unroll
@@ -1482,6 +1481,10 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     if (s + 1 < ns) body(std::false_type{}, s + 1, tA, tB);
   }
   sk_barrier();  // every wave is done with the ring (and, when the slice is one step long, the table is published here)
+  // (ATOMIC: ALL tile values of the row -- issued here, behind the unit's last counted wait, so that they land under the last factor
+  //  FMAs and the staging of the tile; issued inside the loop they would keep their registers allocated across it)
+  SkRowStats<ATOMIC ? NG * 2 / PH : 1, PH> st_a;
+  if constexpr (ATOMIC) st_a.issue(p.tile_lse, p.nt, p.B, prow, ph);
   if ((ns - 1) & 1) add_scaled(ns - 1, tB);
   else add_scaled(ns - 1, tA);
   DPRHOT_TMB(2, 2);
@@ -1506,7 +1509,7 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) T[(wr * 32 + a * 16 + g4 * 4 + r) * TS + (wc * NB + b) * 16 + i16] = acc[a][b][r];
-  if (p.dq_atomic) {
+  if constexpr (ATOMIC) {
     // ---- no slab: the tile is scaled to the row softmax HERE and added into dQ.  Per row (the PH threads that hold its statistics):
     //      e_i = exp(m_is - lse_i) * scale (0 for a slice without an unmasked column), and -- when the row's gold column lies in this
     //      slice -- g_i = (exp(S_gold,i - lse_i) - 1) * scale with its column, the term sk_dq_finish_kernel adds once per row.
@@ -1975,14 +1978,14 @@ __device__ __forceinline__ void sk_fin_unit(const SkBwdFArgs& p, int f, uint16_t
 // NW = 4: 256 threads.  NW = 8: 512 threads, the same LDS, half the output tile per wave (option sk_w8).  The stamps showed a dQ
 // unit's step bound by ONE wave's instruction stream (wait, barrier, 20 LDS reads, 16 MFMAs in a dependent chain: 0.73 us, of which
 // 0.11 waiting for the slot), and two dQ workgroups sharing a CU running at the speed of one: the CU has issue room for twice the waves.
-template <int NG, int NW>
+template <int NG, int NW, bool ATOMIC = false>
 __global__ __launch_bounds__(NW * 64, NW / 2) void sk_bwdf_kernel(SkBwdFArgs p) {  // (second argument: waves per SIMD, two workgroups per CU either way)
   extern __shared__ __attribute__((aligned(16))) uint16_t sk_smem[];
   const int b = blockIdx.x;
   const int ndq = p.nslices * (p.d / SK_QN);
   if (b < p.ndq_pad) {
     if (b >= ndq || (p.dbg & 2)) return;  // padding
-    sk_dq_unit_f<NG, NW>(p, sk_xcd_order(b, ndq), sk_smem);
+    sk_dq_unit_f<NG, NW, ATOMIC>(p, sk_xcd_order(b, ndq), sk_smem);
   } else if (b < (int)gridDim.x - p.nfin) {
     if (p.dbg & 1) return;
     sk_dc_unit_f<NG, NW>(p, sk_xcd_order(b - p.ndq_pad, (int)gridDim.x - p.nfin - p.ndq_pad), sk_smem);
