@@ -127,38 +127,44 @@ struct AttrOnce {
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
              OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_COUNT };
-struct OptDef { const char* name; int def; const char* what; };
+struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
-    {"tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
-    {"no_tr", 0, "1 swaps the LDS transpose read for plain 16-bit gathers (cross-check)"},
-    {"unfused_bwd", 0, "1 runs dC and dQ as two launches"},
-    {"big_min", 256, "fewest 256x256 tiles for which the large-shape kernels are chosen (0 = never; tests lower it)"},
-    {"no_nl", 0, "1 disables the no-logits forward"},
-    {"no_big_bwd", 0, "1 disables the 256x256 backward pair"},
-    {"no_skinny", 0, "1 disables the few-rows x many-contexts plan (skinny.h)"},
-    {"no_small_step", 0, "1 disables the fused softmax+backward kernel of the latency-bound shapes (step_small.h)"},
-    {"no_short", 0, "1 disables the short-row (K-split slab) forward"},
-    {"sk_cols", 0, "64 / 128 forces the sim unit width of the skinny plan, 0 = plan"},
-    {"search_unfused", 0, "1 materialises every chunk's scores in dprhot_search (no filter epilogue)"},
-    {"no_8pb", 0, "1 keeps the backward pair on gemm256.h instead of the phase-interleaved schedule"},
-    {"no_wide", 0, "1 keeps vocabulary-wide fp32 operands on the register-staged sim kernel (wide.h off)"},
-    {"wide_nocopy", 0, "TIMING EXPERIMENT ONLY: 1 drops the bf16 copy-out of wide.h (the backward then reads garbage)"},
-    {"no_8p_store", 0, "1 keeps dprhot_sim_fwd's large shapes on the round-1 256 x 256 kernel (gemm256.h)"},
-    {"no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
-    {"nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
-    {"sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
-    {"sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured faster (B x Nc >= 2^19), 2 = wherever the plan exists (tests), 0 = never"},
-    {"sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward; bits): 1 dC units leave at once, 2 dQ units leave at once, 4 (unused), 8 the plain slab sum in the finishing launch's place (wrong dQ), 16 the dQ slabs leave with ordinary instead of non-temporal stores"},
-    {"sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
-    {"sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
-    {"sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},
-    {"sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
-    {"sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
-    {"sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
-    {"g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
-    {"sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
-    {"nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
+    {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
+    {OPT_NO_TR, "no_tr", 0, "1 swaps the LDS transpose read for plain 16-bit gathers (cross-check)"},
+    {OPT_UNFUSED_BWD, "unfused_bwd", 0, "1 runs dC and dQ as two launches"},
+    {OPT_BIG_MIN, "big_min", 256, "fewest 256x256 tiles for which the large-shape kernels are chosen (0 = never; tests lower it)"},
+    {OPT_NO_NL, "no_nl", 0, "1 disables the no-logits forward"},
+    {OPT_NO_BIG_BWD, "no_big_bwd", 0, "1 disables the 256x256 backward pair"},
+    {OPT_NO_SKINNY, "no_skinny", 0, "1 disables the few-rows x many-contexts plan (skinny.h)"},
+    {OPT_NO_SMALL_STEP, "no_small_step", 0, "1 disables the fused softmax+backward kernel of the latency-bound shapes (step_small.h)"},
+    {OPT_NO_SHORT, "no_short", 0, "1 disables the short-row (K-split slab) forward"},
+    {OPT_SK_COLS, "sk_cols", 0, "64 / 128 forces the sim unit width of the skinny plan, 0 = plan"},
+    {OPT_SEARCH_UNFUSED, "search_unfused", 0, "1 materialises every chunk's scores in dprhot_search (no filter epilogue)"},
+    {OPT_NO_8PB, "no_8pb", 0, "1 keeps the backward pair on gemm256.h instead of the phase-interleaved schedule"},
+    {OPT_NO_WIDE, "no_wide", 0, "1 keeps vocabulary-wide fp32 operands on the register-staged sim kernel (wide.h off)"},
+    {OPT_WIDE_NOCOPY, "wide_nocopy", 0, "TIMING EXPERIMENT ONLY: 1 drops the bf16 copy-out of wide.h (the backward then reads garbage)"},
+    {OPT_NO_8P_STORE, "no_8p_store", 0, "1 keeps dprhot_sim_fwd's large shapes on the round-1 256 x 256 kernel (gemm256.h)"},
+    {OPT_NO_WIDE_BWD, "no_wide_bwd", 0, "1 keeps the backward of vocabulary-wide vectors on the generic pair kernel (skinny.h units off)"},
+    {OPT_NT_STORES, "nt_stores", 1, "0 writes dC_part of the few-rows plans (skinny.h units: cfg3 per rank, router width) with plain instead of non-temporal stores (A/B of the cache policy)"},
+    {OPT_SK_DQ_SLICES, "sk_dq_slices", 0, "context slices of the few-rows plan's dQ units (0 = plan)"},
+    {OPT_SK_FUSED, "sk_fused", 1, "few-rows plan without its dScores launch (G == NULL): 1 = where it measured faster (B x Nc >= 2^19), 2 = wherever the plan exists (tests), 0 = never"},
+    {OPT_SK_DBG, "sk_dbg", 0, "TIMING EXPERIMENTS ONLY (fused few-rows backward; bits): 1 dC units leave at once, 2 dQ units leave at once, 4 (unused), 8 the plain slab sum in the finishing launch's place (wrong dQ), 16 the dQ slabs leave with ordinary instead of non-temporal stores"},
+    {OPT_SK_W8, "sk_w8", 1, "fused few-rows backward with eight waves per workgroup (512 threads, half the output tile per wave: 13.0-13.5 against 13.9-14.4 us at cfg3 per rank); 0 = four"},
+    {OPT_SK_PAIR, "sk_pair", 0, "fused few-rows backward with one kind of unit (sk_bwdp_kernel: a P tile is loaded once for both products: measured 21.2 against 13.5 us at cfg3 per rank); 0 = dQ units and dC units (sk_bwdf_kernel)"},
+    {OPT_SK_SIM_W8, "sk_sim_w8", 1, "few-rows sim launch with eight waves per workgroup (128-column units, fp32 q): 0 = four"},
+    {OPT_SK_SIM_PRIV, "sk_sim_priv", 1, "few-rows sim launch with wave-private rings and no barrier in the K loop (sk_simp_kernel; fp32 q, 128-column units, grids of at most one unit per CU): 0 = sk_sim_kernel"},
+    {OPT_SK_TAIL, "sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
+    {OPT_SK_DC_REGSCALE, "sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
+    {OPT_G8_ONE_TILE, "g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
+    {OPT_NL_P16, "nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
+    {OPT_SK_DQ_ATOMIC, "sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
 };
+constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (kOptDefs[i].id != (OptId)i) return false;
+  return true;
+}
+static_assert(opt_table_in_enum_order(), "kOptDefs must list the options in the order of enum OptId");
 long long g_opt_epoch = 0;  // bumped by every dprhot_set_option: host-side caches of plan facts key on it (dprhot_options_epoch)
 int g_opt[OPT_COUNT];  // the defaults of the table above (one place: a default typed twice was typed wrong once)
 const bool g_opt_defaults = [] {

@@ -15,7 +15,6 @@ HAND_COUNTED = ("sk_sim_kernel", "sk_simp_kernel", "sk_bwd_kernel", "sk_bwdf_ker
 def _kernels():
     cur, rows = None, {}
     for ln in open(REPORT, errors="replace"):
-        m = re.search(r"Function Name: (\S+)|remark: [^ ]* Name: (\S+)", ln)
         m = re.search(r" Name: (\S+)", ln)
         if m:
             cur = m.group(1)
