@@ -126,7 +126,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -158,6 +158,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_G8_ONE_TILE, "g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
     {OPT_NL_P16, "nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
     {OPT_SK_DQ_ATOMIC, "sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
+    {OPT_NL_MIN, "nl_min", 128, "fewest 256x256 tiles from which the forward never stores the logits (round 6: 128 -- with the one-pass forward 1024 x 8192 x 768 steps in 81 instead of 92 us, 512 x 16384 in 116 instead of 126; at 64 tiles it is a wash, at 32 it loses); the smaller of this and big_min counts"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -200,8 +201,15 @@ bool big_ok(int M, int N, int K) {
 
 // The phase-interleaved persistent 256x256 kernel (gemm8p.h) and the forward built on it that never stores the logits: same gate
 // as the 256x256 tile, plus an even number of K steps and operands addressable with 32-bit byte offsets.
-bool nl_ok(int M, int N, int K) {
+// (the storing / filtering uses of the same kernel -- dprhot_sim_fwd, dprhot_search -- keep the 256-tile gate they were measured at)
+bool g8_ok(int M, int N, int K) {
   return !opt(OPT_NO_NL) && force_tile() < 0 && big_ok(M, N, K) && K % 128 == 0 && (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
+}
+bool nl_ok(int M, int N, int K) {
+  const long wgs = (long)((M + 255) / 256) * ((N + 255) / 256);
+  const int need = big_min_wgs() < opt(OPT_NL_MIN) ? big_min_wgs() : opt(OPT_NL_MIN);
+  const bool big = M > 128 && K % 64 == 0 && K >= 128 && big_min_wgs() > 0 && wgs >= need;  // (big_ok with this plan's own tile count)
+  return !opt(OPT_NO_NL) && force_tile() < 0 && big && K % 128 == 0 && (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
 }
 
 // Tile for D[M,N] with contraction length K: the largest tile (BM capped by M) that still yields `want`
@@ -920,7 +928,7 @@ int dprhot_sim_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, in
   REQUIRE(Q && C && S, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
   REQUIRE(aligned16(Q) && aligned16(C) && aligned16(S), "pointers must be 16-byte aligned");
-  if (nl_ok(B, Nc, d) && !opt(OPT_NO_8P_STORE)) {
+  if (g8_ok(B, Nc, d) && !opt(OPT_NO_8P_STORE)) {
     // large score matrices (validation with the logits wanted, the head chunk of a retrieval): the phase-interleaved kernel with
     // the store epilogue that writes whole rows (Epi8Store); the round-1 256 x 256 kernel stays behind the option
     Epi8Store epi;
@@ -1155,7 +1163,7 @@ int dprhot_search(const dprhot_bf16* Q, int nq, const dprhot_bf16* C, int64_t n_
       continue;
     }
     // scores that cannot enter the top-k never leave the GEMM tile
-    if (nl_ok(nq, cols, d)) {  // the phase-interleaved kernel (gemm8p.h); thresholds arrive with the tile's input words
+    if (g8_ok(nq, cols, d)) {  // the phase-interleaved kernel (gemm8p.h); thresholds arrive with the tile's input words
       // (Round 4 merged warm chunks in groups of up to four -- option search_group: up to four chunks filtered against the same stale
       //  thresholds appended to ONE candidate list of `chunk` entries per row, with no bound on the append: a corpus whose later
       //  chunks beat the current k-th value could write past its row.  It had measured no gain -- 4.76 ms either way at 1024 x 2 M,

@@ -1534,9 +1534,12 @@ __device__ __forceinline__ void sk_dq_unit_f(const SkBwdFArgs& p, int unit, uint
     }
     sk_barrier();  // the staged tile and the table
     float* const dq = p.dQ + c0;
+    const int rot = (ks * SK_MAXB) / max(p.nslices, 1);
 #pragma unroll 4
     for (int it = 0; it < SK_MAXB * SK_QN / NT; ++it) {
-      const int e = tid + it * NT, row = e >> 6, col = e & 63;  // one wave = one row: 256 contiguous bytes per atomic instruction
+      // one wave = one row: 256 contiguous bytes per atomic instruction; the slices of a dQ tile finish together, so each starts at
+      // its own row (rotation by slice): at any moment the units adding into one tile are in different lines
+      const int e = tid + it * NT, row = ((e >> 6) + rot) & (SK_MAXB - 1), col = e & 63;
       if (row < p.B) {
         float v = T[row * TS + col] * fs[row];
         const int yg = reinterpret_cast<const int*>(fs)[256 + row];

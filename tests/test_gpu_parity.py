@@ -1009,7 +1009,8 @@ def test_short_and_long_forward_plans_agree(kn, dev, monkeypatch):
 # 16 -- the persistent K pipeline wraps into the next tile differently than at 2 / 4 steps), ragged rows and a column count that is no
 # multiple of 256 included (VERDICT r5 "what's weak" #1)
 NL_SHAPES = [(4096, 4096, 256), (1000, 16392, 128), (300, 70000, 128),
-             (4096, 4096, 768), (2048, 16384, 768), (1024, 32768, 1024), (4100, 4360, 768)]
+             (4096, 4096, 768), (2048, 16384, 768), (1024, 32768, 1024), (4100, 4360, 768),
+             (1024, 8192, 768), (1500, 6216, 256)]  # (the last two: 128 / 150 tiles -- one workgroup per tile, the gate of round 6: option nl_min)
 
 
 def _nl_problem(B, Nc, d, seed, dev, dup=False):
