@@ -100,7 +100,7 @@ def test_host_side_plans_are_consistent():
         rows = _lib.packed_rows(n_ctx, d)
         assert rows % 8 == 0 and rows * d * 2 >= n_ctx * d * 2 + n_ctx and rows - n_ctx <= -(-n_ctx // (2 * d)) + 7
     last = 0
-    for B in [8, 32, 128, 1024]:
+    for B in [8, 32, 128, 512]:  # (1024 x 8192 is a no-logits shape since round 6 -- 128 tiles, option nl_min: no logit buffer there)
         w = _lib.workspace_bytes(B, 8192, 768)
         assert w >= B * 8192 * 4 and w > last
         last = w
