@@ -23,6 +23,7 @@
 #include "gemm256.h"
 #include "gemm8p.h"
 #include "gemm8pb.h"
+#include "gemm128d.h"
 #include "rowwise.h"
 #include "step_small.h"
 #include "skinny.h"
@@ -126,7 +127,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -159,6 +160,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_NL_P16, "nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
     {OPT_SK_DQ_ATOMIC, "sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
     {OPT_NL_MIN, "nl_min", 128, "fewest 256x256 tiles from which the forward never stores the logits (round 6: 128 -- with the one-pass forward 1024 x 8192 x 768 steps in 81 instead of 92 us, 512 x 16384 in 116 instead of 126; at 64 tiles it is a wash, at 32 it loses); the smaller of this and big_min counts"},
+    {OPT_G128_DMA, "g128_dma", 0, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -299,6 +301,19 @@ int launch_gemm(int tile, const GemmArgs& a, const Epi& epi, int splits, hipStre
   }
   constexpr bool needs_tr = !(AK && BKM);
   const bool tr = needs_tr ? use_tr() : false;
+  if (tile == 0 && opt(OPT_G128_DMA) != 0 && (tr || !needs_tr) && a.K % 64 == 0 && a.kchunk % 64 == 0 && a.M >= 8 && a.N >= 8 &&
+      (double)a.M * a.lda < 4.0e9 && (double)a.N * a.ldb < 4.0e9 && (double)a.K * (AK ? 1 : a.lda) < 4.0e9 && (double)a.K * (BKM ? 1 : a.ldb) < 4.0e9) {
+    // the same tile with LDS-DMA staging (gemm128d.h): same images, same fragments, same epilogues
+    auto kern = gemm128d_kernel<AK, BKM, Epi>;
+    static AttrOnce attr_done;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g1_lds_bytes));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 128), cdiv(a.M, 128), splits), dim3(256), g1_lds_bytes, st, a, epi);
+    HIP_TRY(hipGetLastError());
+    return DPRHOT_OK;
+  }
 #define DPRHOT_TILE_CASE(T, BM, BN, BK_)                                                       \
   case T:                                                                                      \
     if constexpr (needs_tr) {                                                                  \
