@@ -1469,3 +1469,35 @@ def test_backward_over_a_very_long_context_axis(B, Nc, d, separate, kn, dev):
     if names:
         assert any("gemm_bf16_kernel" in n for n in names) == separate, names  # (the 128 x 128 engine: dC, and dQ below 512 rows)
         assert any("gemm8p_bwd_kernel" in n for n in names) == (not separate or B >= 512), names
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Nc,d", [(512, 16384, 768), (320, 8200, 512), (1024, 32768, 1024), (192, 4096, 128)])
+def test_lds_dma_staged_128_tile_is_bit_identical(B, Nc, d, kn, dev):
+    """Option g128_dma (round 6, csrc/gemm128d.h): the 128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA instead
+    of global -> VGPR -> ds_write.  Same LDS images, same fragments, same MFMA order, same epilogues: dQ = G x C (A k-major, B mn-major),
+    dC = G^T x Q (both mn-major) and the stored-logits similarity GEMM (both k-major, statistics epilogue) must be BIT-identical to the
+    register-staged kernel's, ragged edges included; and equal to fp32 torch within the gradient bar."""
+    from dpr_scale_amd import _lib
+
+    gen = torch.Generator(device="cpu").manual_seed(B + d)
+    G = (torch.randn(B, Nc, generator=gen) * 0.01).to(torch.bfloat16).to(dev)
+    Qb = torch.randn(B, d, generator=gen).to(torch.bfloat16).to(dev)
+    Cb = torch.randn(Nc, d, generator=gen).to(torch.bfloat16).to(dev)
+    m8 = (torch.rand(Nc, generator=gen) < 0.05).to(torch.uint8).to(dev)
+    outs = {}
+    defaults = {k: _lib.get_option(k) for k in ("g128_dma", "tile")}
+    try:
+        _lib.set_option("tile", 0)  # (pins the 128 x 128 tile for the single-GEMM launches; the large-shape kernels stand aside)
+        for mode in (0, 1):
+            _lib.set_option("g128_dma", mode)
+            outs[mode] = (kn.dq(G, Cb, 1.0).clone(), kn.dc(G, Qb, 1.0).clone(), kn.sim(Qb, Cb, m8, 0.5).clone())
+    finally:
+        for k, v in defaults.items():
+            _lib.set_option(k, v)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    ref_dq = G.float() @ Cb.float()
+    ref_dc = G.float().t() @ Qb.float()
+    assert ((outs[1][0] - ref_dq).abs().max() / ref_dq.abs().max()).item() <= 1e-3
+    assert ((outs[1][1] - ref_dc).abs().max() / ref_dc.abs().max()).item() <= 1e-3
