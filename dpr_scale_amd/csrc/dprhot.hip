@@ -127,7 +127,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -160,7 +160,8 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_NL_P16, "nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
     {OPT_SK_DQ_ATOMIC, "sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
     {OPT_NL_MIN, "nl_min", 128, "fewest 256x256 tiles from which the forward never stores the logits (round 6: 128 -- with the one-pass forward 1024 x 8192 x 768 steps in 81 instead of 92 us, 512 x 16384 in 116 instead of 126; at 64 tiles it is a wash, at 32 it loses); the smaller of this and big_min counts"},
-    {OPT_G128_DMA, "g128_dma", 0, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
+    {OPT_G128_DMA, "g128_dma", 1, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
+    {OPT_DC_ALONE_8P, "dc_alone_8p", 0, "long context axis (512 <= B <= 2048, Nc >= 32 B): 1 = the dC tiles run ALONE on the phase-interleaved 256 x 256 kernel (gemm8pb.h) in a launch of their own, in front of the launch with the dQ units; 0 = dC on the 128 x 128 engine (dprhot_dc)"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -1520,7 +1521,10 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
   hipStream_t st = (hipStream_t)stream;
   // (the long context axis under fewer than 512 rows: both GEMMs on the 128 x 128 engine -- see `long_axis` below; 256 x 65536 x 768:
   //  146 us against 174 with the dQ units on the 256 x 256 kernel and 252 for the pair)
-  const bool long_axis_small = B < 512 && Nc >= 56 * 1024 && !sk_plan(B, Nc, d).ok && !wide_bwd_ok(B, Nc, d) && big_bwd_ok(B, Nc, d);
+  // (round 6, with the LDS-DMA 128 x 128 tile: also 512 <= B < 1024 from Nc >= 32 B on -- 512 x 16384 56 against 65 us with the dQ units on
+  //  the 256 x 256 kernel and 73 for the pair, 512 x 32768 90 / 100 / 116: profiles/r06_bwd_plan_ab.txt)
+  const bool long_axis_small = ((B < 512 && Nc >= 56 * 1024) || (B >= 512 && B < 1024 && (long)Nc >= 32L * B)) && !sk_plan(B, Nc, d).ok &&
+                               !wide_bwd_ok(B, Nc, d) && big_bwd_ok(B, Nc, d);
   if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0 || long_axis_small) {
     if (dC_part != nullptr)
       if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
@@ -1605,13 +1609,28 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     // 512 x 16384 73 / 70, 512 x 32768 117 / 112, 512 x 65536 356 / 202, 2048 x 65536 611 / 555, 1024 x 32768 x 1024 217 / 197; the
     // pair stays where it wins: 1024 x 8192 43 / 71, 1024 x 16384 82 / 96, 2048 x 16384 122 / 146, 2048 x 32768 228 / 289, 512 x 8192 33 / 50.
     const bool long_axis = B >= 512 && B <= 2048 && (long)Nc >= 32L * B;
-    if (long_axis)
-      if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
-    const int nbx1 = cdiv(d, G2_B), nby1 = long_axis ? 0 : cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
-    a1.kchunk = B;  // dC: one K range (B % 64 == 0)
-    const int grid = nbx1 * nby1 + nbx2 * nby2 * p.splits;
     const bool no8 = opt(OPT_NO_8PB) != 0;
-    if (!no8 && B % 128 == 0 && Nc % 128 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9) {
+    const bool ok8 = !no8 && B % 128 == 0 && Nc % 128 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9;
+    a1.kchunk = B;  // dC: one K range (B % 64 == 0)
+    if (long_axis && ok8 && opt(OPT_DC_ALONE_8P) != 0) {
+      // (A/B, round 6) the dC tiles alone on the phase-interleaved kernel: no dQ units four times as long next to them
+      auto k8 = gemm8p_bwd_kernel<Epi8Scale>;
+      static AttrOnce attr8a_done;
+      if (!attr8a_done) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g8_lds_total));
+        attr8a_done = true;
+      }
+      const Epi8Scale s1{e1.out, e1.M, e1.N, e1.h_scale, e1.d_scale, e1.stamp_src, e1.stamp_period, e1.stamp_row};
+      const Epi8Scale s2{e2.out, e2.M, e2.N, e2.h_scale, e2.d_scale, e2.stamp_src, e2.stamp_period, e2.stamp_row};
+      const int nbx1a = cdiv(d, G2_B), nby1a = cdiv(Nc, G2_B);
+      hipLaunchKernelGGL(k8, dim3((unsigned)(nbx1a * nby1a)), dim3(G2_THREADS), g8_lds_total, st, a1, s1, nbx1a, nby1a, a2, s2, cdiv(d, G2_B), 0, p.splits);
+      HIP_TRY(hipGetLastError());
+    } else if (long_axis) {
+      if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
+    }
+    const int nbx1 = cdiv(d, G2_B), nby1 = long_axis ? 0 : cdiv(Nc, G2_B), nbx2 = cdiv(d, G2_B), nby2 = cdiv(B, G2_B);
+    const int grid = nbx1 * nby1 + nbx2 * nby2 * p.splits;
+    if (ok8) {
       // the phase-interleaved schedule (gemm8pb.h): an even number of K steps per unit, byte offsets in 32 bits
       auto k8 = gemm8p_bwd_kernel<Epi8Scale>;
       static AttrOnce attr8_done;

@@ -52,7 +52,24 @@ __global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  // Tile order.  Workgroup L (x fastest) runs on XCD L % 8; the nx column tiles of one row block (by, bz) read the SAME A block, and
+  // in the plain order they are neighbours in L, i.e. spread over all eight XCDs at the same time: every XCD's L2 fetches that block
+  // for itself (dC = G^T Q at 1024 x 65536 x 768: the 134 MB of G went through the fabric six times, 805 MB for a 120 us GEMM).
+  // Remapped so that XCD x takes row blocks x, x + 8, ... and walks their nx column tiles one after the other: the block is fetched
+  // once per XCD that needs it.  (Whole groups of eight row blocks only; the remainder keeps the plain order.)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int nx = gridDim.x, ngr = gridDim.y * gridDim.z;
+    const int L = (bz * (int)gridDim.y + by) * nx + bx;
+    const int whole = (ngr >> 3) << 3;
+    if (L < nx * whole) {
+      const int xcd = L & 7, slot = L >> 3;
+      const int g = xcd + ((slot / nx) << 3);
+      bx = slot % nx;
+      by = g % (int)gridDim.y;
+      bz = g / (int)gridDim.y;
+    }
+  }
   const int m0 = by * G1_B, n0 = bx * G1_B;
   const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg) / G1_BK;  // (whole steps: checked by the launcher)
