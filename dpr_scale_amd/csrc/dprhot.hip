@@ -127,7 +127,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -162,6 +162,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_NL_MIN, "nl_min", 128, "fewest 256x256 tiles from which the forward never stores the logits (round 6: 128 -- with the one-pass forward 1024 x 8192 x 768 steps in 81 instead of 92 us, 512 x 16384 in 116 instead of 126; at 64 tiles it is a wash, at 32 it loses); the smaller of this and big_min counts"},
     {OPT_G128_DMA, "g128_dma", 1, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
     {OPT_DC_ALONE_8P, "dc_alone_8p", 1, "long context axis (512 <= B <= 2048, Nc >= 32 B): the dC tiles ALONE on the phase-interleaved 256 x 256 kernel (gemm8pb.h) in a launch of their own, in front of the launch with the dQ units, instead of dC on the 128 x 128 tile: 1 = where the row pitch of G is a multiple of 128 KiB (Nc = 65536: the 128-wide tiles' 256-byte pieces then alias in the memory system -- 180 us where 126 are expected -- and the 512-byte pieces of the 256-wide tile do not: backward 325 -> 275 us at 1024 x 65536, 557 -> 470 at 2048 x 65536; it LOSES at 32768 / 49152 columns: profiles/r06_dc_alone_ab.txt), 2 = always, 0 = never"},
+    {OPT_DQ_ONE_ROUND, "dq_one_round", 0, "long context axis (1024 <= B <= 2048, Nc >= 32 B): 1 = the context slices of the dQ units are cut so that the units fill the 256 CUs once (up to 32 slices), 0 = at most 16 slices"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -412,6 +413,15 @@ DqPlan dq_plan(int B, int Nc, int d) {
     // dQ units as long as dC units (K = B each): split Nc into ~Nc/B slices, at most 16
     int splits = (Nc + B - 1) / B;
     if (splits > 16) splits = 16;
+    // Long context axis (the dQ units run in a launch of their own: dprhot_inbatch_bwd's long_axis rule): ONE round of units on the
+    // 256 CUs instead -- 1024 x 65536 x 768: 12 tiles x 21 slices = 252 units where 16 slices left a quarter of the chip idle;
+    // 2048 x 65536: 24 x 10 = 240 units in one round where 24 x 16 = 384 took two (round 6)
+    if (B >= 1024 && B <= 2048 && (long)Nc >= 32L * B && opt(OPT_DQ_ONE_ROUND) != 0) {
+      const int tiles = cdiv(B, 256) * cdiv(d, 256);
+      int one = kNumCU / tiles;
+      if (one > 32) one = 32;
+      if (one >= 1 && one < (Nc + B - 1) / B) splits = one;
+    }
     if (splits < 1) splits = 1;
     p.tile = kBigTile;
     p.kchunk = cdiv(cdiv(Nc, 128), splits) * 128;  // an even number of 64-deep K steps per slice (gemm8pb.h)

@@ -1441,13 +1441,17 @@ def test_cpp_autograd_node_equals_the_python_operator(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Nc,d,separate", [(1024, 65536, 768, True), (512, 16384, 768, True), (256, 57344, 768, True), (2048, 65536, 768, True), (1024, 16384, 768, False),
-                                                    (2048, 32768, 768, False)])
-def test_backward_over_a_very_long_context_axis(B, Nc, d, separate, kn, dev):
-    """dprhot_inbatch_bwd's plan rule for few query rows against a long context axis (512 <= B <= 2048 and Nc >= 32 B: dC through the
-    128 x 128 engine in a launch of its own, dQ on the pair kernel's units; below 512 rows and from 56 Ki contexts both on the 128 x 128
-    engine: 482 -> 298 us at 1024 x 65536 x 768):
-    both gradients against fp32 matmuls of the same bf16 operands, and the launches that run are the ones the rule names.  Autograd of
+@pytest.mark.parametrize("B,Nc,d,engine128,k256", [(1024, 49152, 768, True, True), (1024, 65536, 768, False, True), (512, 16384, 768, True, False),
+                                                     (256, 57344, 768, True, False), (2048, 65536, 768, False, True), (1024, 16384, 768, False, True),
+                                                     (2048, 32768, 768, False, True)])
+def test_backward_over_a_very_long_context_axis(B, Nc, d, engine128, k256, kn, dev):
+    """dprhot_inbatch_bwd's plan rules for few query rows against a long context axis (round 5; re-measured in round 6 with the LDS-DMA
+    128 x 128 tile, profiles/r06_bwd_plan_ab.txt, r06_dc_alone_ab.txt):
+      1024 <= B <= 2048, Nc >= 32 B   dC on the 128 x 128 tile in a launch of its own, dQ on the 256 x 256 kernel's units -- except where G's
+                                      row pitch is a multiple of 128 KiB (Nc = 65536): there the dC tiles run ALONE on the 256 x 256 kernel
+      512 <= B < 1024, Nc >= 32 B     both GEMMs apart on the 128 x 128 tile (as below 512 rows from 56 Ki contexts on)
+      otherwise                       the pair launch
+    Both gradients against fp32 matmuls of the same bf16 operands, and the launches that run are the ones the rule names.  Autograd of
     dpr_task.py:98-105 into q and c."""
     from torch.profiler import ProfilerActivity, profile
 
@@ -1467,8 +1471,8 @@ def test_backward_over_a_very_long_context_axis(B, Nc, d, separate, kn, dev):
         torch.cuda.synchronize()
     names = [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
     if names:
-        assert any("gemm_bf16_kernel" in n for n in names) == separate, names  # (the 128 x 128 engine: dC, and dQ below 512 rows)
-        assert any("gemm8p_bwd_kernel" in n for n in names) == (not separate or B >= 512), names
+        assert any("gemm_bf16_kernel" in n or "gemm128d_kernel" in n for n in names) == engine128, names  # (the 128 x 128 tile, either staging)
+        assert any("gemm8p_bwd_kernel" in n for n in names) == k256, names
 
 
 @pytest.mark.gpu
