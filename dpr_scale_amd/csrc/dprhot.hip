@@ -162,7 +162,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_NL_MIN, "nl_min", 128, "fewest 256x256 tiles from which the forward never stores the logits (round 6: 128 -- with the one-pass forward 1024 x 8192 x 768 steps in 81 instead of 92 us, 512 x 16384 in 116 instead of 126; at 64 tiles it is a wash, at 32 it loses); the smaller of this and big_min counts"},
     {OPT_G128_DMA, "g128_dma", 1, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
     {OPT_DC_ALONE_8P, "dc_alone_8p", 1, "long context axis (512 <= B <= 2048, Nc >= 32 B): the dC tiles ALONE on the phase-interleaved 256 x 256 kernel (gemm8pb.h) in a launch of their own, in front of the launch with the dQ units, instead of dC on the 128 x 128 tile: 1 = where the row pitch of G is a multiple of 128 KiB (Nc = 65536: the 128-wide tiles' 256-byte pieces then alias in the memory system -- 180 us where 126 are expected -- and the 512-byte pieces of the 256-wide tile do not: backward 325 -> 275 us at 1024 x 65536, 557 -> 470 at 2048 x 65536; it LOSES at 32768 / 49152 columns: profiles/r06_dc_alone_ab.txt), 2 = always, 0 = never"},
-    {OPT_DQ_ONE_ROUND, "dq_one_round", 0, "long context axis (1024 <= B <= 2048, Nc >= 32 B): 1 = the context slices of the dQ units are cut so that the units fill the 256 CUs once (up to 32 slices), 0 = at most 16 slices"},
+    {OPT_DQ_ONE_ROUND, "dq_one_round", 1, "long context axis (1024 <= B <= 2048, Nc >= 32 B): 1 = the context slices of the dQ units are cut so that the units fill the 256 CUs once (up to 32 slices: 1536 x 65536 x 768 backward 419 -> 351 us, 2048 x 65536 497 -> 459, 1024 x 65536 294 -> 282; profiles/r06_dq_round_ab.txt), 0 = at most 16 slices"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
