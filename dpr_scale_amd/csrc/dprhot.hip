@@ -1620,7 +1620,9 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     // pair stays where it wins: 1024 x 8192 43 / 71, 1024 x 16384 82 / 96, 2048 x 16384 122 / 146, 2048 x 32768 228 / 289, 512 x 8192 33 / 50.
     const bool long_axis = B >= 512 && B <= 2048 && (long)Nc >= 32L * B;
     const bool no8 = opt(OPT_NO_8PB) != 0;
-    const bool ok8 = !no8 && B % 128 == 0 && Nc % 128 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9;
+    // (round 6: B and Nc multiples of 64 suffice -- a unit with an odd number of K steps skips the MFMAs of its last half pair; the packed
+    //  multi-rank layout's column counts are multiples of 64, rarely of 128)
+    const bool ok8 = !no8 && B % 64 == 0 && Nc % 64 == 0 && p.kchunk % 128 == 0 && (double)B * Nc < 2.0e9 && (double)Nc * d < 2.0e9;
     a1.kchunk = B;  // dC: one K range (B % 64 == 0)
     if (long_axis && ok8 && (opt(OPT_DC_ALONE_8P) == 2 || (opt(OPT_DC_ALONE_8P) == 1 && ((size_t)Nc * 2) % ((size_t)128 << 10) == 0))) {
       // (A/B, round 6) the dC tiles alone on the phase-interleaved kernel: no dQ units four times as long next to them

@@ -114,11 +114,13 @@ __device__ __forceinline__ void g8b_unit(const GemmArgs& p, const Epi& epi, int 
   }
   auto img = [&](int par, int which) { return smem + (par * 4 + which) * G8_HALF; };
   // byte offset of K step TT of this unit in the operand (K steps beyond the unit's last wrap around: fetched, never read)
+  // (a unit of ONE or TWO steps wraps twice: the fall-back is step 0 -- any address inside the unit's own K range will do)
+  auto wrap = [&](int tt) { return tt < nt ? tt : (tt - nt < nt ? tt - nt : 0); };
   auto kofsA = [&](int tt) -> size_t {
-    const size_t k = (size_t)(kbeg + (tt >= nt ? tt - nt : tt) * G2_BK);
+    const size_t k = (size_t)(kbeg + wrap(tt) * G2_BK);
     return A_KM ? k * 2 : k * (size_t)p.lda * 2;
   };
-  auto kofsB = [&](int tt) -> size_t { return (size_t)(kbeg + (tt >= nt ? tt - nt : tt) * G2_BK) * (size_t)p.ldb * 2; };
+  auto kofsB = [&](int tt) -> size_t { return (size_t)(kbeg + wrap(tt) * G2_BK) * (size_t)p.ldb * 2; };
 #define G8B_STAGE(P, KOFS, O0, O1, IMG)                                                                                             \
   {                                                                                                                                 \
     const char* base_ = reinterpret_cast<const char*>(P) + (KOFS);                                                                  \
@@ -132,9 +134,14 @@ __device__ __forceinline__ void g8b_unit(const GemmArgs& p, const Epi& epi, int 
     else af[a_ * 4 + k_] = g8_trfrag32((IMG), wm * 64 + a_ * 32, k_, lane);                                                         \
   }
 #define G8B_RD_B(DST, IMG) _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) DST[k_] = g8_trfrag32((IMG), wn * 32, k_, lane);
-#define G8B_MM(AH, BH, BQ)                                                                                                          \
-  _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                                 \
-      acc.v[(AH) * 2 + a_][(BH)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BQ[k_], af[a_ * 4 + k_], acc.v[(AH) * 2 + a_][(BH)], 0, 0, 0);
+// (LIVE: false only in the second K step of the last pair when the unit has an ODD number of K steps -- round 6: column counts of the
+//  packed multi-rank layout are multiples of 64, rarely of 128; the step's DMAs and fragment reads run as always, on wrapped-around
+//  addresses, and only its MFMAs are skipped: a scalar branch per phase in that one step)
+#define G8B_MM(AH, BH, BQ, LIVE)                                                                                                    \
+  if (LIVE) {                                                                                                                       \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) _Pragma("unroll") for (int a_ = 0; a_ < 2; ++a_)                               \
+        acc.v[(AH) * 2 + a_][(BH)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BQ[k_], af[a_ * 4 + k_], acc.v[(AH) * 2 + a_][(BH)], 0, 0, 0); \
+  }
 
   bf16x8 af[8], bq[2][4];
   G8Acc acc;
@@ -157,39 +164,39 @@ __device__ __forceinline__ void g8b_unit(const GemmArgs& p, const Epi& epi, int 
 
   if (wm == 1) g8_bar();  // this wave group runs one barrier behind from here on
   for (int t = 0; t < nt; t += 2) {
-#define G8B_KSTEP(PAR, T)                                                                \
+#define G8B_KSTEP(PAR, T, LIVE)                                                          \
   {                                                                                      \
     /* p0 */                                                                             \
     G8B_RD_A(img(PAR, 0));                                                               \
     G8B_STAGE(p.A, kofsA((T) + 1), oa10, oa11, img((PAR) ^ 1, 1));                       \
     g8_bar();                                                                            \
     g8_wait_lgkm0();                                                                     \
-    G8B_MM(0, 0, bq[PAR]);                                                               \
+    G8B_MM(0, 0, bq[PAR], LIVE);                                                         \
     g8_bar();                                                                            \
     /* p1 */                                                                             \
     G8B_RD_B(bq[(PAR) ^ 1], img(PAR, 3));                                                \
     G8B_STAGE(p.B, kofsB((T) + 2), ob00, ob01, img(PAR, 2));                             \
     g8_bar();                                                                            \
     g8_wait_lgkm0();                                                                     \
-    G8B_MM(0, 1, bq[(PAR) ^ 1]);                                                         \
+    G8B_MM(0, 1, bq[(PAR) ^ 1], LIVE);                                                   \
     g8_bar();                                                                            \
     /* p2 */                                                                             \
     G8B_RD_A(img(PAR, 1));                                                               \
     G8B_STAGE(p.A, kofsA((T) + 2), oa00, oa01, img(PAR, 0));                             \
     g8_bar();                                                                            \
     g8_wait_lgkm0();                                                                     \
-    G8B_MM(1, 1, bq[(PAR) ^ 1]);                                                         \
+    G8B_MM(1, 1, bq[(PAR) ^ 1], LIVE);                                                   \
     g8_bar();                                                                            \
     /* p3 */                                                                             \
     G8B_RD_B(bq[(PAR) ^ 1], img((PAR) ^ 1, 2));                                          \
     G8B_STAGE(p.B, kofsB((T) + 2), ob10, ob11, img(PAR, 3));                             \
     g8_bar();                                                                            \
     g8_wait_lgkm0();                                                                     \
-    G8B_MM(1, 0, bq[PAR]);                                                               \
+    G8B_MM(1, 0, bq[PAR], LIVE);                                                         \
     g8_bar();                                                                            \
   }
-    G8B_KSTEP(0, t);
-    G8B_KSTEP(1, t + 1);
+    G8B_KSTEP(0, t, true);
+    G8B_KSTEP(1, t + 1, t + 1 < nt);
   }
   if (wm == 0) g8_bar();  // both wave groups in step again
   g8_wait_vm<0>();        // the wrap-around fetches: nothing may still be writing LDS when the workgroup ends

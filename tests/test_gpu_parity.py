@@ -1443,7 +1443,10 @@ def test_cpp_autograd_node_equals_the_python_operator(dev):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Nc,d,engine128,k256", [(1024, 49152, 768, True, True), (1024, 65536, 768, False, True), (512, 16384, 768, True, False),
                                                      (256, 57344, 768, True, False), (2048, 65536, 768, False, True), (1024, 16384, 768, False, True),
-                                                     (2048, 32768, 768, False, True)])
+                                                     (2048, 32768, 768, False, True),
+                                                     # round 6: units with an ODD number of 64-deep K steps on the 256 x 256 kernel (packed-layout column
+                                                     # counts are multiples of 64, rarely of 128): dC K = 320 = 5 steps, dQ slices of 10 / 9 steps; 1025 steps
+                                                     (320, 8256, 768, False, True), (1024, 65600, 768, True, True)])
 def test_backward_over_a_very_long_context_axis(B, Nc, d, engine128, k256, kn, dev):
     """dprhot_inbatch_bwd's plan rules for few query rows against a long context axis (round 5; re-measured in round 6 with the LDS-DMA
     128 x 128 tile, profiles/r06_bwd_plan_ab.txt, r06_dc_alone_ab.txt):
