@@ -157,7 +157,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_SK_TAIL, "sk_tail", 0, "fused few-rows backward: 1 = the dQ slabs are folded by the last workgroups of the backward launch itself, behind a count of the dQ units (write-through slab stores, sc1 loads; no sk_dq_finish launch), 2 = the same with ordinary stores + one release fence per dQ unit and an acquire fence in the finishing role; 0 = the finishing launch (measured: scratch/negative/README.md, round 5)"},
     {OPT_SK_DC_REGSCALE, "sk_dc_regscale", 0, "fused few-rows backward, dC units: 1 = the Q fragments are scaled by f in registers between the transpose read and the MFMA (no scale pass over the LDS image, one workgroup barrier less; measured: the pass's 0.75 us reappear in the MFMA loop, step 25.7-25.8 against 25.3-25.6 us), 0 = the scale pass of round 4"},
     {OPT_G8_ONE_TILE, "g8_one_tile", 0, "storing epilogues of the phase-interleaved 256 x 256 kernel (dScores pass, stored logits): 1 = one workgroup per tile instead of persistent workgroups (a finished workgroup's stores drain under its successor's prologue)"},
-    {OPT_NL_P16, "nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 2 = the same on the four-phase schedule; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
+    {OPT_NL_P16, "nl_p16", 1, "no-logits forward with the dScores wanted: 1 = ONE pass of the GEMM (strip statistics + the tile's fp16 softmax numerators, Epi8StatsP, two-phase schedule) and a row kernel that rescales them into G in place; 0 = two GEMM passes (statistics, then the logits recomputed into G: Epi8G)"},
     {OPT_SK_DQ_ATOMIC, "sk_dq_atomic", 0, "fused few-rows backward: 1 = the dQ units scale their tiles to the row softmax themselves and ADD them into dQ (global_atomic_add_f32; dQ zero-filled by the sim launch): no slabs, no finishing launch -- dQ reproducible to rounding, not to the bit; 0 = slice-normalised slabs + sk_dq_finish_kernel (bit-reproducible)"},
     {OPT_NL_MIN, "nl_min", 128, "fewest 256x256 tiles from which the forward never stores the logits (round 6: 128 -- with the one-pass forward 1024 x 8192 x 768 steps in 81 instead of 92 us, 512 x 16384 in 116 instead of 126; at 64 tiles it is a wash, at 32 it loses); the smaller of this and big_min counts"},
     {OPT_G128_DMA, "g128_dma", 1, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
@@ -1483,7 +1483,7 @@ int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc
     epi.npart = cdiv(Nc, G2_B) * 4;
     epi.P = G;
     GemmArgs a8{Q, C, B, Nc, d, d, d, d};
-    if (int rc = (opt(OPT_NL_P16) == 2 ? launch_g8<Epi8StatsP, 4>(a8, epi, st) : launch_g8<Epi8StatsP, 2>(a8, epi, st))) return rc;
+    if (int rc = launch_g8<Epi8StatsP, 2>(a8, epi, st)) return rc;  // (two-phase schedule, as every storing epilogue; the four-phase instantiation spilled two registers)
     hipLaunchKernelGGL(g8_lse_p2g_kernel, dim3((unsigned)B), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart,
                        reinterpret_cast<const float*>(ws + wl.gold), B, Nc, y, y_offset, grad_scale, reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss,
                        reinterpret_cast<float*>(ws + wl.rloss), G);

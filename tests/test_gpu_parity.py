@@ -1052,7 +1052,7 @@ def test_no_logits_forward_equals_the_two_launch_plan(B, Nc, d, kn, dev):
 @pytest.mark.parametrize("B,Nc,d", [(4096, 4096, 768), (1000, 16392, 128), (1024, 32768, 1024), (4100, 4360, 768)])
 def test_one_pass_forward_equals_the_two_pass_forward(B, Nc, d, kn, dev):
     """Option nl_p16 (round 6): the no-logits forward with the dScores wanted as ONE pass of the GEMM (strip statistics + fp16 softmax
-    numerators, then the row kernel that rescales them into G in place; both schedules) against the two-pass forward (statistics GEMM,
+    numerators, then the row kernel that rescales them into G in place) against the two-pass forward (statistics GEMM,
     then the logits recomputed into G): row logsumexp, row loss and the loss sum BIT-IDENTICAL (same statistics, same order), G at most
     one bf16 ulp apart, masked columns exactly 0, and against fp32 torch on stored logits."""
     from dpr_scale_amd import _lib
@@ -1061,13 +1061,13 @@ def test_one_pass_forward_equals_the_two_pass_forward(B, Nc, d, kn, dev):
     m8[y[B // 2:]] = 0  # (the first half of the gold columns may stay masked: -inf gold logit, loss +inf, G[gold] = -scale)
     outs = {}
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1):
             _lib.set_option("nl_p16", mode)
             outs[mode] = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
     finally:
         _lib.set_option("nl_p16", 1)
     rl0, lse0, ls0, G0, _ = outs[0]
-    for mode in (1, 2):
+    for mode in (1,):
         rl, lse, ls, G, _ = outs[mode]
         assert torch.equal(lse, lse0) and torch.equal(rl, rl0)
         assert torch.equal(ls, ls0) or (not math.isfinite(ls0.item()) and not math.isfinite(ls.item()))
@@ -1076,7 +1076,8 @@ def test_one_pass_forward_equals_the_two_pass_forward(B, Nc, d, kn, dev):
         cols = torch.nonzero(m8).flatten()
         keep = cols[~torch.isin(cols, y)]
         assert torch.all(g1[:, keep] == 0)
-    assert torch.equal(outs[1][3], outs[2][3])  # the two schedules are bit-identical
+    rerun = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
+    assert torch.equal(outs[1][3], rerun[3]) and torch.equal(outs[1][1], rerun[1])  # (reruns are bit-identical)
     S = kn.sim(Qb, Cb, m8, 0.5)
     ref = torch.softmax(S, dim=1)
     fin = torch.isfinite(lse0)
