@@ -317,6 +317,8 @@ def roofline_cfg3_rank(dev, d=768, B=128, K=8, W=8):
            "frac": round(algo / us * 1e-3 / HBM_PEAK_GBS, 4), "flops": 6 * bn * d,
            "mfma_frac": round(6 * bn * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4),
            "operator_path_step_us": op_us, "operator_path": "dprhot_train_step_packed_f32 (dQ slabs deferred) + dprhot_rescale_grads"}
+    out["dq_reduction"] = ("slice-normalised slabs + finishing launch (bit-reproducible); option sk_dq_atomic (fp32 atomics, no finishing launch) "
+                           "measured 2 us SLOWER at this shape: profiles/r06_sk_atomic.txt")
     if isinstance(op_us.get("fp32_wire"), float):
         out["operator_path_frac_fp32_wire"] = round(algo / op_us["fp32_wire"] * 1e-3 / HBM_PEAK_GBS, 4)
     if isinstance(op_us.get("bf16_wire"), float):
