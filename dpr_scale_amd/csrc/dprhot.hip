@@ -227,6 +227,11 @@ int pick_tile(int M, int N, int K, int splits_hint, int want) {
     return wg64 >= want / 2 ? 4 : 5;
   }
   const int first = M <= 64 ? 1 : 0;
+  // (round 6: the 128 x 128 tile is the LDS-DMA kernel now and wins earlier -- 768 x 8192 x 768 stored-logits GEMM 30.0 -> 22.6 us with 384
+  //  workgroups where the plan wanted 512 and took 64 x 128 tiles; a tie at 256 workgroups, a loss below: scratch/sim_tile_ab.py)
+  if (first == 0 && opt(OPT_G128_DMA) != 0 && K % 64 == 0 &&
+      (long)cdiv(M, kTiles[0].bm) * cdiv(N, kTiles[0].bn) * splits_hint * 8 >= (long)want * 5)
+    return 0;
   for (int t = first; t <= 2; ++t) {
     const long wgs = (long)cdiv(M, kTiles[t].bm) * cdiv(N, kTiles[t].bn) * splits_hint;
     if (wgs >= want) return t;
