@@ -925,7 +925,11 @@ int dprhot_prep(const float* q, size_t nq, dprhot_bf16* Qb, const float* c, size
 int dprhot_packed_rows(int n_ctx, int d, int* h_rows) {
   REQUIRE(h_rows != nullptr && n_ctx > 0 && d > 0 && d % 8 == 0, "bad argument");
   const int extra = cdiv(n_ctx, 2 * d);           // rows needed for n_ctx mask bytes
-  *h_rows = cdiv(n_ctx + extra, 8) * 8;           // gathered column count stays a multiple of 8
+  // gathered column count stays a multiple of 8 -- and, from 2048 contexts per rank on (round 6), of 64: the 256 x 256 backward wants
+  // whole 64-deep K steps over the gathered axis, and W x 8200 columns (8192 contexts + 8 header rows) sent a large-batch multi-rank
+  // step to the 128 x 128 pair kernel; the (at most 56) extra rows are masked columns like every header row
+  const int align = n_ctx >= 2048 ? 64 : 8;
+  *h_rows = cdiv(n_ctx + extra, align) * align;
   return DPRHOT_OK;
 }
 

@@ -76,7 +76,7 @@ int dprhot_prep(const float* q, size_t nq, dprhot_bf16* Qb, const float* c, size
 /* Multi-rank gather in ONE collective (the reference issues four all_gathers, dpr_task.py:169-176).
  * dprhot_pack_ctx writes this rank's all-gather send buffer [rows_c, d] bf16: rows [0, n_ctx) = the context rows
  * (fp32 -> bf16 RNE), followed by rows whose bytes carry the dummy-context mask (mask may be NULL = no dummies).
- * rows_c = dprhot_packed_rows(n_ctx, d) (a multiple of 8).  After all-gathering W such buffers back to back, the
+ * rows_c = dprhot_packed_rows(n_ctx, d) (a multiple of 8; of 64 from n_ctx = 2048 on).  After all-gathering W such buffers back to back, the
  * result IS the context matrix C [W*rows_c, d] of every other entry point -- the mask rows are just extra columns
  * that dprhot_unpack_mask marks as masked in the column mask it builds ([W*rows_c] bytes).  The label offset of
  * rank r becomes r * rows_c, and rank r's gradient is the first n_ctx rows of its reduce-scatter chunk. */

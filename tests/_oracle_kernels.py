@@ -23,7 +23,8 @@ class OracleKernels:
 
     def packed_rows(self, n_ctx, d):
         extra = -(-n_ctx // (2 * d))
-        return -(-(n_ctx + extra) // 8) * 8
+        align = 64 if n_ctx >= 2048 else 8  # (as dprhot_packed_rows: whole 64-deep K steps over the gathered axis for large batches)
+        return -(-(n_ctx + extra) // align) * align
 
     def pack_ctx(self, c, m8, send):
         n_ctx, d = c.shape
