@@ -25,8 +25,8 @@ def main():
     ap.add_argument("--shapes", default=DEFAULT)
     ap.add_argument("--opt", default="", help="comma list of library options name=value (dprhot_set_option) applied before the sweep, e.g. big_min=64")
     a = ap.parse_args()
+    from dpr_scale_amd import _lib
     if a.opt:
-        from dpr_scale_amd import _lib
         for kv in a.opt.split(","):
             k, v = kv.split("=")
             _lib.set_option(k, int(v))
@@ -46,14 +46,18 @@ def main():
         }
         if hp.nl:  # no-logits forward: the dScores come from a GEMM pass that recomputes the logits (two-pass form), or the whole forward
             kern["dscores"] = (hp.k_dscores, 2 * (bd + nd) + 2 * bn, 2 * bn * d)   # is ONE GEMM pass + a row kernel (fwd_bf16)
-        kern["fwd_bf16"] = (hp.k_fwd, 2 * (bd + nd) + (4 * bn if hp.nl else 10 * bn), 2 * bn * d)   # dprhot_inbatch_fwd: everything up to G and the loss
+        kern["fwd_bf16"] = (hp.k_fwd, 2 * (bd + nd) + (4 * bn if (hp.nl or _lib.fwd_one_pass(B, Nc, d)) else 10 * bn), 2 * bn * d)   # dprhot_inbatch_fwd: everything up to G and the loss
         kern["bwd_pair"] = (hp.k_bwd, 4 * bn + 6 * (bd + nd), 4 * bn * d)
         # THE STEP: one call of dprhot_inbatch_step_f32 (fp32 embeddings in, dQ / dC_part out) -- what a training iteration runs.  (Until
         # round 5 `step_us` was the SUM of the rows above, which counts the similarity GEMM twice -- sim_stats_f32 and prep + sim_stats_bf16
         # are alternatives, a step runs one of them: 1024 x 8192 read 133 us where the step takes ~95.)
         kern["step"] = (hp.k_step, (4 * bd + 4 * nd) + (2 * (bd + nd) + 4 * bn) + 4 * bn + 6 * (bd + nd), 6 * bn * d)
         reps = 20 if bn * d < 1e11 else 4
-        row = {"B": B, "Nc": Nc, "d": d, "forward_plan": "no-logits" if hp.nl else "logits"}
+        # forward_plan: what the separate calls do (sim_stats / softmax_finish rows); fused_forward: how fwd_bf16 and the step form G
+        # (dprhot_fwd_one_pass: 0 logits stored, 1 one pass on the 256 x 256 tile, 2 one pass on the 128 x 128 LDS-DMA tile)
+        one = _lib.fwd_one_pass(B, Nc, d)
+        row = {"B": B, "Nc": Nc, "d": d, "forward_plan": "no-logits" if hp.nl else "logits",
+               "fused_forward": ("logits stored", "one pass, 256 x 256 tile", "one pass, 128 x 128 tile")[one]}
         for name, (fn, by, fl) in kern.items():
             us = time_kernel(hp, fn, reps=reps, iters=5)
             row[name] = {"us": round(us, 2), "GBps": round(by / us * 1e-3, 1), "hbm_frac": round(by / us * 1e-3 / HBM_PEAK_GBS, 4),

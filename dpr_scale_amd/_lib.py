@@ -98,6 +98,7 @@ SIGNATURES = {
     "dprhot_allgather_allpairs": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dprhot_comm_has_allpairs": (c_int, [c_void_p]),
     "dprhot_fwd_no_logits": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
+    "dprhot_fwd_one_pass": (c_int, [c_int, c_int, c_int, POINTER(c_int)]),
     "dprhot_reducescatter_allpairs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "dprhot_inbatch_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -171,6 +172,14 @@ def fwd_no_logits(B: int, Nc: int, d: int) -> bool:
     out = c_int(0)
     check(lib.dprhot_fwd_no_logits(B, Nc, d, ctypes.byref(out)), "dprhot_fwd_no_logits")
     return bool(out.value)
+
+
+def fwd_one_pass(B: int, Nc: int, d: int) -> int:
+    """How the fused forward forms G without stored logits (dprhot_fwd_one_pass): 0 logits stored, 1 one pass on the 256 x 256 tile,
+    2 one pass on the 128 x 128 LDS-DMA tile."""
+    out = c_int(0)
+    check(lib.dprhot_fwd_one_pass(B, Nc, d, ctypes.byref(out)), "dprhot_fwd_one_pass")
+    return int(out.value)
 
 
 def workspace_bytes(B: int, Nc: int, d: int) -> int:

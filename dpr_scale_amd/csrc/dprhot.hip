@@ -84,6 +84,10 @@ struct LossScaleScope {
   explicit LossScaleScope(float s) { g_loss_scale = s; }
   ~LossScaleScope() { g_loss_scale = 1.0f; }
 };
+// The one-call training step may carry the sum of the row losses into the launch that combines its dQ slabs (splitk_reduce_loss_kernel):
+// `armed` while its forward runs, `pending` from the forward's skipped launch until launch_dq (or the step's own fall-back) consumes it.
+struct LossDefer { bool armed = false, pending = false; const float* src = nullptr; int n = 0; float scale = 1.f; float* out = nullptr; };
+thread_local LossDefer g_loss_defer;
 
 // dC_part as bf16 (the reduce-scatter's wire format written by the dC epilogue): set by dprhot_train_step_* for the plans that have
 // such an epilogue (the skinny step); every other plan refuses while it is set
@@ -127,7 +131,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -163,6 +167,10 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_G128_DMA, "g128_dma", 1, "128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA (gemm128d.h) instead of global -> VGPR -> ds_write (gemm_bf16.h): 1 = wherever the launch qualifies (bf16 operands, whole 64-deep K steps, 32-bit offsets); 0 = never"},
     {OPT_DC_ALONE_8P, "dc_alone_8p", 1, "long context axis (512 <= B <= 2048, Nc >= 32 B): the dC tiles ALONE on the phase-interleaved 256 x 256 kernel (gemm8pb.h) in a launch of their own, in front of the launch with the dQ units, instead of dC on the 128 x 128 tile: 1 = where the row pitch of G is a multiple of 128 KiB (Nc = 65536: the 128-wide tiles' 256-byte pieces then alias in the memory system -- 180 us where 126 are expected -- and the 512-byte pieces of the 256-wide tile do not: backward 325 -> 275 us at 1024 x 65536, 557 -> 470 at 2048 x 65536; it LOSES at 32768 / 49152 columns: profiles/r06_dc_alone_ab.txt), 2 = always, 0 = never"},
     {OPT_DQ_ONE_ROUND, "dq_one_round", 1, "long context axis (1024 <= B <= 2048, Nc >= 32 B): 1 = the context slices of the dQ units are cut so that the units fill the 256 CUs once (up to 32 slices: 1536 x 65536 x 768 backward 419 -> 351 us, 2048 x 65536 497 -> 459, 1024 x 65536 294 -> 282; profiles/r06_dq_round_ab.txt), 0 = at most 16 slices"},
+    {OPT_DQ_CAP_FEW, "dq_cap_few", 0, "256 x 256 backward pair under 512 query rows: the most context slices a dQ tile is cut into; 0 = the rule (16, or 32 where 16 slices already take more than one round of the 256 CUs), else that many"},
+    {OPT_LOSS_WITH_DQ, "loss_with_dq", 1, "one-call training step on the no-logits forward, single rank: 1 = the sum of the row losses is formed by one more workgroup of the launch that combines the dQ slabs (same arithmetic as reduce_sum_kernel) instead of a launch of its own between forward and backward; 0 = its own launch"},
+    {OPT_NL128, "nl128", 1, "training forward (dScores wanted, logits not) in ONE pass on the 128 x 128 LDS-DMA tile (EpiSimP: strip statistics + fp16 softmax numerators, then the row kernel of the 256 x 256 family) where the 256-wide tiles would leave most of the chip idle: 1 = on, 0 = the logits-storing forward (sim GEMM with fp32 S, streaming softmax) there"},
+    {OPT_NL128_BELOW, "nl128_below", 256, "the 128-tile one-pass forward takes the shapes with fewer 256 x 256 tiles than this (256 = every shape that cannot give each CU a 256-wide tile; 128 = only the shapes the 256 x 256 no-logits forward does not take)"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -214,6 +222,15 @@ bool nl_ok(int M, int N, int K) {
   const int need = big_min_wgs() < opt(OPT_NL_MIN) ? big_min_wgs() : opt(OPT_NL_MIN);
   const bool big = M > 128 && K % 64 == 0 && K >= 128 && big_min_wgs() > 0 && wgs >= need;  // (big_ok with this plan's own tile count)
   return !opt(OPT_NO_NL) && force_tile() < 0 && big && K % 128 == 0 && (double)M * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
+}
+
+// One-pass training forward on the 128 x 128 LDS-DMA tile (EpiSimP + g8_lse_p2g_kernel): more than 128 rows, whole 64-deep K steps,
+// at least half a chip of 128-wide tiles, fewer 256-wide tiles than option nl128_below; 32-bit element offsets.
+bool nl128_ok(int M, int N, int K) {
+  if (!opt(OPT_NL128) || opt(OPT_NO_NL) || !opt(OPT_G128_DMA) || !opt(OPT_NL_P16) || force_tile() >= 0) return false;
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= 128 && t256 < opt(OPT_NL128_BELOW) &&
+         (double)M * K < 4.0e9 && (double)N * K < 4.0e9 && (N + 63) / 64 <= 1024 * 64;
 }
 
 // Tile for D[M,N] with contraction length K: the largest tile (BM capped by M) that still yields `want`
@@ -417,7 +434,17 @@ DqPlan dq_plan(int B, int Nc, int d) {
   if (p.big) {
     // dQ units as long as dC units (K = B each): split Nc into ~Nc/B slices, at most 16
     int splits = (Nc + B - 1) / B;
-    if (splits > 16) splits = 16;
+    // at most 16 slices (bounds the fp32 slab traffic) -- 32 under 512 rows when the launch takes more than one round of the chip anyway:
+    // the dQ units are then as short as the dC units (K = B) instead of the long pole at the end of the grid.  Measured, step us
+    // (profiles/r06_dq_cap_ab.txt): 256 x 32768 172.6 -> 146.6, 384 x 16384 116.5 -> 107.4, 448 x 16384 124.1 -> 113.5; where 16 slices
+    // fit one round, 32 lose or change nothing (256 x 16384 86.0 -> 100.3, 256 x 8192 60.2 -> 60.9).
+    int cap = 16;
+    if (B < 512) {
+      const int forced = opt(OPT_DQ_CAP_FEW);
+      const long at16 = (long)cdiv(Nc, 256) * cdiv(d, 256) + (long)cdiv(B, 256) * cdiv(d, 256) * 16;
+      cap = forced > 0 ? forced : (at16 > kNumCU ? 32 : 16);
+    }
+    if (splits > cap) splits = cap;
     // Long context axis (the dQ units run in a launch of their own: dprhot_inbatch_bwd's long_axis rule): ONE round of units on the
     // 256 CUs instead -- 1024 x 65536 x 768: 12 tiles x 21 slices = 252 units where 16 slices left a quarter of the chip idle;
     // 2048 x 65536: 24 x 10 = 240 units in one round where 24 x 16 = 384 took two (round 6)
@@ -627,6 +654,18 @@ bool wide_bwd_ok(int B, int Nc, int d) {
          B % 32 == 0 && Nc % 8 == 0 && Nc >= 64 && Nc <= 1536 && (double)Nc * d < 4.0e9;
 }
 
+// the loss launch of the no-logits forward -- or, inside the one-call step, a note for launch_dq
+int launch_loss_sum(const float* src, int n, float scale, float* out, hipStream_t st) {
+  if (g_loss_defer.armed) {
+    g_loss_defer.pending = true;
+    g_loss_defer.src = src; g_loss_defer.n = n; g_loss_defer.scale = scale; g_loss_defer.out = out;
+    return DPRHOT_OK;
+  }
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, src, n, scale, out);
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
               char* ws, const WsLayout& wl, hipStream_t st, bool gemm_too) {
   DqPlan p = dq_plan(B, Nc, d);
@@ -643,8 +682,14 @@ int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
   if (p.splits > 1) {
     const size_t n4 = (size_t)B * d / 4;
     const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
-                       p.splits, n4, h_scale, d_scale, dQ);
+    if (g_loss_defer.pending) {
+      g_loss_defer.pending = false;
+      hipLaunchKernelGGL(splitk_reduce_loss_kernel, dim3(blocks + 1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
+                         p.splits, n4, h_scale, d_scale, dQ, g_loss_defer.src, g_loss_defer.n, g_loss_defer.scale, g_loss_defer.out);
+    } else {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
+                         p.splits, n4, h_scale, d_scale, dQ);
+    }
     HIP_TRY(hipGetLastError());
   }
   return DPRHOT_OK;
@@ -1337,9 +1382,8 @@ int dprhot_softmax_finish(const float* S_in, int B, int Nc, int d, const int64_t
     hipLaunchKernelGGL(g8_lse_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.part_m),
                        reinterpret_cast<const float*>(ws + wl.part_s), cdiv(Nc, G2_B) * 4, reinterpret_cast<const float*>(ws + wl.gold), B,
                        reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss, reinterpret_cast<float*>(ws + wl.rloss));
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum);
     HIP_TRY(hipGetLastError());
-    return DPRHOT_OK;
+    return launch_loss_sum(reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum, st);
   }
   const FwdPlan fp = fwd_plan(B, Nc, d);  // same plan as dprhot_sim_stats -> same intermediate layout
   if (fp.short_rows) {
@@ -1465,14 +1509,44 @@ int dprhot_sim_rank_loss(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int 
   hipLaunchKernelGGL(g8_rank_finish_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, count, B, rank);
   hipLaunchKernelGGL(g8_lse_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart, gold, B,
                      reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss, reinterpret_cast<float*>(ws + wl.rloss));
-  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum);
   HIP_TRY(hipGetLastError());
-  return DPRHOT_OK;
+  return launch_loss_sum(reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum, st);
 }
 
 int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc, int d, const int64_t* y, int64_t y_offset,
                        const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss, float* row_lse,
                        float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
+  if (S_out == nullptr && G != nullptr && nl128_ok(B, Nc, d)) {
+    // the same one-pass forward on the 128 x 128 LDS-DMA tile (round 6): the shapes whose 256-wide tiles cannot fill the chip
+    REQUIRE(Q && C && y && loss_sum, "NULL pointer");
+    if (int rc = check_shape(B, Nc, d)) return rc;
+    REQUIRE(aligned16(Q) && aligned16(C) && aligned16(G), "pointers must be 16-byte aligned");
+    const WsLayout wl = ws_layout(B, Nc, d);
+    if (workspace == nullptr || workspace_bytes < wl.total)
+      return fail(DPRHOT_E_WORKSPACE, "inbatch_fwd needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+    REQUIRE(aligned16(workspace), "workspace must be 16-byte aligned");
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    EpiSimP epi;
+    static_cast<EpiSim&>(epi) = with_packed_mask(EpiSim{nullptr, colmask, B, Nc, inv_T, reinterpret_cast<float*>(ws + wl.part_m),
+                                                        reinterpret_cast<float*>(ws + wl.part_s), y, y_offset,
+                                                        reinterpret_cast<float*>(ws + wl.gold), nullptr, 0});
+    epi.P = G;
+    epi.npart = cdiv(Nc, 64);
+    GemmArgs a{Q, C, B, Nc, d, d, d, d};
+    auto kern = gemm128d_kernel<true, true, EpiSimP, false>;
+    static AttrOnce attr_done;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g1_lds_bytes));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(Nc, 128), cdiv(B, 128), 1), dim3(256), g1_lds_bytes, st, a, epi);
+    hipLaunchKernelGGL(g8_lse_p2g_kernel, dim3((unsigned)B), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart,
+                       reinterpret_cast<const float*>(ws + wl.gold), B, Nc, y, y_offset, grad_scale, reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss,
+                       reinterpret_cast<float*>(ws + wl.rloss), G);
+    HIP_TRY(hipGetLastError());
+    return launch_loss_sum(reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum, st);
+  }
   if (S_out == nullptr && G != nullptr && nl_ok(B, Nc, d) && opt(OPT_NL_P16) != 0) {
     // no-logits forward in ONE pass of the GEMM (round 6): strip statistics + fp16 softmax numerators into the G buffer (Epi8StatsP),
     // then one row kernel: logsumexp / loss, and the numerators rescaled into the bf16 dScores in place
@@ -1496,9 +1570,8 @@ int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc
     hipLaunchKernelGGL(g8_lse_p2g_kernel, dim3((unsigned)B), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart,
                        reinterpret_cast<const float*>(ws + wl.gold), B, Nc, y, y_offset, grad_scale, reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss,
                        reinterpret_cast<float*>(ws + wl.rloss), G);
-    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum);
     HIP_TRY(hipGetLastError());
-    return DPRHOT_OK;
+    return launch_loss_sum(reinterpret_cast<const float*>(ws + wl.rloss), B, g_loss_scale, loss_sum, st);
   }
   if (S_out == nullptr && nl_ok(B, Nc, d)) {
     // no-logits forward: statistics pass -> logsumexp / loss -> dScores pass (logits recomputed); S is never in memory
@@ -1517,7 +1590,7 @@ int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc
 int dprhot_inbatch_fwd_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d, const int64_t* y,
                            int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale, float* S_out, float* row_loss,
                            float* row_lse, float* loss_sum, dprhot_bf16* G, void* workspace, size_t workspace_bytes, void* stream) {
-  if (S_out == nullptr && B > 128 && nl_ok(B, Nc, d)) {  // cast once, then the no-logits forward on the bf16 copies
+  if (S_out == nullptr && B > 128 && (nl_ok(B, Nc, d) || (G != nullptr && nl128_ok(B, Nc, d)))) {  // cast once, then the no-logits forward on the bf16 copies
     REQUIRE(q && Qb && Cb && y, "NULL pointer");
     if (c != nullptr) {
       if (int rc = dprhot_prep(q, (size_t)B * d, Qb, c, (size_t)Nc * d, Cb, stream)) return rc;
@@ -1698,6 +1771,13 @@ int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants) {
   return DPRHOT_OK;
 }
 
+int dprhot_fwd_one_pass(int B, int Nc, int d, int* h_kind) {
+  REQUIRE(h_kind != nullptr, "NULL pointer");
+  if (int rc = check_shape(B, Nc, d)) return rc;
+  *h_kind = nl128_ok(B, Nc, d) ? 2 : (nl_ok(B, Nc, d) && opt(OPT_NL_P16) != 0 ? 1 : 0);
+  return DPRHOT_OK;
+}
+
 int dprhot_fwd_no_logits(int B, int Nc, int d, int* h_nl) {
   REQUIRE(h_nl != nullptr, "NULL pointer");
   if (int rc = check_shape(B, Nc, d)) return rc;
@@ -1734,10 +1814,19 @@ int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dpr
     }
   }
   if (!small_step_ok(B, Nc, d)) {
-    if (int rc = dprhot_inbatch_fwd_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, S_out, row_loss, row_lse,
-                                        loss_sum, G, workspace, workspace_bytes, stream))
-      return rc;
-    return dprhot_inbatch_bwd(G, Qb, Cb, B, Nc, d, h_scale, d_scale, dQ, dC_part, workspace, workspace_bytes, stream);
+    // (single rank only: the packed step's backward stamps the finished loss into dC_part, so it must exist before that launch)
+    g_loss_defer.armed = g_packed.stamp_src == nullptr && opt(OPT_LOSS_WITH_DQ) != 0;
+    g_loss_defer.pending = false;
+    int rc = dprhot_inbatch_fwd_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, grad_scale, S_out, row_loss, row_lse, loss_sum, G,
+                                    workspace, workspace_bytes, stream);
+    g_loss_defer.armed = false;
+    if (rc == DPRHOT_OK) rc = dprhot_inbatch_bwd(G, Qb, Cb, B, Nc, d, h_scale, d_scale, dQ, dC_part, workspace, workspace_bytes, stream);
+    if (g_loss_defer.pending) {  // a backward without a slab-combining launch (or one that failed): the loss launch after all
+      g_loss_defer.pending = false;
+      const int rc2 = launch_loss_sum(g_loss_defer.src, g_loss_defer.n, g_loss_defer.scale, g_loss_defer.out, (hipStream_t)stream);
+      if (rc == DPRHOT_OK) rc = rc2;
+    }
+    return rc;
   }
   if (int rc = dprhot_sim_stats_f32(q, c, Qb, Cb, B, Nc, d, y, y_offset, colmask, inv_T, nullptr, workspace, workspace_bytes, stream))
     return rc;

@@ -45,7 +45,7 @@ __device__ __forceinline__ void g1_frag(bf16x8& out, bf16x4& lo, bf16x4& hi, con
   }
 }
 
-template <bool A_KM, bool B_KM, class Epi>
+template <bool A_KM, bool B_KM, class Epi, bool REMAP = true>
 __global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
   constexpr int TM = 4, TN = 4;
@@ -57,8 +57,13 @@ __global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
   // for itself (dC = G^T Q at 1024 x 65536 x 768: the 134 MB of G went through the fabric six times, 805 MB for a 120 us GEMM).
   // Remapped so that XCD x takes row blocks x, x + 8, ... and walks their nx column tiles one after the other: the block is fetched
   // once per XCD that needs it.  (Whole groups of eight row blocks only; the remainder keeps the plain order.)
+  // (REMAP = false, the similarity GEMM of a few hundred query rows against many contexts: the plain order already puts the column
+  //  tile bx of every row block on XCD bx % 8 -- each block of C is fetched by one XCD, the small Q by all of them)
+  // (Four LDS buffers with three K steps in flight instead of two, for grids of at most one workgroup per CU, were measured in round 6
+  //  and changed nothing -- 256 x 8192 x 768 forward 22.9 / 23.0 us: a lone workgroup's K step is bound by its own fragment reads and
+  //  MFMAs taking turns, not by the load latency; scratch/negative/README.md.)
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  {
+  if constexpr (REMAP) {
     const int nx = gridDim.x, ngr = gridDim.y * gridDim.z;
     const int L = (bz * (int)gridDim.y + by) * nx + bx;
     const int whole = (ngr >> 3) << 3;

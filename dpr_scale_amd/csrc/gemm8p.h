@@ -991,23 +991,43 @@ __global__ __launch_bounds__(256) void g8_lse_kernel(const float* __restrict__ p
 // place, 16 bytes per thread and step: G = (P * 2^-14 * exp(strip max - lse) - onehot) * grad_scale.  The gold column gets its -1 whether
 // masked or not, as in Epi8G; a row with no unmasked column (lse = -inf) has P == 0 everywhere and gets factor 0, not NaN.
 typedef _Float16 g8_h8 __attribute__((ext_vector_type(8)));
+constexpr int kP2gMaxPart = 1024, kP2gPre = 4;
 __global__ __launch_bounds__(256) void g8_lse_p2g_kernel(const float* __restrict__ part_m, const float* __restrict__ part_s, int npart,
                                                          const float* __restrict__ gold, int M, int N, const int64_t* __restrict__ y,
                                                          int64_t y_offset, float grad_scale, float* __restrict__ lse_ws, float* __restrict__ row_lse,
                                                          float* __restrict__ row_loss, float* __restrict__ loss_ws, uint16_t* __restrict__ PG) {
   __shared__ float bc;
+  __shared__ float s_pm[kP2gMaxPart], s_ps[kP2gMaxPart];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const float* pm = part_m + (size_t)row * npart;
-  if (tid < 64) {
-    const float* ps = part_s + (size_t)row * npart;
+  const float* ps = part_s + (size_t)row * npart;
+  uint16_t* prow = PG + (size_t)row * N;
+  // Every read this workgroup can issue without knowing the logsumexp goes out first (the launch at 1024 x 8192 is three dependent
+  // trips to memory otherwise -- strip maxima, strip sums, then the numerators: 8.2 us for 32 MB): the first kP2gPre 16-byte groups of
+  // each thread, and the strip statistics into LDS.
+  uint4 raw[kP2gPre];
+#pragma unroll
+  for (int u = 0; u < kP2gPre; ++u) {
+    const int c8 = tid + u * 256;
+    if (c8 * 8 < N) raw[u] = *reinterpret_cast<const uint4*>(prow + c8 * 8);
+  }
+  const int yc = (int)(y[row] + y_offset);
+  const bool staged = npart <= kP2gMaxPart;
+  if (staged)
+    for (int k = tid; k < npart; k += 256) {
+      s_pm[k] = pm[k];
+      s_ps[k] = ps[k];
+    }
+  __syncthreads();
+  if (tid < 64) {  // (the sums in g8_lse_kernel's order: the logsumexp of the two forward plans is bit-identical)
     float mx = -INFINITY;
-    for (int k = lane; k < npart; k += 64) mx = fmaxf(mx, pm[k]);
+    for (int k = lane; k < npart; k += 64) mx = fmaxf(mx, staged ? s_pm[k] : pm[k]);
     mx = wave_max(mx);
     float sm = 0.f;
     if (mx != -INFINITY)
       for (int k = lane; k < npart; k += 64) {
-        const float m = pm[k];
-        if (m != -INFINITY) sm += ps[k] * __expf(m - mx);
+        const float m = staged ? s_pm[k] : pm[k];
+        if (m != -INFINITY) sm += (staged ? s_ps[k] : ps[k]) * __expf(m - mx);
       }
     sm = wave_sum(sm);
     if (lane == 0) {
@@ -1022,14 +1042,11 @@ __global__ __launch_bounds__(256) void g8_lse_p2g_kernel(const float* __restrict
   }
   __syncthreads();
   const float lse = bc;
-  const int yc = (int)(y[row] + y_offset);
   const float fs = grad_scale * kG8PInvScale;
-  uint16_t* prow = PG + (size_t)row * N;
-  for (int c8 = tid; c8 * 8 < N; c8 += 256) {
-    const int col = c8 * 8;
-    const uint4 raw = *reinterpret_cast<const uint4*>(prow + col);
-    const float f = lse == -INFINITY ? 0.f : __expf(pm[col >> 6] - lse) * fs;
-    const g8_h8 hv = __builtin_bit_cast(g8_h8, raw);
+  auto rescale = [&](const uint4 in, int col) {
+    const float pmv = staged ? s_pm[col >> 6] : pm[col >> 6];
+    const float f = lse == -INFINITY ? 0.f : __expf(pmv - lse) * fs;
+    const g8_h8 hv = __builtin_bit_cast(g8_h8, in);
     float g[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1037,7 +1054,13 @@ __global__ __launch_bounds__(256) void g8_lse_p2g_kernel(const float* __restrict
       if (col + j == yc) g[j] -= grad_scale;
     }
     *reinterpret_cast<uint4*>(prow + col) = make_uint4(cvt_pk_bf16(g[0], g[1]), cvt_pk_bf16(g[2], g[3]), cvt_pk_bf16(g[4], g[5]), cvt_pk_bf16(g[6], g[7]));
+  };
+#pragma unroll
+  for (int u = 0; u < kP2gPre; ++u) {
+    const int c8 = tid + u * 256;
+    if (c8 * 8 < N) rescale(raw[u], c8 * 8);
   }
+  for (int c8 = tid + kP2gPre * 256; c8 * 8 < N; c8 += 256) rescale(*reinterpret_cast<const uint4*>(prow + c8 * 8), c8 * 8);
 }
 
 // The logit of every row's gold column, bit-identical to what gemm8p_kernel accumulates for that element: one wave per 32 rows runs

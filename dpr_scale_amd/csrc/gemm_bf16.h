@@ -451,6 +451,17 @@ struct EpiSim {
     return colmask != nullptr ? colmask[n] : (uint8_t)0;
   }
 
+  // the byte alone (a load whose value nothing in begin() looks at) and what the packed layout adds to it without a load: mask_at's
+  // select on the loaded byte made begin() wait for each of its TN mask loads in turn (four trips to memory before the first tile load)
+  __device__ __forceinline__ uint8_t mask_raw(int n) const {
+    if (packed != nullptr) {
+      const int r = n / p_rows_c, j = n - r * p_rows_c;
+      return packed[(size_t)(r * p_rows_c + p_n_ctx) * p_row_bytes + min(j, p_n_ctx - 1)];
+    }
+    return colmask != nullptr ? colmask[n] : (uint8_t)0;
+  }
+  __device__ __forceinline__ bool mask_pad(int n) const { return packed != nullptr && n - (n / p_rows_c) * p_rows_c >= p_n_ctx; }
+
   // begin(): raw loads only, issued back to back BEFORE the tile loads (nothing is used here, or the compiler
   // parks one s_waitcnt per load at the top of the kernel); settle(): turned into what finish() needs, after the
   // tile loads have been issued.
@@ -470,7 +481,10 @@ struct EpiSim {
     const int i = c.lane & 15;
     State<TM, TN> st;
 #pragma unroll
-    for (int b = 0; b < TN; ++b) st.masked[b] = (c.n0 + c.wn * (BN / WN) + b * 16 + i >= N) || raw.mraw[b] != 0;
+    for (int b = 0; b < TN; ++b) {
+      const int n = c.n0 + c.wn * (BN / WN) + b * 16 + i;
+      st.masked[b] = n >= N || raw.mraw[b] != 0 || mask_pad(min(n, N - 1));
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -485,7 +499,7 @@ struct EpiSim {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int n = min(c.n0 + c.wn * (BN / WN) + b * 16 + i, N - 1);
-      st.mraw[b] = mask_at(n);
+      st.mraw[b] = mask_raw(n);
     }
 #pragma unroll
     for (int a = 0; a < TM; ++a)
@@ -578,6 +592,67 @@ struct EpiSim {
         part_m[(size_t)(c.m0 + c.tid) * c.nbx + c.bx] = mx;
         part_s[(size_t)(c.m0 + c.tid) * c.nbx + c.bx] = sm;
       }
+    }
+  }
+};
+
+// Training forward in ONE pass on the 128 x 128 tile (round 6; the 256 x 256 family's Epi8StatsP, gemm8p.h, for the shapes whose 256-wide
+// tiles would leave most of the chip idle: B = 256 .. 1024 rows against 8192 contexts are 32 .. 128 of them).  Each wave owns one
+// statistics strip of 64 columns per row: it publishes (strip max, sum exp(S - strip max)) at part[m][n / 64] and the numerators
+// exp(S - strip max) * 2^14 as fp16 into the buffer that will hold G -- the format g8_lse_p2g_kernel rescales in place.  The numerators
+// leave through the tile memory (free after the K loop): a lane holds single columns of 16 rows, the store wants 16-byte runs of a row.
+struct EpiSimP : EpiSim {
+  uint16_t* P = nullptr;  // [M][N] fp16 bit patterns
+  int npart = 0;          // strips per row: cdiv(N, 64)
+
+  template <int BM, int BN, int WM, int WN, int TM, int TN>
+  __device__ __forceinline__ void finish(f32x4 (&acc)[TM][TN], const TileCtx& c, const State<TM, TN>& st) const {
+    static_assert(TN * 16 == 64, "one 64-column statistics strip per wave");
+    constexpr int WR = TM * 16, WC = TN * 16, LDP = WC + 8;  // (row pitch 144 bytes: 16-byte aligned, the four row groups of a write on distinct banks)
+    const int i = c.lane & 15, g = c.lane >> 4;
+    uint16_t* stage = reinterpret_cast<uint16_t*>(c.scratch) + (c.wm * WN + c.wn) * WR * LDP;
+    const int mw = c.m0 + c.wm * WR, nw = c.n0 + c.wn * WC;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = a * 16 + g * 4 + r;
+        const int m = mw + lrow;
+        float v[TN];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          v[b] = st.masked[b] ? -INFINITY : acc[a][b][r] * inv_T;
+          mx = fmaxf(mx, v[b]);
+        }
+        mx = row16_max(mx);
+        const float mref = mx == -INFINITY ? 0.f : mx;
+        float sm = 0.f;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const float e = __expf(v[b] - mref);  // exp(-inf) == 0 at masked columns
+          sm += e;
+          stage[lrow * LDP + b * 16 + i] = __builtin_bit_cast(uint16_t, (_Float16)(e * 16384.f));
+        }
+        sm = row16_sum(sm);
+        if (m < M) {
+          if (i == 0 && nw < N) {
+            part_m[(size_t)m * npart + (nw >> 6)] = mx;
+            part_s[(size_t)m * npart + (nw >> 6)] = sm;
+          }
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            if (st.yi[a][r] == nw + b * 16 + i) gold[m] = v[b];
+        }
+      }
+    }
+    // (wave-private staging: program order within the wave is all the synchronisation it needs)
+#pragma unroll
+    for (int it = 0; it < WR / 8; ++it) {
+      const int row = it * 8 + (c.lane >> 3), c8 = c.lane & 7;
+      const uint4 w = *reinterpret_cast<const uint4*>(stage + row * LDP + c8 * 8);
+      const int m = mw + row, n = nw + c8 * 8;
+      if (m < M && n < N) *reinterpret_cast<uint4*>(P + (size_t)m * N + n) = w;
     }
   }
 };

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(SoftmaxArgs p) {
 // ----------------------------------------------------------------------------------------------------
 // out[0] = scale * sum(x[0..n))   single workgroup, fixed order -> deterministic
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float scale, float* out) {
+__device__ __forceinline__ void reduce_sum_body(const float* __restrict__ x, int n, float scale, float* out) {
   __shared__ float sm[4];
   float a = 0.f;
   int i = threadIdx.x;
@@ -610,22 +610,49 @@ __global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict
   __syncthreads();
   if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) * scale;
 }
+__global__ __launch_bounds__(256) void reduce_sum_kernel(const float* __restrict__ x, int n, float scale, float* out) {
+  reduce_sum_body(x, n, scale, out);
+}
 
 // ----------------------------------------------------------------------------------------------------
 // split-K combine: out[i] = scale * sum_z part[z][i]      (n4 = elements / 4)
 // ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, size_t n4, float h_scale,
-                                                            const float* d_scale, float* __restrict__ out) {
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ part, int splits, size_t n4, float h_scale, const float* d_scale,
+                                                   float* __restrict__ out, unsigned nblocks) {
   const float sc = h_scale * (d_scale ? *d_scale : 1.0f);
-  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n4; c += (size_t)gridDim.x * blockDim.x) {
-    float4 a = reinterpret_cast<const float4*>(part)[c];
-    for (int z = 1; z < splits; ++z) {
-      const float4 b = reinterpret_cast<const float4*>(part)[(size_t)z * n4 + c];
+  for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n4; c += (size_t)nblocks * blockDim.x) {
+    const float4* src = reinterpret_cast<const float4*>(part) + c;
+    float4 a = src[0];
+    int z = 1;
+    for (; z + 8 <= splits; z += 8) {  // eight slabs in flight, added in slab order (the sum is the one the plain loop forms)
+      float4 b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) b[u] = src[(size_t)(z + u) * n4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+    }
+    for (; z < splits; ++z) {
+      const float4 b = src[(size_t)z * n4];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
     a.x *= sc; a.y *= sc; a.z *= sc; a.w *= sc;
     reinterpret_cast<float4*>(out)[c] = a;
   }
+}
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int splits, size_t n4, float h_scale,
+                                                            const float* d_scale, float* __restrict__ out) {
+  splitk_reduce_body(part, splits, n4, h_scale, d_scale, out, gridDim.x);
+}
+// The same launch with one more workgroup, which sums the row losses the forward left (reduce_sum_kernel's arithmetic): the one-call
+// training step then has no loss launch of its own between its forward and its backward (round 6: 4.6 us of a 82 us step at 1024 x 8192).
+__global__ __launch_bounds__(256) void splitk_reduce_loss_kernel(const float* __restrict__ part, int splits, size_t n4, float h_scale,
+                                                                 const float* d_scale, float* __restrict__ out, const float* __restrict__ lx,
+                                                                 int ln, float lscale, float* lout) {
+  if (blockIdx.x == gridDim.x - 1) {
+    reduce_sum_body(lx, ln, lscale, lout);
+    return;
+  }
+  splitk_reduce_body(part, splits, n4, h_scale, d_scale, out, gridDim.x - 1);
 }
 
 // ----------------------------------------------------------------------------------------------------

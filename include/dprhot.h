@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 171 /* 0.1.71: + dprhot_comm_has_allpairs, dprhot_fwd_no_logits; options nl_p16, sk_dq_atomic */
+#define DPRHOT_VERSION 172 /* 0.1.72: + dprhot_fwd_one_pass; options nl128, nl128_below, loss_with_dq, dq_cap_few */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
@@ -224,6 +224,11 @@ int dprhot_step_wants_g(int B, int Nc, int d, int* h_wants);
  * big_min -- K % 128 == 0; dprhot_softmax_finish then yields logsumexp / loss only and G comes from dprhot_inbatch_fwd / dprhot_dscores),
  * 0 when the logits live in the workspace.  A pure function of the shape and the options, like every plan. */
 int dprhot_fwd_no_logits(int B, int Nc, int d, int* h_nl);
+/* How dprhot_inbatch_fwd / the one-call steps form G when the caller wants the dScores and not the logits (S_out == NULL, G != NULL):
+ * *h_kind = 0 the logits are stored (workspace) and a streaming softmax turns them into G; 1 ONE pass of the 256 x 256 GEMM (strip
+ * statistics + fp16 softmax numerators, then a row kernel that rescales them into G in place); 2 the same on the 128 x 128 LDS-DMA tile
+ * (the shapes whose 256-wide tiles would leave most of the chip idle: a few hundred query rows against thousands of contexts). */
+int dprhot_fwd_one_pass(int B, int Nc, int d, int* h_kind);
 int dprhot_inbatch_step_f32(const float* q, const float* c, dprhot_bf16* Qb, dprhot_bf16* Cb, int B, int Nc, int d,
                             const int64_t* y, int64_t y_offset, const uint8_t* colmask, float inv_T, float grad_scale,
                             float h_scale, const float* d_scale, float* S_out, float* row_loss, float* row_lse,

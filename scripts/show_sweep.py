@@ -4,7 +4,8 @@ for l in src:
     if not l.startswith('{'):
         continue
     d = json.loads(l)
-    out = 'B=%5d Nc=%6d %-9s |' % (d['B'], d['Nc'], d.get('forward_plan', ''))
+    ff = {'logits stored': 'S', 'one pass, 256 x 256 tile': 'P256', 'one pass, 128 x 128 tile': 'P128'}.get(d.get('fused_forward'), '')
+    out = 'B=%5d Nc=%6d %-9s %-4s |' % (d['B'], d['Nc'], d.get('forward_plan', ''), ff)
     for k, nm in (('prep', 'prep'), ('sim_stats_f32', 'simf32'), ('sim_stats_bf16', 'sim'), ('softmax_finish', 'fin'), ('dscores', 'dsc'), ('fwd_bf16', 'fwd'), ('bwd_pair', 'bwd'),
                   ('step', 'STEP')):
         if k in d:

@@ -1085,6 +1085,84 @@ def test_one_pass_forward_equals_the_two_pass_forward(B, Nc, d, kn, dev):
     assert ((outs[1][3].float()[fin] - ref[fin] / B).abs().max() / (ref[fin] / B).abs().max()).item() <= 2.0 ** -8
 
 
+@pytest.mark.parametrize("B,Nc,d", [(256, 8192, 768), (512, 8192, 768), (1024, 8192, 768), (300, 8200, 128), (520, 4104, 256), (136, 16392, 64)])
+def test_one_pass_forward_on_the_128_tile(B, Nc, d, kn, dev):
+    """Option nl128 (round 6): the shapes whose 256-wide tiles cannot fill the chip (a few hundred query rows against thousands of
+    contexts) run the training forward in ONE pass on the 128 x 128 LDS-DMA tile -- 64-column strip statistics + fp16 softmax numerators
+    (EpiSimP), then the row kernel that rescales them into G in place -- instead of storing fp32 logits for a streaming softmax
+    (dpr_task.py:209-212).  Against that logits-storing plan on the same operands: loss / logsumexp to fp32 rounding, G at most one bf16
+    ulp apart, masked columns exactly 0 (gold columns excepted), rows summing to ~0; against fp32 torch on the stored logits; reruns
+    bit-identical.  Half of the gold columns may be masked (loss +inf, G[gold] = -scale)."""
+    from dpr_scale_amd import _lib
+
+    assert _lib.fwd_one_pass(B, Nc, d) == 2
+    Qb, Cb, y, m8 = _nl_problem(B, Nc, d, 29, dev)
+    m8[y[B // 2:]] = 0
+    try:
+        _lib.set_option("nl128", 0)
+        _lib.set_option("nl_min", 1 << 30)  # (the reference leg stores its logits at every shape here)
+        assert _lib.fwd_one_pass(B, Nc, d) == 0
+        rl0, lse0, ls0, G0, S0 = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=True)
+    finally:
+        _lib.set_option("nl128", 1)
+        _lib.set_option("nl_min", 128)
+    rl1, lse1, ls1, G1, S1 = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
+    assert S1 is None
+    fin = torch.isfinite(rl0)
+    assert torch.equal(torch.isfinite(rl1), fin) and fin.sum().item() >= B // 2
+    assert ((lse1 - lse0).abs().max() / lse0.abs().max()).item() <= 1e-6
+    assert ((rl1[fin] - rl0[fin]).abs().max() / rl0[fin].abs().max()).item() <= 1e-5
+    assert (not math.isfinite(ls0.item()) and not math.isfinite(ls1.item())) or abs(ls1.item() - ls0.item()) <= 1e-5 * abs(ls0.item())
+    g0, g1 = G0.float(), G1.float()
+    assert ((g1 - g0).abs() <= 2.0 ** -7 * g0.abs() + 1e-12).all()
+    cols = torch.nonzero(m8).flatten()
+    keep = cols[~torch.isin(cols, y)]
+    assert torch.all(g1[:, keep] == 0)
+    ref = torch.softmax(S0, dim=1)
+    ref[torch.arange(B, device=dev), y] -= 1.0
+    assert ((g1[fin] - ref[fin] / B).abs().max() / (ref[fin] / B).abs().max()).item() <= 2.0 ** -8
+    rerun = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
+    assert torch.equal(G1, rerun[3]) and torch.equal(lse1, rerun[1]) and torch.equal(rl1, rerun[0])
+
+
+@pytest.mark.parametrize("B,Nc,d", [(1024, 8192, 768), (512, 16384, 256), (2048, 4104, 128), (4096, 4096, 256), (256, 8192, 128)])
+def test_step_forms_its_loss_in_the_slab_combining_launch(B, Nc, d, kn, dev):
+    """Option loss_with_dq (round 6): in the one-call step on the no-logits forward the sum of the row losses is formed by one more
+    workgroup of the launch that combines the dQ slabs, not by a launch of its own between forward and backward.  Same arithmetic:
+    loss, row losses, dQ and dC BIT-IDENTICAL with the option off; the loss against fp32 torch on the same operands."""
+    from dpr_scale_amd import _lib
+
+    assert _lib.fwd_one_pass(B, Nc, d) > 0  # (both tile families: 4096 x 4096 is the 256 x 256 one)
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    q = (torch.randn(B, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev)
+    c = (torch.randn(Nc, d, generator=gen) * d ** -0.25).to(torch.bfloat16).float().to(dev)
+    y = torch.randperm(Nc, generator=gen)[:B].to(dev)
+    m8 = (torch.rand(Nc, generator=gen) < 0.01).to(torch.uint8).to(dev)
+    m8[y] = 0
+    one = torch.ones(1, device=dev)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            _lib.set_option("loss_with_dq", mode)
+            Qb = torch.empty((B, d), dtype=torch.bfloat16, device=dev)
+            Cb = torch.empty((Nc, d), dtype=torch.bfloat16, device=dev)
+            outs[mode] = kn.train_step_f32(q, c, Qb, Cb, y, 0, m8, 0.5, 0.5 / B, 1.0 / B, one)
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_option("loss_with_dq", 1)
+    rl0, lse0, lo0, _, dQ0, dC0 = outs[0]
+    rl1, lse1, lo1, _, dQ1, dC1 = outs[1]
+    assert torch.equal(lo0[:1], lo1[:1]) and torch.equal(rl0, rl1) and torch.equal(lse0, lse1)
+    assert torch.equal(dQ0, dQ1) and torch.equal(dC0, dC1)
+    rq, rc = q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    S = (rq @ rc.T).masked_fill(m8.bool()[None, :], float("-inf")) * 0.5
+    ref = torch.nn.functional.cross_entropy(S, y)
+    ref.backward()  # (grad_scale = inv_T / B: the mean loss's gradient, as the operator asks for it)
+    assert abs(lo1[0].item() - ref.item()) <= LOSS_RTOL * abs(ref.item())
+    assert ((dQ1 - rq.grad).abs().max() / rq.grad.abs().max()).item() <= GRAD_RTOL
+    assert ((dC1 - rc.grad).abs().max() / rc.grad.abs().max()).item() <= GRAD_RTOL
+
+
 def test_no_logits_forward_from_fp32_inputs_and_autograd(dev):
     """The fp32 entry point and the autograd operator at a no-logits shape against fp32 torch (reference formulation,
     dpr_task.py:197-212)."""
