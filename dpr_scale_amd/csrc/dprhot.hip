@@ -131,7 +131,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_PAIR128, OPT_PAIR128_CAP, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -171,6 +171,8 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_LOSS_WITH_DQ, "loss_with_dq", 1, "one-call training step on the no-logits forward, single rank: 1 = the sum of the row losses is formed by one more workgroup of the launch that combines the dQ slabs (same arithmetic as reduce_sum_kernel) instead of a launch of its own between forward and backward; 0 = its own launch"},
     {OPT_NL128, "nl128", 1, "training forward (dScores wanted, logits not) in ONE pass on the 128 x 128 LDS-DMA tile (EpiSimP: strip statistics + fp16 softmax numerators, then the row kernel of the 256 x 256 family) where the 256-wide tiles would leave most of the chip idle: 1 = on, 0 = the logits-storing forward (sim GEMM with fp32 S, streaming softmax) there"},
     {OPT_NL128_BELOW, "nl128_below", 256, "the 128-tile one-pass forward takes the shapes with fewer 256 x 256 tiles than this (256 = every shape that cannot give each CU a 256-wide tile; 128 = only the shapes the 256 x 256 no-logits forward does not take)"},
+    {OPT_PAIR128, "pair128", 1, "backward pair (dC tiles next to split-K dQ tiles in one launch) on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): 1 = where the rule pair128_use picks it, 2 = wherever the launch qualifies (A/B), 0 = never (the register-staged pair / the 256 x 256 pair)"},
+    {OPT_PAIR128_CAP, "pair128_slices", 0, "K slices of a dQ tile in the 128 x 128 backward pair: 0 = the rule of pair128_plan, else that many (A/B)"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -476,6 +478,43 @@ DqPlan dq_plan(int B, int Nc, int d) {
   return p;
 }
 
+// The backward pair on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): whole 64-deep K steps in both problems (K = B for dC, K = Nc
+// in slices for dQ), 32-bit element offsets, the LDS transpose read for the mn-major operands.
+struct Pair128Plan { bool ok; int splits, kchunk; };
+Pair128Plan pair128_plan(int B, int Nc, int d) {
+  Pair128Plan p{};
+  p.ok = opt(OPT_PAIR128) != 0 && opt(OPT_G128_DMA) != 0 && use_tr() && force_tile() < 0 && !unfused_bwd() && B % 64 == 0 && Nc % 64 == 0 &&
+         d % 8 == 0 && B >= 64 && d >= 8 && (double)B * Nc < 4.0e9 && (double)Nc * d < 4.0e9;
+  // K slices of a dQ tile.  The dQ units lead the grid and the (shorter) dC tiles fill in behind them, so the launch is as long as the
+  // larger of one dQ unit and the chip's share of all K steps; every slice costs a slab of B x d fp32 written and read again.  Two
+  // lower bounds, the larger wins, at most 16: (balance) a dQ unit no longer than twice the per-slot average of the launch's K steps
+  // (512 slots: two workgroups per CU); (traffic is cheap) slabs up to a quarter of the dC bytes: Nc / (4 B).  Measured against 8 / 16 /
+  // 32 slices (profiles/r06_pair128_ab.txt): 256 x 8192 22.2 / 22.7 / 26.9 us, 384 x 8192 24.6 / 28.9 / 29.4, 512 x 8192 28.5 / 33.1 /
+  // 33.2, 448 x 16384 42.8 / 45.3 / 53.0, 256 x 32768 55.8 / 50.2 / 54.6.
+  const double avg = (double)B * Nc * ((d + 127) / 128 * 128) / 268435456.0;  // K steps per slot: 2 B Nc d / (128 * 128 * 64) / 512
+  int s = (int)((double)Nc / (128.0 * (avg < 1.0 ? 1.0 : avg)) + 0.999);
+  if (s < Nc / (4 * B)) s = Nc / (4 * B);
+  if (s > 16) s = 16;
+  if (opt(OPT_PAIR128_CAP) > 0) s = opt(OPT_PAIR128_CAP);
+  if (s > Nc / 256) s = Nc / 256;
+  if (s < 1) s = 1;
+  p.kchunk = cdiv(cdiv(Nc, 64), s) * 64;
+  p.splits = cdiv(Nc, p.kchunk);
+  return p;
+}
+// Where it runs (measured against the plan it replaces at 60 shapes, profiles/r06_pair128_ab.txt): under 1024 query rows everywhere, and up
+// to B x Nc = 2^25 scores above that.  Beyond, the 256 x 256 kernels keep the backward: their tiles need half the operand bytes per flop,
+// and at that size they fill the chip (8192^2: 191 against 200 us; 1024 x 65536: 258 / 295, the 128-wide tiles' pieces alias at a 128 KiB
+// row pitch; 4096 x 32768: 410 / 458) -- although 4096 x 16384 (216 / 201) and 2048 x 49152 (393 / 359) would still gain.
+// What it replaced: the register-staged pair under the 256 x 256 gate (2048 x 4096 x 768: 70 -> 39 us, 1024 x 4096 44 -> 27, 4096 x 4096
+// 86 -> 62), the 256 x 256 pair of the few-rows shapes (256 x 8192 29.7 -> 21.0, 768 x 16384 76.8 -> 57.0, 256 x 32768 76.9 -> 52.5,
+// 1024 x 16384 79.5 -> 70.3) and the two separate launches of the long axis under 512 rows (512 x 65536 184 -> 164, 128 x 32768 63 -> 37).
+bool pair128_use(int B, int Nc, int d) {
+  if (!pair128_plan(B, Nc, d).ok) return false;
+  if (opt(OPT_PAIR128) == 2) return true;
+  return B < 1024 || (double)B * Nc <= 33554432.0;
+}
+
 int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
 
 // Few query rows against many contexts (skinny.h): B <= 128 (a multiple of 32), d a multiple of 128 up to 1024, 512 (256 above 64 rows) <= Nc <= 16384
@@ -584,6 +623,10 @@ WsLayout ws_layout(int B, int Nc, int d) {
   const DqPlan p = dq_plan(B, Nc, d);
   const SkPlan sk = sk_plan(B, Nc, d);
   int slabs = sk.ok && sk.nslices > p.splits ? sk.nslices : p.splits;
+  {
+    const Pair128Plan pp = pair128_plan(B, Nc, d);
+    if (pp.ok && pp.splits > slabs) slabs = pp.splits;
+  }
   if (sk.ok && slabs < 16) slabs = 16;  // (sk_bwdp_kernel: up to 16 slices)
   if (sk.ok && slabs < cdiv(cdiv(Nc, 64), 2 * (SK_FT - 1) - 1)) slabs = cdiv(cdiv(Nc, 64), 2 * (SK_FT - 1) - 1);  // (sk_fused_plan's own slices)
   w.dq_part = off; off += align256((size_t)slabs * B * d * 4);
@@ -666,6 +709,21 @@ int launch_loss_sum(const float* src, int n, float scale, float* out, hipStream_
   return DPRHOT_OK;
 }
 
+// dQ = scale * (slab 0 + slab 1 + ...), in slab order; inside the one-call step the same launch also forms the loss sum (launch_loss_sum)
+int launch_slab_sum(const float* part, int splits, int B, int d, float h_scale, const float* d_scale, float* dQ, hipStream_t st) {
+  const size_t n4 = (size_t)B * d / 4;
+  const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
+  if (g_loss_defer.pending) {
+    g_loss_defer.pending = false;
+    hipLaunchKernelGGL(splitk_reduce_loss_kernel, dim3(blocks + 1), dim3(256), 0, st, part, splits, n4, h_scale, d_scale, dQ, g_loss_defer.src,
+                       g_loss_defer.n, g_loss_defer.scale, g_loss_defer.out);
+  } else {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, splits, n4, h_scale, d_scale, dQ);
+  }
+  HIP_TRY(hipGetLastError());
+  return DPRHOT_OK;
+}
+
 int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, float h_scale, const float* d_scale, float* dQ,
               char* ws, const WsLayout& wl, hipStream_t st, bool gemm_too) {
   DqPlan p = dq_plan(B, Nc, d);
@@ -679,19 +737,7 @@ int launch_dq(const dprhot_bf16* G, const dprhot_bf16* C, int B, int Nc, int d, 
     EpiScaleF32 epi{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
     if (int rc = launch_gemm<true, false>(p.tile, a, epi, p.splits, st)) return rc;
   }
-  if (p.splits > 1) {
-    const size_t n4 = (size_t)B * d / 4;
-    const int blocks = (int)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256);
-    if (g_loss_defer.pending) {
-      g_loss_defer.pending = false;
-      hipLaunchKernelGGL(splitk_reduce_loss_kernel, dim3(blocks + 1), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
-                         p.splits, n4, h_scale, d_scale, dQ, g_loss_defer.src, g_loss_defer.n, g_loss_defer.scale, g_loss_defer.out);
-    } else {
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float*>(ws + wl.dq_part),
-                         p.splits, n4, h_scale, d_scale, dQ);
-    }
-    HIP_TRY(hipGetLastError());
-  }
+  if (p.splits > 1) return launch_slab_sum(reinterpret_cast<const float*>(ws + wl.dq_part), p.splits, B, d, h_scale, d_scale, dQ, st);
   return DPRHOT_OK;
 }
 
@@ -1616,7 +1662,7 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
   // (round 6, with the LDS-DMA 128 x 128 tile: also 512 <= B < 1024 from Nc >= 32 B on -- 512 x 16384 56 against 65 us with the dQ units on
   //  the 256 x 256 kernel and 73 for the pair, 512 x 32768 90 / 100 / 116: profiles/r06_bwd_plan_ab.txt)
   const bool long_axis_small = ((B < 512 && Nc >= 56 * 1024) || (B >= 512 && B < 1024 && (long)Nc >= 32L * B)) && !sk_plan(B, Nc, d).ok &&
-                               !wide_bwd_ok(B, Nc, d) && big_bwd_ok(B, Nc, d);
+                               !wide_bwd_ok(B, Nc, d) && big_bwd_ok(B, Nc, d) && !pair128_use(B, Nc, d);
   if (dQ == nullptr || dC_part == nullptr || unfused_bwd() || force_tile() >= 0 || long_axis_small) {
     if (dC_part != nullptr)
       if (int rc = dprhot_dc(G, Q, B, Nc, d, h_scale, d_scale, dC_part, stream)) return rc;
@@ -1676,6 +1722,32 @@ int dprhot_inbatch_bwd(const dprhot_bf16* G, const dprhot_bf16* Q, const dprhot_
     return DPRHOT_OK;
   }
   const WsLayout wl = ws_layout(B, Nc, d);
+  if (pair128_use(B, Nc, d)) {
+    // [dC tiles | dQ tiles x K slices] on the 128 x 128 LDS-DMA tile (round 6): the shapes under the 256 x 256 gate ran this pair on the
+    // register-staged tiles (2048 x 4096 x 768: 69.5 us for 26 GFLOP)
+    const Pair128Plan pp = pair128_plan(B, Nc, d);
+    char* ws = static_cast<char*>(workspace);
+    if (pp.splits > 1 && (ws == nullptr || workspace_bytes < wl.total))
+      return fail(DPRHOT_E_WORKSPACE, "inbatch_bwd needs %zu workspace bytes, got %zu", wl.total, workspace_bytes);
+    GemmArgs a1{G, Q, Nc, d, B, Nc, d, B};
+    const EpiScaleF32 e1 = with_loss_stamp(EpiScaleF32{dC_part, Nc, d, h_scale, d_scale});
+    GemmArgs a2{G, C, B, d, Nc, Nc, d, pp.kchunk};
+    const EpiScaleF32 e2 = pp.splits == 1 ? EpiScaleF32{dQ, B, d, h_scale, d_scale}
+                                          : EpiScaleF32{reinterpret_cast<float*>(ws + wl.dq_part), B, d, 1.0f, nullptr};
+    auto kern = gemm128d_pair_kernel<EpiScaleF32>;
+    static AttrOnce attr_done;
+    if (!attr_done) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g1_lds_bytes));
+      attr_done = true;
+    }
+    const int nbx1 = cdiv(d, 128), nby1 = cdiv(Nc, 128), nbx2 = cdiv(d, 128), nby2 = cdiv(B, 128);
+    const long grid = (long)nbx1 * nby1 + (long)nbx2 * nby2 * pp.splits;
+    if (grid > 0x7fffffffL) return fail(DPRHOT_E_UNSUPPORTED, "grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), g1_lds_bytes, st, a1, e1, nbx1, nby1, a2, e2, nbx2, nby2, pp.splits);
+    HIP_TRY(hipGetLastError());
+    if (pp.splits > 1) return launch_slab_sum(reinterpret_cast<const float*>(ws + wl.dq_part), pp.splits, B, d, h_scale, d_scale, dQ, st);
+    return DPRHOT_OK;
+  }
   const DqPlan p = dq_plan(B, Nc, d);
   char* ws = static_cast<char*>(workspace);
   if (p.splits > 1 && (ws == nullptr || workspace_bytes < wl.total))

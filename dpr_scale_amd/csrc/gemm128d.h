@@ -45,36 +45,13 @@ __device__ __forceinline__ void g1_frag(bf16x8& out, bf16x4& lo, bf16x4& hi, con
   }
 }
 
-template <bool A_KM, bool B_KM, class Epi, bool REMAP = true>
-__global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+// one tile (bx, by) of K slice bz; nbx = column tiles per row block (what the statistics epilogues index their per-tile arrays with)
+template <bool A_KM, bool B_KM, class Epi>
+__device__ __forceinline__ void g1_tile(const GemmArgs& p, const Epi& epi, int bx, int by, int bz, int nbx, uint16_t* smem) {
   constexpr int TM = 4, TN = 4;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // Tile order.  Workgroup L (x fastest) runs on XCD L % 8; the nx column tiles of one row block (by, bz) read the SAME A block, and
-  // in the plain order they are neighbours in L, i.e. spread over all eight XCDs at the same time: every XCD's L2 fetches that block
-  // for itself (dC = G^T Q at 1024 x 65536 x 768: the 134 MB of G went through the fabric six times, 805 MB for a 120 us GEMM).
-  // Remapped so that XCD x takes row blocks x, x + 8, ... and walks their nx column tiles one after the other: the block is fetched
-  // once per XCD that needs it.  (Whole groups of eight row blocks only; the remainder keeps the plain order.)
-  // (REMAP = false, the similarity GEMM of a few hundred query rows against many contexts: the plain order already puts the column
-  //  tile bx of every row block on XCD bx % 8 -- each block of C is fetched by one XCD, the small Q by all of them)
-  // (Four LDS buffers with three K steps in flight instead of two, for grids of at most one workgroup per CU, were measured in round 6
-  //  and changed nothing -- 256 x 8192 x 768 forward 22.9 / 23.0 us: a lone workgroup's K step is bound by its own fragment reads and
-  //  MFMAs taking turns, not by the load latency; scratch/negative/README.md.)
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if constexpr (REMAP) {
-    const int nx = gridDim.x, ngr = gridDim.y * gridDim.z;
-    const int L = (bz * (int)gridDim.y + by) * nx + bx;
-    const int whole = (ngr >> 3) << 3;
-    if (L < nx * whole) {
-      const int xcd = L & 7, slot = L >> 3;
-      const int g = xcd + ((slot / nx) << 3);
-      bx = slot % nx;
-      by = g % (int)gridDim.y;
-      bz = g / (int)gridDim.y;
-    }
-  }
   const int m0 = by * G1_B, n0 = bx * G1_B;
   const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
   const int nt = (kend - kbeg) / G1_BK;  // (whole steps: checked by the launcher)
@@ -123,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the epilogue's own global reads first (consumed by settle() behind the first wait below), then step 0
-  const TileCtx ctx{m0, n0, wm, wn, lane, tid, bx, (int)gridDim.x, bz, reinterpret_cast<float*>(smem)};
+  const TileCtx ctx{m0, n0, wm, wn, lane, tid, bx, nbx, bz, reinterpret_cast<float*>(smem)};
   const auto eraw = epi.template begin<G1_B, G1_B, 2, 2, TM, TN>(ctx);
   if (nt > 0) stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -171,6 +148,62 @@ __global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // the epilogue reuses the tile memory as scratch
   epi.template finish<G1_B, G1_B, 2, 2, TM, TN>(acc, ctx, est);
+}
+
+// Tile order.  Workgroup L (x fastest) runs on XCD L % 8; the nx column tiles of one row block (by, bz) read the SAME A block, and
+// in the plain order they are neighbours in L, i.e. spread over all eight XCDs at the same time: every XCD's L2 fetches that block
+// for itself (dC = G^T Q at 1024 x 65536 x 768: the 134 MB of G went through the fabric six times, 805 MB for a 120 us GEMM).
+// Remapped so that XCD x takes row blocks x, x + 8, ... and walks their nx column tiles one after the other: the block is fetched
+// once per XCD that needs it.  (Whole groups of eight row blocks only; the remainder keeps the plain order.)  L: linear index inside a
+// grid of nx x ngr tiles -- a constant offset of L (the pair launch's second problem) only renames the XCDs.
+__device__ __forceinline__ void g1_remap(int L, int nx, int ngr, int& bx, int& g) {
+  const int whole = (ngr >> 3) << 3;
+  if (L < nx * whole) {
+    const int xcd = L & 7, slot = L >> 3;
+    g = xcd + ((slot / nx) << 3);
+    bx = slot % nx;
+  } else {
+    g = L / nx;
+    bx = L - g * nx;
+  }
+}
+
+template <bool A_KM, bool B_KM, class Epi, bool REMAP = true>
+__global__ __launch_bounds__(256, 2) void gemm128d_kernel(GemmArgs p, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  // (REMAP = false, the similarity GEMM of a few hundred query rows against many contexts: the plain order already puts the column
+  //  tile bx of every row block on XCD bx % 8 -- each block of C is fetched by one XCD, the small Q by all of them)
+  // (Four LDS buffers with three K steps in flight instead of two, for grids of at most one workgroup per CU, were measured in round 6
+  //  and changed nothing -- 256 x 8192 x 768 forward 22.9 / 23.0 us: a lone workgroup's K step is bound by its own fragment reads and
+  //  MFMAs taking turns, not by the load latency; scratch/negative/README.md.)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if constexpr (REMAP) {
+    int g;
+    g1_remap((bz * (int)gridDim.y + by) * (int)gridDim.x + bx, gridDim.x, gridDim.y * gridDim.z, bx, g);
+    by = g % (int)gridDim.y;
+    bz = g / (int)gridDim.y;
+  }
+  g1_tile<A_KM, B_KM>(p, epi, bx, by, bz, (int)gridDim.x, smem);
+}
+
+// The backward pair in ONE launch on this tile: [dQ tiles x K slices (problem 2: A k-major, B mn-major) | dC tiles (problem 1: A and B
+// mn-major, one K range)] -- what gemm_pair_kernel is for the register-staged tiles.  Both halves in the XCD-aware order.
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void gemm128d_pair_kernel(GemmArgs p1, Epi e1, int nbx1, int nby1, GemmArgs p2, Epi e2, int nbx2, int nby2,
+                                                               int splits2) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+  // the dQ units FIRST: where they are the longer ones (few query rows against a long context axis: K slices several times K = B) they
+  // must not be what the launch ends on
+  const int L = blockIdx.x;
+  const int n2 = nbx2 * nby2 * splits2;
+  int bx, g;
+  if (L < n2) {
+    g1_remap(L, nbx2, nby2 * splits2, bx, g);
+    g1_tile<true, false>(p2, e2, bx, g % nby2, g / nby2, nbx2, smem);
+  } else {
+    g1_remap(L - n2, nbx1, nby1, bx, g);
+    g1_tile<false, false>(p1, e1, bx, g, 0, nbx1, smem);
+  }
 }
 
 }  // namespace dprhot

@@ -1085,6 +1085,38 @@ def test_one_pass_forward_equals_the_two_pass_forward(B, Nc, d, kn, dev):
     assert ((outs[1][3].float()[fin] - ref[fin] / B).abs().max() / (ref[fin] / B).abs().max()).item() <= 2.0 ** -8
 
 
+@pytest.mark.parametrize("B,Nc,d,mode", [(1024, 4096, 768, 1), (2048, 4096, 256, 1), (512, 2048, 128, 1), (320, 4160, 768, 1), (256, 1088, 1024, 1),
+                                          (512, 8192, 768, 2), (1024, 16448, 128, 2), (64, 8192, 72, 2)])
+def test_backward_pair_on_the_lds_dma_tile(B, Nc, d, mode, kn, dev):
+    """Option pair128 (round 6, gemm128d_pair_kernel): dC tiles next to split-K dQ tiles in ONE launch on the 128 x 128 LDS-DMA tile -- the
+    plan of the shapes under the 256 x 256 gate from 256 rows on (mode 1), forced onto other shapes for A/B (mode 2: column counts of the
+    packed layout, a vector width that is no multiple of 128, 64 rows).  dC (one K range, the same MFMA order) BIT-identical to the
+    register-staged plan it replaces, dQ to fp32 rounding of a different slice count, both against fp32 torch (dpr_task.py:209-212 backward)."""
+    from dpr_scale_amd import _lib
+
+    gen = torch.Generator(device="cpu").manual_seed(B + Nc + d)
+    G = (torch.randn(B, Nc, generator=gen) * 0.01).to(torch.bfloat16).to(dev)
+    Qb = torch.randn(B, d, generator=gen).to(torch.bfloat16).to(dev)
+    Cb = torch.randn(Nc, d, generator=gen).to(torch.bfloat16).to(dev)
+    one = torch.full((1,), 0.5, device=dev)
+    outs = {}
+    try:
+        for m in (0, mode):
+            _lib.set_option("pair128", m)
+            dQ, dC = kn.inbatch_bwd(G, Qb, Cb, 2.0, one)
+            outs[m] = (dQ.clone(), dC.clone())
+    finally:
+        _lib.set_option("pair128", 1)
+    ref_dq = G.float() @ Cb.float()
+    ref_dc = G.float().t() @ Qb.float()
+    if mode == 1:  # (against the register-staged engine: the same 16 x 16 x 32 chain per element; the 256 x 256 family chains 32 x 32 x 16)
+        assert torch.equal(outs[0][1], outs[mode][1])
+    assert ((outs[mode][1] - outs[0][1]).abs().max() / ref_dc.abs().max()).item() <= 1e-5
+    assert ((outs[mode][0] - outs[0][0]).abs().max() / ref_dq.abs().max()).item() <= 1e-5
+    assert ((outs[mode][0] - ref_dq).abs().max() / ref_dq.abs().max()).item() <= 1e-3
+    assert ((outs[mode][1] - ref_dc).abs().max() / ref_dc.abs().max()).item() <= 1e-3
+
+
 @pytest.mark.parametrize("B,Nc,d", [(256, 8192, 768), (512, 8192, 768), (1024, 8192, 768), (300, 8200, 128), (520, 4104, 256), (136, 16392, 64)])
 def test_one_pass_forward_on_the_128_tile(B, Nc, d, kn, dev):
     """Option nl128 (round 6): the shapes whose 256-wide tiles cannot fill the chip (a few hundred query rows against thousands of
@@ -1520,19 +1552,21 @@ def test_cpp_autograd_node_equals_the_python_operator(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Nc,d,engine128,k256", [(1024, 49152, 768, True, True), (1024, 65536, 768, False, True), (512, 16384, 768, True, False),
-                                                     (256, 57344, 768, True, False), (2048, 65536, 768, False, True), (1024, 16384, 768, False, True),
-                                                     (2048, 32768, 768, False, True),
-                                                     # round 6: units with an ODD number of 64-deep K steps on the 256 x 256 kernel (packed-layout column
-                                                     # counts are multiples of 64, rarely of 128): dC K = 320 = 5 steps, dQ slices of 10 / 9 steps; 1025 steps
-                                                     (320, 8256, 768, False, True), (1024, 65600, 768, True, True)])
-def test_backward_over_a_very_long_context_axis(B, Nc, d, engine128, k256, kn, dev):
-    """dprhot_inbatch_bwd's plan rules for few query rows against a long context axis (round 5; re-measured in round 6 with the LDS-DMA
-    128 x 128 tile, profiles/r06_bwd_plan_ab.txt, r06_dc_alone_ab.txt):
+@pytest.mark.parametrize("B,Nc,d,engine128,k256,pair128", [(1024, 49152, 768, True, True, False), (1024, 65536, 768, False, True, False),
+                                                             (512, 16384, 768, False, False, True), (256, 57344, 768, False, False, True),
+                                                             (2048, 65536, 768, False, True, False), (1024, 16384, 768, False, False, True),
+                                                             (2048, 32768, 768, False, True, False), (128, 32768, 768, False, False, True),
+                                                             # units with an ODD number of 64-deep K steps on the 256 x 256 kernel (packed-layout column
+                                                             # counts are multiples of 64, rarely of 128): dC K = 1088 = 17 steps, dQ slices of odd length; 1025 steps
+                                                             (1088, 32832, 768, False, True, False), (1024, 65600, 768, True, True, False),
+                                                             (320, 8256, 768, False, False, True)])
+def test_backward_over_a_very_long_context_axis(B, Nc, d, engine128, k256, pair128, kn, dev):
+    """dprhot_inbatch_bwd's plan rules (round 5; re-measured in round 6 with the LDS-DMA 128 x 128 tile and its pair launch,
+    profiles/r06_bwd_plan_ab.txt, r06_dc_alone_ab.txt, r06_pair128_ab.txt):
+      B < 1024, or B x Nc <= 2^25     the pair launch on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel), long context axes included
       1024 <= B <= 2048, Nc >= 32 B   dC on the 128 x 128 tile in a launch of its own, dQ on the 256 x 256 kernel's units -- except where G's
                                       row pitch is a multiple of 128 KiB (Nc = 65536): there the dC tiles run ALONE on the 256 x 256 kernel
-      512 <= B < 1024, Nc >= 32 B     both GEMMs apart on the 128 x 128 tile (as below 512 rows from 56 Ki contexts on)
-      otherwise                       the pair launch
+      otherwise                       the 256 x 256 pair launch
     Both gradients against fp32 matmuls of the same bf16 operands, and the launches that run are the ones the rule names.  Autograd of
     dpr_task.py:98-105 into q and c."""
     from torch.profiler import ProfilerActivity, profile
@@ -1555,6 +1589,7 @@ def test_backward_over_a_very_long_context_axis(B, Nc, d, engine128, k256, kn, d
     if names:
         assert any("gemm_bf16_kernel" in n or "gemm128d_kernel" in n for n in names) == engine128, names  # (the 128 x 128 tile, either staging)
         assert any("gemm8p_bwd_kernel" in n for n in names) == k256, names
+        assert any("gemm128d_pair_kernel" in n for n in names) == pair128, names
 
 
 @pytest.mark.gpu
