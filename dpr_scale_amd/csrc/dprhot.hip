@@ -170,7 +170,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_DQ_CAP_FEW, "dq_cap_few", 0, "256 x 256 backward pair under 512 query rows: the most context slices a dQ tile is cut into; 0 = the rule (16, or 32 where 16 slices already take more than one round of the 256 CUs), else that many"},
     {OPT_LOSS_WITH_DQ, "loss_with_dq", 1, "one-call training step on the no-logits forward, single rank: 1 = the sum of the row losses is formed by one more workgroup of the launch that combines the dQ slabs (same arithmetic as reduce_sum_kernel) instead of a launch of its own between forward and backward; 0 = its own launch"},
     {OPT_NL128, "nl128", 1, "training forward (dScores wanted, logits not) in ONE pass on the 128 x 128 LDS-DMA tile (EpiSimP: strip statistics + fp16 softmax numerators, then the row kernel of the 256 x 256 family) where the 256-wide tiles would leave most of the chip idle: 1 = on, 0 = the logits-storing forward (sim GEMM with fp32 S, streaming softmax) there"},
-    {OPT_NL128_BELOW, "nl128_below", 256, "the 128-tile one-pass forward takes the shapes with fewer 256 x 256 tiles than this (256 = every shape that cannot give each CU a 256-wide tile; 128 = only the shapes the 256 x 256 no-logits forward does not take)"},
+    {OPT_NL128_BELOW, "nl128_max_tiles", 512, "the 128-tile one-pass forward takes the shapes with at most this many 128 x 128 tiles (512 = one round of two workgroups per CU; beyond, where the 256 x 256 no-logits forward qualifies, that one runs: 1536 x 8192 x 768, 768 tiles, 48.6 us against ~37)"},
     {OPT_PAIR128, "pair128", 1, "backward pair (dC tiles next to split-K dQ tiles in one launch) on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): 1 = where the rule pair128_use picks it, 2 = wherever the launch qualifies (A/B), 0 = never (the register-staged pair / the 256 x 256 pair)"},
     {OPT_PAIR128_CAP, "pair128_slices", 0, "K slices of a dQ tile in the 128 x 128 backward pair: 0 = the rule of pair128_plan, else that many (A/B)"},
 };
@@ -227,11 +227,12 @@ bool nl_ok(int M, int N, int K) {
 }
 
 // One-pass training forward on the 128 x 128 LDS-DMA tile (EpiSimP + g8_lse_p2g_kernel): more than 128 rows, whole 64-deep K steps,
-// at least half a chip of 128-wide tiles, fewer 256-wide tiles than option nl128_below; 32-bit element offsets.
+// at least half a chip of 128-wide tiles and at most one round of them (option nl128_max_tiles) unless the 256 x 256 forward does not
+// take the shape at all, fewer than 256 tiles of 256 x 256; 32-bit element offsets.
 bool nl128_ok(int M, int N, int K) {
   if (!opt(OPT_NL128) || opt(OPT_NO_NL) || !opt(OPT_G128_DMA) || !opt(OPT_NL_P16) || force_tile() >= 0) return false;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= 128 && t256 < opt(OPT_NL128_BELOW) &&
+  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= 128 && (t128 <= opt(OPT_NL128_BELOW) || !nl_ok(M, N, K)) && t256 < 256 &&
          (double)M * K < 4.0e9 && (double)N * K < 4.0e9 && (N + 63) / 64 <= 1024 * 64;
 }
 

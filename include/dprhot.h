@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define DPRHOT_VERSION 172 /* 0.1.72: + dprhot_fwd_one_pass; options nl128, nl128_below, loss_with_dq, dq_cap_few */
+#define DPRHOT_VERSION 172 /* 0.1.72: + dprhot_fwd_one_pass; options nl128, nl128_max_tiles, loss_with_dq, dq_cap_few, pair128, pair128_slices */
 
 #define DPRHOT_OK 0
 #define DPRHOT_E_INVALID (-1)     /* bad argument (NULL pointer, non-positive or misaligned size) */
