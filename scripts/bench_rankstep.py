@@ -42,7 +42,8 @@ def main():
         algo = (4 * bd + 2 * nd + 4 * bn) + 6 * bn + (2 * bn + 2 * nd + 4 * bd) + (2 * bn + 2 * bd + 4 * nd)  # SURVEY 8(d), 3-kernel design
         print(json.dumps({"B": B, "K": K, "d": d, "W": W, "Nc": hp.Nc, "step_us": round(us, 2), "loss_sum": float(hp.loss_sum.item()),
                           "algorithmic_MB": round(algo / 1e6, 2), "hbm_frac": round(algo / us * 1e-3 / 8000.0, 4),
-                          "skinny": not _lib.get_option("no_skinny"), "G_materialised": bool(hp.want_g)}), flush=True)
+                          "few_rows_plan_enabled": not _lib.get_option("no_skinny"), "fused_forward": ("logits stored", "one pass 256x256", "one pass 128x128")[_lib.fwd_one_pass(hp.B, hp.Nc, hp.d)] if hp.want_g else "few-rows plan (no dScores)",
+                          "G_materialised": bool(hp.want_g)}), flush=True)
         del hp
         torch.cuda.empty_cache()
 

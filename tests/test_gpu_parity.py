@@ -1435,7 +1435,8 @@ def test_rank_and_loss_with_a_hidden_size_that_is_not_a_multiple_of_8(kn, dev):
     assert abs(loss.item() - ref) <= LOSS_RTOL * max(1.0, abs(ref))
 
 
-@pytest.mark.parametrize("W,B,K,d", [(2, 1024, 16, 128), (2, 512, 32, 256), (8, 1024, 8, 256), (2, 1024, 16, 768), (4, 512, 16, 1024)])
+@pytest.mark.parametrize("W,B,K,d", [(2, 1024, 16, 128), (2, 512, 32, 256), (8, 1024, 8, 256), (2, 1024, 16, 768), (4, 512, 16, 1024),
+                                     (8, 256, 8, 768), (4, 384, 8, 256)])  # (the last two: the one-pass forward on the 128 x 128 tile, mask bytes and padding rows read from the packed buffer)
 def test_packed_multi_rank_step_at_a_no_logits_shape(W, B, K, d, kn, dev):
     """Large per-rank batch over several ranks, emulated on one GPU: dprhot_inbatch_step_packed_f32 then runs the no-logits forward
     with the column mask read from the gathered buffer's mask rows (Epi8Base::mask_byte, packed layout) and stamps the loss numerator
@@ -1457,7 +1458,9 @@ def test_packed_multi_rank_step_at_a_no_logits_shape(W, B, K, d, kn, dev):
         kn.pack_ctx(cs[r], ms[r].to(torch.uint8).to(dev), send)
         sends.append(send)
     Cb = torch.cat(sends, 0).contiguous()
-    assert kn._lib.workspace_bytes(B, W * rows_c, d) < B * W * rows_c * 4  # a no-logits shape
+    assert kn._lib.fwd_one_pass(B, W * rows_c, d) == (2 if B < 512 else 1)  # no logits stored in the fused forward; B >= 512 here: not in the workspace either
+    if B >= 512:
+        assert kn._lib.workspace_bytes(B, W * rows_c, d) < B * W * rows_c * 4
     colmask = torch.empty(W * rows_c, dtype=torch.uint8, device=dev)
     kn.unpack_mask(Cb, W, n_ctx, colmask)
     yd = y.to(dev)
