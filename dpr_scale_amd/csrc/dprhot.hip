@@ -131,7 +131,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_PAIR128, OPT_PAIR128_CAP, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_PAIR128, OPT_PAIR128_CAP, OPT_NL128_MIN_TILES, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -173,6 +173,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_NL128_BELOW, "nl128_max_tiles", 512, "the 128-tile one-pass forward takes the shapes with at most this many 128 x 128 tiles (512 = one round of two workgroups per CU; beyond, where the 256 x 256 no-logits forward qualifies, that one runs: 1536 x 8192 x 768, 768 tiles, 48.6 us against ~37)"},
     {OPT_PAIR128, "pair128", 1, "backward pair (dC tiles next to split-K dQ tiles in one launch) on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): 1 = where the rule pair128_use picks it, 2 = wherever the launch qualifies (A/B), 0 = never (the register-staged pair / the 256 x 256 pair)"},
     {OPT_PAIR128_CAP, "pair128_slices", 0, "K slices of a dQ tile in the 128 x 128 backward pair: 0 = the rule of pair128_plan, else that many (A/B)"},
+    {OPT_NL128_MIN_TILES, "nl128_min_tiles", 32, "fewest 128 x 128 tiles for the 128-tile one-pass forward (32 against 128, step us: 512 x 2048 44.1 -> 40.7, 768 x 2048 49.7 -> 42.5, 1024 x 1024 47.3 -> 43.5, 256 x 4096 / 192 x 4096 / 256 x 2048 level)"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -227,12 +228,12 @@ bool nl_ok(int M, int N, int K) {
 }
 
 // One-pass training forward on the 128 x 128 LDS-DMA tile (EpiSimP + g8_lse_p2g_kernel): more than 128 rows, whole 64-deep K steps,
-// at least half a chip of 128-wide tiles and at most one round of them (option nl128_max_tiles) unless the 256 x 256 forward does not
+// at least 32 128-wide tiles (option nl128_min_tiles) and at most one round of them (option nl128_max_tiles) unless the 256 x 256 forward does not
 // take the shape at all, fewer than 256 tiles of 256 x 256; 32-bit element offsets.
 bool nl128_ok(int M, int N, int K) {
   if (!opt(OPT_NL128) || opt(OPT_NO_NL) || !opt(OPT_G128_DMA) || !opt(OPT_NL_P16) || force_tile() >= 0) return false;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= 128 && (t128 <= opt(OPT_NL128_BELOW) || !nl_ok(M, N, K)) && t256 < 256 &&
+  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= opt(OPT_NL128_MIN_TILES) && (t128 <= opt(OPT_NL128_BELOW) || !nl_ok(M, N, K)) && t256 < 256 &&
          (double)M * K < 4.0e9 && (double)N * K < 4.0e9 && (N + 63) / 64 <= 1024 * 64;
 }
 

@@ -1117,7 +1117,8 @@ def test_backward_pair_on_the_lds_dma_tile(B, Nc, d, mode, kn, dev):
     assert ((outs[mode][1] - ref_dc).abs().max() / ref_dc.abs().max()).item() <= 1e-3
 
 
-@pytest.mark.parametrize("B,Nc,d", [(256, 8192, 768), (512, 8192, 768), (1024, 8192, 768), (300, 8200, 128), (520, 4104, 256), (136, 16392, 64)])
+@pytest.mark.parametrize("B,Nc,d", [(256, 8192, 768), (512, 8192, 768), (1024, 8192, 768), (300, 8200, 128), (520, 4104, 256), (136, 16392, 64),
+                                    (1024, 1024, 768), (256, 2048, 128)])
 def test_one_pass_forward_on_the_128_tile(B, Nc, d, kn, dev):
     """Option nl128 (round 6): the shapes whose 256-wide tiles cannot fill the chip (a few hundred query rows against thousands of
     contexts) run the training forward in ONE pass on the 128 x 128 LDS-DMA tile -- 64-column strip statistics + fp16 softmax numerators
