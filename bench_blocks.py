@@ -424,6 +424,41 @@ def hipblaslt_same_box(dev, d=768):
     return out
 
 
+def band_block(dev, d=768, shapes=((256, 8192), (512, 8192), (1024, 8192), (1024, 4096), (2048, 4096), (256, 32768))):
+    """Extra information (never `value`): the one-call training step (dprhot_inbatch_step_f32: fp32 embeddings in, loss / dQ / dC out) at
+    the shapes between the BASELINE configs and 8192^2 -- a few hundred to a few thousand query rows against thousands of contexts on one
+    GPU (SURVEY 8(d)'s sweep rows; profiles/r06_sweep.jsonl holds the full table).  Each shape is CHECKED before it is timed: loss, dQ and
+    dC against fp32 torch autograd on the same bf16-rounded operands (dpr_task.py:197-212); an unchecked shape reports no time."""
+    from dpr_scale_amd import _lib
+
+    out = {"timing": "HIP events around 20 steps per graph replay x 5, as time_kernel", "unit": "us per step", "shapes": {}}
+    for B, Nc in shapes:
+        hp = HotPathStep(B, Nc // B, d, 1.0, 1, 0, dev)
+        hp.k_step()
+        torch.cuda.synchronize()
+        q = hp.q.to(torch.bfloat16).float().requires_grad_(True)
+        c = hp.c.to(torch.bfloat16).float().requires_grad_(True)
+        S = (q @ c.T).masked_fill(hp.mask_all.bool()[None, :], float("-inf")) * hp.inv_T
+        ref = torch.nn.functional.cross_entropy(S, hp.y, reduction="sum")
+        (ref * (hp.gscale / hp.inv_T)).backward()
+        go = float(hp.go.item())
+        err = {"loss": abs(float(hp.loss_sum.item()) - float(ref.item())) / abs(float(ref.item())),
+               "dQ": float((hp.dQ - q.grad * go).abs().max() / (q.grad * go).abs().max()),
+               "dC": float((hp.dC - c.grad * go).abs().max() / (c.grad * go).abs().max())}
+        ok = err["loss"] <= 1e-3 and err["dQ"] <= 1e-2 and err["dC"] <= 1e-2
+        row = {"checked": bool(ok), "check_errors": {k: float("%.3g" % v) for k, v in err.items()},
+               "forward": ("logits stored", "one pass, 256 x 256 tile", "one pass, 128 x 128 tile")[_lib.fwd_one_pass(B, Nc, d)]}
+        if ok:
+            us = time_kernel(hp, hp.k_step, reps=20, iters=5)
+            bn, bd, nd = float(B) * Nc, float(B) * d, float(Nc) * d
+            by = (4 * bd + 4 * nd) + (2 * (bd + nd) + 4 * bn) + 4 * bn + 6 * (bd + nd)  # bench_sweep.py's step bytes (SURVEY 8(d): G written once, read twice)
+            row.update({"step_us": round(us, 2), "hbm_floor_us": round(by / (HBM_PEAK_GBS * 1e3), 2), "mfma_frac": round(6.0 * B * Nc * d / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)})
+        out["shapes"]["%dx%d" % (B, Nc)] = row
+        del hp, q, c, S, ref
+        torch.cuda.empty_cache()
+    return out
+
+
 def check_at_scale(hp, S_full, k_simfwd):
     """What roofline_at_scale times, verified BEFORE it is timed (the 0.40 / 0.36 / 0.43 figures were of unverified work).
     Every launch of the block runs once on the block's own operands; fp32 torch on the SAME bf16 operands is the checker
