@@ -56,11 +56,13 @@ def parse():
     ap.add_argument("--negatives", type=int, default=7)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--temperature", type=float, default=1.0)
-    ap.add_argument("--driver", choices=["auto", "graph", "graph10", "eager"], default="eager",
-                    help="issue mechanism behind `value`: eager (default) = one C-ABI call per step from a prepared argument block, what a C / "
-                         "C++ binding of include/dprhot.h pays (the Python autograd operator pays more on the host: `operator` block); "
-                         "graph / graph10 = HIP graphs of 1 / 10 steps; auto = the fastest of the three.  The mechanisms not chosen are "
-                         "measured too and reported in other_driver")
+    ap.add_argument("--driver", choices=["auto", "graph", "graph10", "eager"], default="auto",
+                    help="issue mechanism behind `value`: auto (default) = the fastest median of the three below, named in config.driver; "
+                         "eager = one C-ABI call per step from a prepared argument block, what a C / C++ binding of include/dprhot.h pays "
+                         "(the Python autograd operator pays more on the host: `operator` block) -- within 1 us of host-bound at cfg2, it "
+                         "moves between 9.2 and 11.5 us per step with the host core the process landed on; graph / graph10 = HIP graphs "
+                         "of 1 / 10 steps (graph10 is device-bound: 9.3 us on every box).  The mechanisms not chosen are measured too and "
+                         "reported in other_driver")
     ap.add_argument("--only", default="", help="comma list of the extra blocks to run (default: all but e2e5): operator, torch_gpu, scale, rank, "
                                                "router, grad_hook, cpu, e2e, model (scaling_model), e2e5 (BASELINE configs[4]: bert-large "
                                                "towers, seq 512, B 64 -- minutes); `step` = none of them (the contract line alone)")
@@ -531,8 +533,8 @@ def main():
         runs["graph"] = (capture(hp, hp.step), 1)
         runs["graph10"] = (capture(hp, hp.step, 10), 10)
         # every mechanism gets the full measurement (W warmup steps, R regions of exactly K steps).  `value` is the one --driver
-        # names: eager by default -- one C-ABI call per step is what a binding and the Lightning task do; the others ride in
-        # `other_driver` (auto = the best median of the three).
+        # names: auto by default = the best median of the three (round 6: the eager loop's pace is the host core's -- 9.2 us on one
+        # box, 11.1 on the next, same kernels -- and the 10-step graph's is the device's); the others ride in `other_driver`.
         measured = {name: measure(fn, per, hp.step) for name, (fn, per) in runs.items()}
         med = {name: sorted(v)[len(v) // 2] for name, v in measured.items()}
         if driver == "auto":
