@@ -612,6 +612,9 @@ struct EpiSimP : EpiSim {
     const int i = c.lane & 15, g = c.lane >> 4;
     uint16_t* stage = reinterpret_cast<uint16_t*>(c.scratch) + (c.wm * WN + c.wn) * WR * LDP;
     const int mw = c.m0 + c.wm * WR, nw = c.n0 + c.wn * WC;
+    // After the row reductions all 16 lanes of a row group hold the row's (max, sum): lane i keeps those of row (a, r) = (i >> 2, i & 3)
+    // of its group, and the strip statistics leave in ONE store per array and lane instead of 32 four-lane stores per wave.
+    float keep_m = -INFINITY, keep_s = 0.f;
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -635,15 +638,24 @@ struct EpiSimP : EpiSim {
           stage[lrow * LDP + b * 16 + i] = __builtin_bit_cast(uint16_t, (_Float16)(e * 16384.f));
         }
         sm = row16_sum(sm);
-        if (m < M) {
-          if (i == 0 && nw < N) {
-            part_m[(size_t)m * npart + (nw >> 6)] = mx;
-            part_s[(size_t)m * npart + (nw >> 6)] = sm;
-          }
+        if (i == a * 4 + r) {
+          keep_m = mx;
+          keep_s = sm;
+        }
+        // the gold logit: only a row whose label falls into this wave's 64 columns looks at them
+        const int rel = st.yi[a][r] - nw - i;  // == b * 16 for the lane that holds the gold column
+        if ((rel & ~48) == 0 && m < M) {
 #pragma unroll
           for (int b = 0; b < TN; ++b)
-            if (st.yi[a][r] == nw + b * 16 + i) gold[m] = v[b];
+            if (rel == b * 16) gold[m] = v[b];
         }
+      }
+    }
+    {
+      const int m = mw + (i >> 2) * 16 + g * 4 + (i & 3);
+      if (TM * 4 > i && m < M && nw < N) {
+        part_m[(size_t)m * npart + (nw >> 6)] = keep_m;
+        part_s[(size_t)m * npart + (nw >> 6)] = keep_s;
       }
     }
     // (wave-private staging: program order within the wave is all the synchronisation it needs)
