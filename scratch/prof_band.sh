@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-for sh in 256x8192 512x8192 1024x8192 2048x8192; do
+for sh in ${SHAPES:-256x8192 512x8192 1024x8192 2048x4096}; do
   rm -rf /tmp/pb
   cat > /tmp/pb_run.py <<PY
 import sys, os
