@@ -1156,6 +1156,15 @@ def test_one_pass_forward_on_the_128_tile(B, Nc, d, kn, dev):
     assert ((g1[fin] - ref[fin] / B).abs().max() / (ref[fin] / B).abs().max()).item() <= 2.0 ** -8
     rerun = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
     assert torch.equal(G1, rerun[3]) and torch.equal(lse1, rerun[1]) and torch.equal(rl1, rerun[0])
+    # no column mask at all (colmask == NULL), against fp32 torch
+    rl2, lse2, ls2, G2, _ = kn.inbatch_fwd(Qb, Cb, y, 0, None, 0.5, 1.0 / B, want_logits=False)
+    S2 = (Qb.float() @ Cb.float().t()) * 0.5
+    ref_lse = torch.logsumexp(S2, dim=1)
+    assert ((lse2 - ref_lse).abs().max() / ref_lse.abs().max()).item() <= 1e-5
+    ref2 = torch.softmax(S2, dim=1)
+    ref2[torch.arange(B, device=dev), y] -= 1.0
+    assert ((G2.float() - ref2 / B).abs().max() / (ref2 / B).abs().max()).item() <= 2.0 ** -8
+    assert abs(ls2.item() - (ref_lse - S2[torch.arange(B, device=dev), y]).sum().item()) <= 1e-4 * abs(ls2.item())
 
 
 @pytest.mark.parametrize("B,Nc,d", [(1024, 8192, 768), (512, 16384, 256), (2048, 4104, 128), (4096, 4096, 256), (256, 8192, 128)])
