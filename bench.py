@@ -610,10 +610,10 @@ def main():
         if not DM and "grad_hook" in a.blocks:
             extra("grad_hook", lambda: BB.grad_hook_block(dev))
         if not DM and "scale" in a.blocks:
+            if d % 64 == 0:  # (before the 8192^2 block: these short steps read 3-4 us longer right behind its minutes of power-limited GEMMs)
+                extra("band", lambda: BB.band_block(dev, d))
             out["roofline_at_scale"] = BB.roofline_at_scale(dev, d)
             extra("hipblaslt_same_box", lambda: BB.hipblaslt_same_box(dev, d))
-            if d % 64 == 0:
-                extra("band", lambda: BB.band_block(dev, d))
         if not DM and "model" in a.blocks and d % 128 == 0 and not os.environ.get("DPRHOT_FORCE_DIST"):
             extra("scaling_model", lambda: BB.scaling_model(dev, d))
         if not DM and "rank" in a.blocks and d % 128 == 0:
