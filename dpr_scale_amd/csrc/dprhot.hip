@@ -514,6 +514,9 @@ Pair128Plan pair128_plan(int B, int Nc, int d) {
 bool pair128_use(int B, int Nc, int d) {
   if (!pair128_plan(B, Nc, d).ok) return false;
   if (opt(OPT_PAIR128) == 2) return true;
+  // (not under 2048 contexts -- 1024 with at most 512 rows: a dozen 128-wide tiles lose to the smaller register-staged ones there,
+  //  128 x 128 5.8 against 3.8 us, 512 x 512 12.6 / 11.6, 1024 x 1024 19.8 / 18.9; 512 x 1024 14.7 / 17.2 and 512 x 2048 15.8 / 21.1 win)
+  if (Nc < 1024 || (Nc < 2048 && B > 512)) return false;
   return B < 1024 || (double)B * Nc <= 33554432.0;
 }
 
