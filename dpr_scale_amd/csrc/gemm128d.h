@@ -16,7 +16,8 @@
 // hipcc would answer a plain LDS read next to an LDS-DMA in flight with s_waitcnt vmcnt(0) and drain the step it was meant to overlap.
 //
 // Restrictions (the launcher checks them and falls back to gemm_bf16_kernel): bf16 operands, every K range a whole number of 64-deep
-// steps (a DMA cannot zero the tail of a step), operands addressable with 32-bit element offsets.
+// steps (a DMA cannot zero the tail of a step; the one exception, dQ's context axis, is in g1_tile), operands addressable with 32-bit
+// element offsets.
 #pragma once
 #include "gemm256.h"
 
@@ -24,6 +25,8 @@ namespace dprhot {
 
 constexpr int G1_B = 128, G1_BK = 64, G1_IMG = G1_B * G1_BK;  // elements of one operand image (16 KiB)
 constexpr size_t g1_lds_bytes = (size_t)4 * G1_IMG * 2;       // 2 buffers x {A, B}
+
+__device__ const uint4 g1_zero16 = {0u, 0u, 0u, 0u};  // what the rows of a partial K step beyond K are read from
 
 __device__ __forceinline__ unsigned g1_lds_addr(const void* p) {
   typedef __attribute__((address_space(3))) int lds_int;
@@ -54,7 +57,12 @@ __device__ __forceinline__ void g1_tile(const GemmArgs& p, const Epi& epi, int b
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = by * G1_B, n0 = bx * G1_B;
   const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const int nt = (kend - kbeg) / G1_BK;  // (whole steps: checked by the launcher)
+  // Whole 64-deep steps (checked by the launcher) -- except for A k-major x B mn-major (dQ = G x C, K = the context axis), where the last
+  // step of the last slice may be partial (K a multiple of 8): its missing rows of B are read from 16 zero bytes, its missing chunks of A
+  // from the step before (any finite values: they meet zeros).  A DMA cannot zero-fill, but it can be pointed at zeros.
+  constexpr bool KTAIL = A_KM && !B_KM;
+  const int tail = KTAIL ? ((kend - kbeg) & (G1_BK - 1)) : 0;
+  const int nt = (kend - kbeg + (KTAIL ? G1_BK - 1 : 0)) / G1_BK;
 
   // per-lane source offsets (elements) of this wave's four pieces per operand image; piece j of wave w is LDS bytes [(w * 4 + j) KiB, +1 KiB)
   unsigned oa[4], ob[4];
@@ -85,6 +93,23 @@ __device__ __forceinline__ void g1_tile(const GemmArgs& p, const Epi& epi, int b
     uint16_t* Bs = As + G1_IMG;
     const uint16_t* a = Ag + (size_t)t * astep;
     const uint16_t* b = Bg + (size_t)t * bstep;
+    if constexpr (KTAIL) {
+      if (tail != 0 && t == nt - 1) {  // the partial step (at most once per launch and workgroup)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pc = wave * 4 + j, r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+          const uint16_t* src = a + oa[j] - (c * 8 < tail ? 0 : G1_BK);
+          __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)src, (g2_lds_ptr*)(As + (wave * 4 + j) * 512), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = (wave * 4 + j) * 4 + (lane >> 4);
+          const uint16_t* src = k < tail ? b + ob[j] : reinterpret_cast<const uint16_t*>(&g1_zero16);
+          __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)src, (g2_lds_ptr*)(Bs + (wave * 4 + j) * 512), 16, 0, 0);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)(a + oa[j]), (g2_lds_ptr*)(As + (wave * 4 + j) * 512), 16, 0, 0);
