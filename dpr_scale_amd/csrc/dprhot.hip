@@ -480,13 +480,13 @@ DqPlan dq_plan(int B, int Nc, int d) {
   return p;
 }
 
-// The backward pair on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): whole 64-deep K steps for dC (K = B), slices of whole steps for
-// dQ (K = Nc: any multiple of 8 -- the packed layout of 2 or 4 ranks is rarely a multiple of 64 -- the last step may be partial, g1_tile),
+// The backward pair on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): dC over K = B (any count above 64: the last step may be partial,
+// g1_tile), dQ over K = Nc in slices of whole steps (any multiple of 8 -- the packed layout of 2 or 4 ranks is rarely a multiple of 64),
 // 32-bit element offsets, the LDS transpose read for the mn-major operands.
 struct Pair128Plan { bool ok; int splits, kchunk; };
 Pair128Plan pair128_plan(int B, int Nc, int d) {
   Pair128Plan p{};
-  p.ok = opt(OPT_PAIR128) != 0 && opt(OPT_G128_DMA) != 0 && use_tr() && force_tile() < 0 && !unfused_bwd() && B % 64 == 0 && Nc % 8 == 0 &&
+  p.ok = opt(OPT_PAIR128) != 0 && opt(OPT_G128_DMA) != 0 && use_tr() && force_tile() < 0 && !unfused_bwd() && Nc % 8 == 0 &&
          d % 8 == 0 && B >= 64 && d >= 8 && (double)B * Nc < 4.0e9 && (double)Nc * d < 4.0e9;
   // K slices of a dQ tile.  The dQ units lead the grid and the (shorter) dC tiles fill in behind them, so the launch is as long as the
   // larger of one dQ unit and the chip's share of all K steps; every slice costs a slab of B x d fp32 written and read again.  Two

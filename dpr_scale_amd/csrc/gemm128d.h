@@ -57,10 +57,10 @@ __device__ __forceinline__ void g1_tile(const GemmArgs& p, const Epi& epi, int b
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = by * G1_B, n0 = bx * G1_B;
   const int kbeg = bz * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  // Whole 64-deep steps (checked by the launcher) -- except for A k-major x B mn-major (dQ = G x C, K = the context axis), where the last
-  // step of the last slice may be partial (K a multiple of 8): its missing rows of B are read from 16 zero bytes, its missing chunks of A
-  // from the step before (any finite values: they meet zeros).  A DMA cannot zero-fill, but it can be pointed at zeros.
-  constexpr bool KTAIL = A_KM && !B_KM;
+  // Whole 64-deep steps (checked by the launcher) -- except with B mn-major (its K index is a row), where the last step of the last slice
+  // may be partial: the missing rows of B are read from 16 zero bytes, the missing chunks (k-major A: K a multiple of 8) or rows (mn-major
+  // A) of A from the step before -- any finite values: they meet zeros.  A DMA cannot zero-fill, but it can be pointed at zeros.
+  constexpr bool KTAIL = !B_KM;  // (B mn-major: dQ = G x C over the contexts, dC = G^T x Q over the query rows)
   const int tail = KTAIL ? ((kend - kbeg) & (G1_BK - 1)) : 0;
   const int nt = (kend - kbeg + (KTAIL ? G1_BK - 1 : 0)) / G1_BK;
 
@@ -97,8 +97,14 @@ __device__ __forceinline__ void g1_tile(const GemmArgs& p, const Epi& epi, int b
       if (tail != 0 && t == nt - 1) {  // the partial step (at most once per launch and workgroup)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int pc = wave * 4 + j, r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-          const uint16_t* src = a + oa[j] - (c * 8 < tail ? 0 : G1_BK);
+          const int pc = wave * 4 + j;
+          const uint16_t* src = a + oa[j];
+          if constexpr (A_KM) {
+            const int r = pc * 8 + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+            if (c * 8 >= tail) src -= G1_BK;
+          } else {
+            if (pc * 4 + (lane >> 4) >= tail) src -= astep;
+          }
           __builtin_amdgcn_global_load_lds((g2_gbl_ptr*)src, (g2_lds_ptr*)(As + (wave * 4 + j) * 512), 16, 0, 0);
         }
 #pragma unroll

@@ -1089,7 +1089,9 @@ def test_one_pass_forward_equals_the_two_pass_forward(B, Nc, d, kn, dev):
                                           (512, 8192, 768, 2), (1024, 16448, 128, 2), (64, 8192, 72, 2),
                                           # context counts that are multiples of 8, not of 64 (the packed layout of 2 or 4 ranks): the last K step of
                                           # the last dQ slice is partial (8 .. 56 contexts deep)
-                                          (512, 4128, 768, 1), (256, 2080, 768, 1), (512, 2064, 256, 1), (320, 4104, 128, 1), (1024, 4152, 768, 1)])
+                                          (512, 4128, 768, 1), (256, 2080, 768, 1), (512, 2064, 256, 1), (320, 4104, 128, 1), (1024, 4152, 768, 1),
+                                          # query rows that are no multiple of 64: the last K step of the dC tiles is partial
+                                          (160, 4096, 768, 1), (300, 8200, 128, 1), (1000, 4104, 256, 1), (100, 2048, 768, 1), (65, 2056, 64, 1)])
 def test_backward_pair_on_the_lds_dma_tile(B, Nc, d, mode, kn, dev):
     """Option pair128 (round 6, gemm128d_pair_kernel): dC tiles next to split-K dQ tiles in ONE launch on the 128 x 128 LDS-DMA tile -- the
     plan of the shapes under the 256 x 256 gate from 256 rows on (mode 1), forced onto other shapes for A/B (mode 2: column counts of the
