@@ -329,7 +329,8 @@ int launch_gemm(int tile, const GemmArgs& a, const Epi& epi, int splits, hipStre
   }
   constexpr bool needs_tr = !(AK && BKM);
   const bool tr = needs_tr ? use_tr() : false;
-  if (tile == 0 && opt(OPT_G128_DMA) != 0 && (tr || !needs_tr) && a.K % 64 == 0 && a.kchunk % 64 == 0 && a.M >= 8 && a.N >= 8 &&
+  // (K: whole 64-deep steps -- or, with B mn-major, any K from 64 on (a multiple of 8 when A is k-major): the partial last step is read against zeros, g1_tile)
+  if (tile == 0 && opt(OPT_G128_DMA) != 0 && (tr || !needs_tr) && (a.K % 64 == 0 || (!BKM && a.K >= 64 && (!AK || a.K % 8 == 0))) && a.kchunk % 64 == 0 && a.M >= 8 && a.N >= 8 &&
       (double)(AK ? a.M : a.K) * a.lda < 4.0e9 && (double)(BKM ? a.N : a.K) * a.ldb < 4.0e9) {  // (32-bit element offsets inside one K range)
     // the same tile with LDS-DMA staging (gemm128d.h): same images, same fragments, same epilogues
     auto kern = gemm128d_kernel<AK, BKM, Epi>;

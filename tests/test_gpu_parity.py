@@ -1611,7 +1611,7 @@ def test_backward_over_a_very_long_context_axis(B, Nc, d, engine128, k256, pair1
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Nc,d", [(512, 16384, 768), (320, 8200, 512), (1024, 32768, 1024), (192, 4096, 128)])
+@pytest.mark.parametrize("B,Nc,d", [(512, 16384, 768), (320, 8200, 512), (1024, 32768, 1024), (192, 4096, 128), (300, 4104, 256)])  # (the last: partial last K steps in dQ and dC)
 def test_lds_dma_staged_128_tile_is_bit_identical(B, Nc, d, kn, dev):
     """Option g128_dma (round 6, csrc/gemm128d.h): the 128 x 128 x 64 tile of the GEMM engine with its operands staged by LDS-DMA instead
     of global -> VGPR -> ds_write.  Same LDS images, same fragments, same MFMA order, same epilogues: dQ = G x C (A k-major, B mn-major),
