@@ -519,7 +519,9 @@ bool pair128_use(int B, int Nc, int d) {
   // (not under 2048 contexts -- 1024 with at most 512 rows: a dozen 128-wide tiles lose to the smaller register-staged ones there,
   //  128 x 128 5.8 against 3.8 us, 512 x 512 12.6 / 11.6, 1024 x 1024 19.8 / 18.9; 512 x 1024 14.7 / 17.2 and 512 x 2048 15.8 / 21.1 win)
   if (Nc < 1024 || (Nc < 2048 && B > 512)) return false;
-  return B < 1024 || (double)B * Nc <= 33554432.0;
+  // (above the bound only the shapes the 256 x 256 pair does not take -- row or column counts that are no multiples of 64: they would run
+  //  on the register-staged pair, 2000 x 32000 x 768: 448 against 262 us)
+  return B < 1024 || (double)B * Nc <= 33554432.0 || !big_bwd_ok(B, Nc, d);
 }
 
 int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
