@@ -228,12 +228,13 @@ bool nl_ok(int M, int N, int K) {
 }
 
 // One-pass training forward on the 128 x 128 LDS-DMA tile (EpiSimP + g8_lse_p2g_kernel): more than 128 rows, whole 64-deep K steps,
-// at least 32 128-wide tiles (option nl128_min_tiles) and at most one round of them (option nl128_max_tiles) unless the 256 x 256 forward does not
-// take the shape at all, fewer than 256 tiles of 256 x 256; 32-bit element offsets.
+// at least 32 128-wide tiles (option nl128_min_tiles); where the 256 x 256 forward qualifies too, at most one round of them (option
+// nl128_max_tiles) and fewer than 256 tiles of 256 x 256 -- where it does not (K a multiple of 64 but not of 128), every size; 32-bit
+// element offsets.
 bool nl128_ok(int M, int N, int K) {
   if (!opt(OPT_NL128) || opt(OPT_NO_NL) || !opt(OPT_G128_DMA) || !opt(OPT_NL_P16) || force_tile() >= 0) return false;
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= opt(OPT_NL128_MIN_TILES) && (t128 <= opt(OPT_NL128_BELOW) || !nl_ok(M, N, K)) && t256 < 256 &&
+  return M > 128 && K % 64 == 0 && K >= 64 && N % 8 == 0 && N >= 1024 && t128 >= opt(OPT_NL128_MIN_TILES) && (!nl_ok(M, N, K) || (t128 <= opt(OPT_NL128_BELOW) && t256 < 256)) &&
          (double)M * K < 4.0e9 && (double)N * K < 4.0e9 && (N + 63) / 64 <= 1024 * 64;
 }
 

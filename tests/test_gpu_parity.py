@@ -1123,7 +1123,7 @@ def test_backward_pair_on_the_lds_dma_tile(B, Nc, d, mode, kn, dev):
 
 
 @pytest.mark.parametrize("B,Nc,d", [(256, 8192, 768), (512, 8192, 768), (1024, 8192, 768), (300, 8200, 128), (520, 4104, 256), (136, 16392, 64),
-                                    (1024, 1024, 768), (256, 2048, 128)])
+                                    (1024, 1024, 768), (256, 2048, 128), (2048, 8192, 192)])  # (the last: K = 3 steps of 64 -- the 256 x 256 forward wants multiples of 128 -- at 1024 tiles)
 def test_one_pass_forward_on_the_128_tile(B, Nc, d, kn, dev):
     """Option nl128 (round 6): the shapes whose 256-wide tiles cannot fill the chip (a few hundred query rows against thousands of
     contexts) run the training forward in ONE pass on the 128 x 128 LDS-DMA tile -- 64-column strip statistics + fp16 softmax numerators
