@@ -131,7 +131,7 @@ struct AttrOnce {
 // ---- explicit process-wide options (dprhot_set_option): test and A/B switches of the plans.  Production never sets one; they replace
 // the environment switches the library used to cache on first use (hidden configuration behind an ABI that advertises none).
 enum OptId { OPT_TILE, OPT_NO_TR, OPT_UNFUSED_BWD, OPT_BIG_MIN, OPT_NO_NL, OPT_NO_BIG_BWD, OPT_NO_SKINNY, OPT_NO_SMALL_STEP, OPT_NO_SHORT,
-             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_PAIR128, OPT_PAIR128_CAP, OPT_NL128_MIN_TILES, OPT_COUNT };
+             OPT_SK_COLS, OPT_SEARCH_UNFUSED, OPT_NO_8PB, OPT_NO_WIDE, OPT_WIDE_NOCOPY, OPT_NO_8P_STORE, OPT_NO_WIDE_BWD, OPT_NT_STORES, OPT_SK_DQ_SLICES, OPT_SK_FUSED, OPT_SK_DBG, OPT_SK_W8, OPT_SK_PAIR, OPT_SK_SIM_W8, OPT_SK_SIM_PRIV, OPT_SK_TAIL, OPT_SK_DC_REGSCALE, OPT_G8_ONE_TILE, OPT_NL_P16, OPT_SK_DQ_ATOMIC, OPT_NL_MIN, OPT_G128_DMA, OPT_DC_ALONE_8P, OPT_DQ_ONE_ROUND, OPT_DQ_CAP_FEW, OPT_LOSS_WITH_DQ, OPT_NL128, OPT_NL128_BELOW, OPT_PAIR128, OPT_PAIR128_CAP, OPT_NL128_MIN_TILES, OPT_P16_STAGED, OPT_COUNT };
 struct OptDef { OptId id; const char* name; int def; const char* what; };
 constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_TILE, "tile", -1, "0..5 pins the tile of the single-GEMM launches (gemm_bf16.h), -1 = plan"},
@@ -174,6 +174,7 @@ constexpr OptDef kOptDefs[OPT_COUNT] = {
     {OPT_PAIR128, "pair128", 1, "backward pair (dC tiles next to split-K dQ tiles in one launch) on the 128 x 128 LDS-DMA tile (gemm128d_pair_kernel): 1 = where the rule pair128_use picks it, 2 = wherever the launch qualifies (A/B), 0 = never (the register-staged pair / the 256 x 256 pair)"},
     {OPT_PAIR128_CAP, "pair128_slices", 0, "K slices of a dQ tile in the 128 x 128 backward pair: 0 = the rule of pair128_plan, else that many (A/B)"},
     {OPT_NL128_MIN_TILES, "nl128_min_tiles", 32, "fewest 128 x 128 tiles for the 128-tile one-pass forward (32 against 128, step us: 512 x 2048 44.1 -> 40.7, 768 x 2048 49.7 -> 42.5, 1024 x 1024 47.3 -> 43.5, 256 x 4096 / 192 x 4096 / 256 x 2048 level)"},
+    {OPT_P16_STAGED, "p16_staged", 1, "one-pass forward on the 256 x 256 kernel: the fp16 numerators leave through the per-wave LDS patch (64-byte pieces of 16 rows per store instruction instead of 32-byte pieces of 32 rows; bit-identical): 1 = except where the row pitch of G is a multiple of 128 KiB (forward us, arms alternating, profiles/r06_p16_staged_ab.txt: 8192^2 155.4 -> 147.8, 4096 x 8192 83.2 -> 79.3, 4096 x 16384 153 -> 146 and its step 390 -> 372; at 65536 columns the forward gains nothing and the step of 8192 x 65536 LOSES 100 us of 2880), 2 = always, 0 = never"},
 };
 constexpr bool opt_table_in_enum_order() {  // (round 6: a row added in the wrong place made two options answer to each other's names)
   for (int i = 0; i < OPT_COUNT; ++i)
@@ -1622,7 +1623,12 @@ int dprhot_inbatch_fwd(const dprhot_bf16* Q, int B, const dprhot_bf16* C, int Nc
     epi.npart = cdiv(Nc, G2_B) * 4;
     epi.P = G;
     GemmArgs a8{Q, C, B, Nc, d, d, d, d};
-    if (int rc = launch_g8<Epi8StatsP, 2>(a8, epi, st)) return rc;  // (two-phase schedule, as every storing epilogue; the four-phase instantiation spilled two registers)
+    if (opt(OPT_P16_STAGED) == 2 || (opt(OPT_P16_STAGED) == 1 && ((size_t)Nc * 2) % ((size_t)128 << 10) != 0)) {
+      Epi8StatsPS es;
+      static_cast<Epi8Stats&>(es) = static_cast<const Epi8Stats&>(epi);
+      es.P = G;
+      if (int rc = launch_g8<Epi8StatsPS, 2>(a8, es, st)) return rc;
+    } else if (int rc = launch_g8<Epi8StatsP, 2>(a8, epi, st)) return rc;  // (two-phase schedule, as every storing epilogue; the four-phase instantiation spilled two registers)
     hipLaunchKernelGGL(g8_lse_p2g_kernel, dim3((unsigned)B), dim3(256), 0, st, epi.part_m, epi.part_s, epi.npart,
                        reinterpret_cast<const float*>(ws + wl.gold), B, Nc, y, y_offset, grad_scale, reinterpret_cast<float*>(ws + wl.lse), row_lse, row_loss,
                        reinterpret_cast<float*>(ws + wl.rloss), G);

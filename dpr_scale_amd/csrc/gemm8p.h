@@ -586,7 +586,15 @@ __device__ __forceinline__ unsigned g8_cvt_pk_f16(float a, float b) {  // one v_
   v[1] = (_Float16)b;
   return __builtin_bit_cast(unsigned, v);
 }
-struct Epi8StatsP : Epi8Stats {
+typedef unsigned g8_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void g8_lds_write2(void* p, unsigned a, unsigned b) {
+  const g8_u32x2 v = {a, b};
+  asm volatile("ds_write_b64 %0, %1" ::"v"(g8_lds_addr(p)), "v"(v) : "memory");
+}
+// STAGED: the numerators leave through the wave's LDS patch, half a strip of sixteen rows at a time -- every store instruction writes
+// 64-byte pieces of 16 rows instead of 32-byte pieces of 32 rows; else straight from the registers.
+template <bool STAGED>
+struct Epi8StatsPT : Epi8Stats {
   uint16_t* P;  // [M][N] fp16 bit patterns
   __device__ __forceinline__ void finish(G8Acc& acc, const Tile8& t) const {
     meta_fix(t);
@@ -619,7 +627,7 @@ struct Epi8StatsP : Epi8Stats {
       const int m = t.m0 + t.wm * 128 + a * 32 + i;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        unsigned pk[4][2];  // run q: two dwords = 4 fp16 = columns q*8 + h*4 ..
+        unsigned pk[4][2];  // run q: two dwords = 4 fp16 = columns b*32 + q*8 + h*4 ..
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -630,13 +638,33 @@ struct Epi8StatsP : Epi8Stats {
             const f32x2 es = e * psc;
             pk[q][u] = g8_cvt_pk_f16(es[0], es[1]);
           }
-        // lanes i and i + 32 trade half-runs: every lane stores whole 16-byte runs (Epi8G, guide T21)
+        if constexpr (STAGED) {
+          // half a strip (32 columns = 64 bytes of a row) of sixteen rows at a time through the wave's LDS patch
+          constexpr int TSH = 40;  // halfs per patch row (80 bytes: 16-byte aligned reads; the 32 writers of a pass land on distinct banks)
+          uint16_t* const patch = reinterpret_cast<uint16_t*>(t.scratch + (t.wm * 4 + t.wn) * (8 * 68));
+          const int rr = t.lane >> 2, c4 = t.lane & 3;
+          const int n = t.n0 + t.wn * 64 + b * 32 + c4 * 8;
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
-          const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
-          const int n = t.n0 + t.wn * 64 + b * 32 + (2 * pr + h) * 8;
-          if (m < sim.M && n < sim.N) *reinterpret_cast<uint4*>(P + (size_t)m * sim.N + n) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+          for (int grp = 0; grp < 2; ++grp) {
+            if ((i >> 4) == grp) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) g8_lds_write2(patch + (i & 15) * TSH + q * 8 + h * 4, pk[q][0], pk[q][1]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const g8_i32x4 w = g8_lds_read4(patch + rr * TSH + c4 * 8);
+            const int mm = t.m0 + t.wm * 128 + a * 32 + grp * 16 + rr;
+            if (mm < sim.M && n < sim.N)
+              *reinterpret_cast<uint4*>(P + (size_t)mm * sim.N + n) = make_uint4((unsigned)w[0], (unsigned)w[1], (unsigned)w[2], (unsigned)w[3]);
+          }
+        } else {
+          // lanes i and i + 32 trade half-runs: every lane stores whole 16-byte runs (Epi8G, guide T21)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const auto w0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+            const auto w1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+            const int n = t.n0 + t.wn * 64 + b * 32 + (2 * pr + h) * 8;
+            if (m < sim.M && n < sim.N) *reinterpret_cast<uint4*>(P + (size_t)m * sim.N + n) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
+          }
         }
       }
       const float sm = g8_sum_x32(sm2[0] + sm2[1]);
@@ -663,6 +691,8 @@ struct Epi8StatsP : Epi8Stats {
     }
   }
 };
+using Epi8StatsP = Epi8StatsPT<false>;
+using Epi8StatsPS = Epi8StatsPT<true>;
 
 // Backward, first half (autograd of dpr_task.py:211-212 into the scores): the logits are recomputed (same GEMM, bit-identical
 // accumulators) and leave the tile as G = (softmax - onehot) * grad_scale in bf16, 2 bytes per score instead of the 4 + 4 + 2 of

@@ -1210,6 +1210,29 @@ def test_step_forms_its_loss_in_the_slab_combining_launch(B, Nc, d, kn, dev):
     assert ((dC1 - rc.grad).abs().max() / rc.grad.abs().max()).item() <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("B,Nc,d", [(4096, 4096, 768), (4100, 4360, 768), (1024, 32768, 1024), (1000, 16392, 128)])
+def test_one_pass_forward_numerators_through_the_lds_patch(B, Nc, d, kn, dev):
+    """Option p16_staged: the fp16 numerators of the 256 x 256 one-pass forward leave through the per-wave LDS patch (64-byte pieces of 16
+    rows per store instruction) instead of straight from the registers (32-byte pieces of 32 rows).  Same values, another way out: G,
+    logsumexp, row losses and the loss sum BIT-identical, ragged rows / columns included."""
+    from dpr_scale_amd import _lib
+
+    assert _lib.fwd_one_pass(B, Nc, d) == 1
+    Qb, Cb, y, m8 = _nl_problem(B, Nc, d, 53, dev)
+    outs = {}
+    default = _lib.get_option("p16_staged")
+    try:
+        for mode in (0, 2):
+            _lib.set_option("p16_staged", mode)
+            outs[mode // 2] = kn.inbatch_fwd(Qb, Cb, y, 0, m8, 0.5, 1.0 / B, want_logits=False)
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_option("p16_staged", default)
+    for k in (0, 1, 3):
+        assert torch.equal(outs[0][k], outs[1][k])
+    assert torch.equal(outs[0][2], outs[1][2]) or (not math.isfinite(outs[0][2].item()) and not math.isfinite(outs[1][2].item()))
+
+
 def test_no_logits_forward_from_fp32_inputs_and_autograd(dev):
     """The fp32 entry point and the autograd operator at a no-logits shape against fp32 torch (reference formulation,
     dpr_task.py:197-212)."""
