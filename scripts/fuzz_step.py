@@ -75,6 +75,8 @@ def main():
         eq = 0.0 if eq <= 4 * ((q32 - q64).abs().max() / dq_den).item() else eq
         ec = 0.0 if ec <= 4 * ((c32 - c64).abs().max() / dc_den).item() else ec
         worst = (max(worst[0], el), max(worst[1], eq), max(worst[2], ec))
+        if os.environ.get("FUZZ_VERBOSE") or max(eq, ec) > 5e-3:  # (half the bar: worth a line)
+            print(f"  case {case}: B={B} K={K} d={d} T={T}: loss rel {el:.2e}, dQ {eq:.2e}, dC {ec:.2e}", flush=True)
         if not (el <= 1e-3 and eq <= 1e-2 and ec <= 1e-2) or not torch.isfinite(loss):
             bad += 1
             print(f"MISMATCH case {case}: B={B} K={K} d={d} T={T}: loss rel {el:.2e}, dQ {eq:.2e}, dC {ec:.2e}")
