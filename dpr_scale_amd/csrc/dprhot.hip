@@ -523,7 +523,16 @@ bool pair128_use(int B, int Nc, int d) {
   if (Nc < 1024 || (Nc < 2048 && B > 512)) return false;
   // (above the bound only the shapes the 256 x 256 pair does not take -- row or column counts that are no multiples of 64: they would run
   //  on the register-staged pair, 2000 x 32000 x 768: 448 against 262 us)
-  return B < 1024 || (double)B * Nc <= 33554432.0 || !big_bwd_ok(B, Nc, d);
+  if (B < 1024 || !big_bwd_ok(B, Nc, d)) return true;
+  if ((double)B * Nc > 33554432.0) return false;
+  // From 1024 rows on the 256 x 256 pair keeps the shapes whose units fill whole rounds of the 256 CUs: with d = 1024 (four column tiles)
+  // 1024 x 8192, 2048 x 8192 and 4096 x 8192 are exactly 256 units and 2048 x 16384 is 512 -- 48.9 / 73.2 / 124.9 / 141.2 us against 55.7 /
+  // 91.8 / 132.4 / 148.5 on the 128-wide pair -- where d = 768 leaves them at 192 / 384 units, three quarters of a round (tie, tie, tie,
+  // 124 -> 111 for the 128-wide pair): profiles/r06_pair128_dim_ab.txt.
+  const DqPlan p8 = dq_plan(B, Nc, d);
+  const long u8 = ((long)cdiv(Nc, 256) + (long)cdiv(B, 256) * p8.splits) * cdiv(d, 256);
+  const long rounds = (u8 + kNumCU - 1) / kNumCU;
+  return u8 * 10 < rounds * kNumCU * 9;  // (fill below 0.9)
 }
 
 int dc_tile(int B, int Nc, int d) { return ((long)cdiv(Nc, 128) * cdiv(d, 128) >= kNumCU) ? 0 : 2; }
